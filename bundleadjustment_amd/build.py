@@ -1,0 +1,72 @@
+"""In-tree build of the native libraries (no cmake: two compiler invocations).
+
+    python -m bundleadjustment_amd.build [--force]
+
+libba_host.so : g++   bundleadjustment_amd/host/ba_host.cpp
+libba_gpu.so  : hipcc --offload-arch=gfx950 bundleadjustment_amd/csrc/*.hip  (cross-compiles without a GPU)
+ba_main       : g++   bundleadjustment_amd/host/ba_main.cpp, linked against both
+"""
+import glob
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+INC = os.path.join(ROOT, "include")
+HOST_SO = os.path.join(PKG, "libba_host.so")
+GPU_SO = os.path.join(PKG, "libba_gpu.so")
+MAIN_BIN = os.path.join(PKG, "ba_main")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+
+
+def build_host(force=False):
+    src = [os.path.join(PKG, "host", "ba_host.cpp")]
+    deps = src + glob.glob(os.path.join(INC, "*.h"))
+    if force or _stale(HOST_SO, deps):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", INC] + src + ["-o", HOST_SO])
+    return HOST_SO
+
+
+def build_gpu(force=False):
+    src = sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")))
+    deps = src + glob.glob(os.path.join(PKG, "csrc", "*.h")) + glob.glob(os.path.join(INC, "*.h"))
+    if force or _stale(GPU_SO, deps):
+        hipcc = os.path.join(ROCM, "bin", "hipcc")
+        _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+              "-Wall", "-Wno-unused-function", "-I", INC, "-I", os.path.join(PKG, "csrc")] + src +
+             ["-L", os.path.join(ROCM, "lib"), "-lrccl", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-o", GPU_SO])
+    return GPU_SO
+
+
+def build_main(force=False):
+    src = [os.path.join(PKG, "host", "ba_main.cpp")]
+    if not os.path.exists(src[0]):
+        return None
+    if force or _stale(MAIN_BIN, src + [HOST_SO, GPU_SO]):
+        _run(["g++", "-O2", "-std=c++17", "-Wall", "-I", INC] + src +
+             ["-L", PKG, "-lba_host", "-lba_gpu", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(ROCM, "lib"),
+              "-o", MAIN_BIN])
+    return MAIN_BIN
+
+
+def build_all(force=False):
+    build_host(force)
+    build_gpu(force)
+    build_main(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,642 @@
+// ba_host.cpp -- file readers/writers, index maps, priors, fixed/free selection, sigma0 and
+// the synthetic network generator.  Interface and reference line citations: include/ba_host.h.
+#include "ba_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <random>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+const double kPi = 3.141592653589793238462643383279502884197169399;  // src/main.cpp:39
+const double kApScale = 1000.0;                                       // src/main.cpp:55
+
+}  // namespace
+
+struct ba_network {
+  // .pho (src/main.cpp:3058-3059)
+  std::vector<int32_t> imageTarget, imageStation;
+  std::vector<double> imageX, imageY, imageXStdDev, imageYStdDev, imageXCorr, imageYCorr;
+  // .eop (:3151-3153)
+  std::vector<int32_t> eopStation, eopCamera;
+  std::vector<double> EOP;  // 6 per station: omega,phi,kappa (rad), Xo,Yo,Zo
+  // .iop (:3541-3544)
+  std::vector<int32_t> iopCamera, iopAxis;
+  std::vector<double> iopXMin, iopYMin, iopXMax, iopYMax;
+  std::vector<double> IOP;  // 3 per camera
+  std::vector<double> AP;   // 16 per camera
+  // .xyz (:3655-3657)
+  std::vector<int32_t> xyzTarget;
+  std::vector<double> XYZ, xyzPrior, xyzStdDev;  // 3 per point
+  // derived
+  std::vector<int32_t> indexPoint, indexPose, staSensor;
+  std::vector<double> iopPrior, iopStdDev;
+  std::vector<uint16_t> apFree;
+  std::vector<uint8_t> iopFree;
+  // truth (synthetic only)
+  std::vector<double> tEOP, tXYZ, tIOP, tAP;
+};
+
+namespace {
+
+// Token reader with the end-of-file behaviour of the reference's extraction loops: `hit_eof`
+// becomes true as soon as an extraction touches the end of the stream, which is what
+// `inp.eof()` reports at src/main.cpp:3082, 3185, 3608, 3679.
+struct Reader {
+  std::ifstream in;
+  bool bad = false;
+  explicit Reader(const char *path) : in(path) {}
+  bool ok() const { return in.is_open(); }
+  template <class T>
+  void get(T &v) {
+    if (bad) return;
+    in >> v;
+    if (in.fail() && !in.eof()) bad = true;  // malformed token: the reference would spin forever
+  }
+  bool eof() const { return in.eof(); }
+};
+
+int read_pho(const char *path, ba_network &n) {
+  Reader r(path);
+  if (!r.ok()) return fail(BA_ERR_INVALID, "cannot open %s", path);
+  while (true) {  // src/main.cpp:3061-3084
+    int c1 = 0, c2 = 0;
+    double c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0, c8 = 0;
+    r.get(c1); r.get(c2); r.get(c3); r.get(c4); r.get(c5); r.get(c6); r.get(c7); r.get(c8);
+    if (r.bad) return fail(BA_ERR_INVALID, "%s: malformed token near record %zu", path, n.imageTarget.size());
+    n.imageTarget.push_back(c1); n.imageStation.push_back(c2);
+    n.imageX.push_back(c3); n.imageY.push_back(c4);
+    n.imageXStdDev.push_back(c5); n.imageYStdDev.push_back(c6);
+    n.imageXCorr.push_back(c7); n.imageYCorr.push_back(c8);
+    if (r.eof()) break;
+  }
+  n.imageTarget.pop_back(); n.imageStation.pop_back();  // :3086-3094
+  n.imageX.pop_back(); n.imageY.pop_back(); n.imageXStdDev.pop_back(); n.imageYStdDev.pop_back();
+  n.imageXCorr.pop_back(); n.imageYCorr.pop_back();
+  return 0;
+}
+
+int read_eop(const char *path, ba_network &n) {
+  Reader r(path);
+  if (!r.ok()) return fail(BA_ERR_INVALID, "cannot open %s", path);
+  while (true) {  // :3154-3187
+    int c1 = 0, c2 = 0;
+    double c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0, c8 = 0;
+    r.get(c1); r.get(c2); r.get(c3); r.get(c4); r.get(c5); r.get(c6); r.get(c7); r.get(c8);
+    if (r.bad) return fail(BA_ERR_INVALID, "%s: malformed token near record %zu", path, n.eopStation.size());
+    c6 *= kPi / 180.0;  // :3161-3163
+    c7 *= kPi / 180.0;
+    c8 *= kPi / 180.0;
+    n.eopStation.push_back(c1); n.eopCamera.push_back(c2);
+    const double e[6] = {c6, c7, c8, c3, c4, c5};  // :3177-3182
+    n.EOP.insert(n.EOP.end(), e, e + 6);
+    if (r.eof()) break;
+  }
+  n.eopStation.pop_back(); n.eopCamera.pop_back();
+  n.EOP.resize(n.EOP.size() - 6);
+  return 0;
+}
+
+int read_iop(const char *path, ba_network &n) {
+  Reader r(path);
+  if (!r.ok()) return fail(BA_ERR_INVALID, "cannot open %s", path);
+  while (true) {  // :3545-3610
+    int c1 = 0, c2 = 0;
+    double c[26] = {0};
+    r.get(c1); r.get(c2);
+    for (int k = 3; k <= 25; ++k) r.get(c[k]);
+    if (r.bad) return fail(BA_ERR_INVALID, "%s: malformed token near record %zu", path, n.iopCamera.size());
+    n.iopCamera.push_back(c1); n.iopAxis.push_back(c2);
+    n.iopXMin.push_back(c[3]); n.iopYMin.push_back(c[4]); n.iopXMax.push_back(c[5]); n.iopYMax.push_back(c[6]);
+    n.IOP.insert(n.IOP.end(), c + 7, c + 10);   // xp yp c  :3581-3583
+    n.AP.insert(n.AP.end(), c + 10, c + 26);    // a1 a2 k1 k2 k3 p1 p2 ep1..ep9  :3588-3604
+    if (r.eof()) break;
+  }
+  n.iopCamera.pop_back(); n.iopAxis.pop_back();
+  n.iopXMin.pop_back(); n.iopYMin.pop_back(); n.iopXMax.pop_back(); n.iopYMax.pop_back();
+  n.IOP.resize(n.IOP.size() - 3);
+  n.AP.resize(n.AP.size() - 16);
+  return 0;
+}
+
+int read_xyz(const char *path, ba_network &n) {
+  Reader r(path);
+  if (!r.ok()) return fail(BA_ERR_INVALID, "cannot open %s", path);
+  while (true) {  // :3658-3681
+    int c1 = 0;
+    double c[8] = {0};
+    r.get(c1);
+    for (int k = 2; k <= 7; ++k) r.get(c[k]);
+    if (r.bad) return fail(BA_ERR_INVALID, "%s: malformed token near record %zu", path, n.xyzTarget.size());
+    n.xyzTarget.push_back(c1);
+    n.XYZ.insert(n.XYZ.end(), c + 2, c + 5);
+    n.xyzStdDev.insert(n.xyzStdDev.end(), c + 5, c + 8);
+    if (r.eof()) break;
+  }
+  n.xyzTarget.pop_back();
+  n.XYZ.resize(n.XYZ.size() - 3);
+  n.xyzStdDev.resize(n.xyzStdDev.size() - 3);
+  return 0;
+}
+
+int first_match(const int32_t *ids, int32_t n_ids, const int32_t *keys, int32_t n_keys, int32_t *out) {
+  std::unordered_map<int32_t, int32_t> first;
+  first.reserve(static_cast<size_t>(n_ids) * 2 + 1);
+  for (int32_t i = 0; i < n_ids; ++i) first.emplace(ids[i], i);  // emplace keeps the first occurrence
+  int missing = 0;
+  for (int32_t n = 0; n < n_keys; ++n) {
+    auto it = first.find(keys[n]);
+    if (it == first.end()) {
+      out[n] = n_ids;
+      ++missing;
+    } else {
+      out[n] = it->second;
+    }
+  }
+  return missing;
+}
+
+// index maps, priors and default fixed/free selection once the four tables are filled
+int finish(ba_network &n) {
+  const int32_t N = static_cast<int32_t>(n.imageTarget.size());
+  const int32_t S = static_cast<int32_t>(n.eopStation.size());
+  const int32_t P = static_cast<int32_t>(n.xyzTarget.size());
+  const int32_t C = static_cast<int32_t>(n.iopCamera.size());
+  n.indexPoint.resize(N);
+  n.indexPose.resize(N);
+  n.staSensor.resize(S);
+  // src/main.cpp:3821-3831
+  if (first_match(n.xyzTarget.data(), P, n.imageTarget.data(), N, n.indexPoint.data()))
+    return fail(BA_ERR_INVALID, "an image observation names a target id that is not in the .xyz file");
+  if (first_match(n.eopStation.data(), S, n.imageStation.data(), N, n.indexPose.data()))
+    return fail(BA_ERR_INVALID, "an image observation names a station id that is not in the .eop file");
+  if (first_match(n.iopCamera.data(), C, n.eopCamera.data(), S, n.staSensor.data()))
+    return fail(BA_ERR_INVALID, "a station names a camera id that is not in the .iop file");
+  n.xyzPrior = n.XYZ;  // the .xyz coordinates are both the start value (:3674) and the prior mean (:4598)
+  n.iopPrior = n.IOP;  // :4628
+  n.iopStdDev.resize(3 * static_cast<size_t>(C));
+  for (int32_t c = 0; c < C; ++c) {  // :4612-4623
+    n.iopStdDev[3 * c] = 10.0;
+    n.iopStdDev[3 * c + 1] = 10.0;
+    n.iopStdDev[3 * c + 2] = 1.0E3;
+  }
+  if (n.apFree.size() != static_cast<size_t>(C)) n.apFree.assign(C, uint16_t(1u << 2));  // only k1 free, :4487-4504
+  if (n.iopFree.size() != static_cast<size_t>(C)) n.iopFree.assign(C, uint8_t(7));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic generator
+// ---------------------------------------------------------------------------------------------
+struct Rng {
+  std::mt19937_64 g;
+  explicit Rng(uint64_t s) : g(s) {}
+  double uni() { return (g() >> 11) * (1.0 / 9007199254740992.0); }
+  double uni(double a, double b) { return a + (b - a) * uni(); }
+  double normal() {
+    double u1 = uni(), u2 = uni();
+    if (u1 < 1e-300) u1 = 1e-300;
+    return std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * kPi * u2);
+  }
+};
+
+void rotation(const double *e, double R[9]) {  // src/main.cpp:1325-1335
+  const double so = std::sin(e[0]), co = std::cos(e[0]), sp = std::sin(e[1]), cp = std::cos(e[1]);
+  const double sk = std::sin(e[2]), ck = std::cos(e[2]);
+  R[0] = cp * ck; R[1] = co * sk + so * sp * ck; R[2] = so * sk - co * sp * ck;
+  R[3] = -cp * sk; R[4] = co * ck - so * sp * sk; R[5] = so * ck + co * sp * sk;
+  R[6] = sp; R[7] = -so * cp; R[8] = co * cp;
+}
+
+// distortion at normalised image coordinates (src/main.cpp:1371-1376)
+void distortion(const double *ap, double xb, double yb, double &dx, double &dy) {
+  const double rr = xb * xb + yb * yb;
+  double pw[14];
+  pw[0] = 1.0;
+  for (int k = 1; k < 14; ++k) pw[k] = pw[k - 1] * rr;
+  const double G = ap[2] * pw[1] + ap[3] * pw[2] + ap[4] * pw[3] + ap[7] * pw[4] + ap[8] * pw[5] + ap[9] * pw[6] +
+                   ap[10] * (pw[7] + pw[8]) + ap[11] * pw[9] + ap[12] * pw[10] + ap[13] * pw[11] + ap[14] * pw[12] +
+                   ap[15] * pw[13];
+  dx = xb * G + ap[5] * (rr + 2.0 * xb * xb) + 2.0 * ap[6] * xb * yb + ap[0] * xb + ap[1] * yb;
+  dy = yb * G + ap[6] * (rr + 2.0 * yb * yb) + 2.0 * ap[5] * xb * yb;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ba_host_last_error(void) { return g_err.c_str(); }
+
+int ba_index_first_match(const int32_t *ids, int32_t n_ids, const int32_t *keys, int32_t n_keys, int32_t *out) {
+  if (n_ids < 0 || n_keys < 0 || (!ids && n_ids) || (!keys && n_keys) || (!out && n_keys))
+    return fail(BA_ERR_INVALID, "ba_index_first_match: bad arguments");
+  const int missing = first_match(ids, n_ids, keys, n_keys, out);
+  if (missing) return fail(BA_ERR_INVALID, "%d key(s) not found", missing);
+  return 0;
+}
+
+int ba_net_read(const char *pho, const char *eop, const char *iop, const char *xyz, ba_network **out) {
+  if (!pho || !eop || !iop || !xyz || !out) return fail(BA_ERR_INVALID, "ba_net_read: null argument");
+  ba_network *n = new ba_network();
+  int rc = read_pho(pho, *n);
+  if (!rc) rc = read_eop(eop, *n);
+  if (!rc) rc = read_iop(iop, *n);
+  if (!rc) rc = read_xyz(xyz, *n);
+  if (!rc) rc = finish(*n);
+  if (rc) {
+    delete n;
+    return rc;
+  }
+  *out = n;
+  return 0;
+}
+
+void ba_synth_default(ba_synth_config *c) {
+  std::memset(c, 0, sizeof *c);
+  c->n_cam = 1;
+  c->n_sta = 24;
+  c->n_pts = 500;
+  c->rays_per_point = 20;
+  c->seed = 0xBA5EBA11ull;
+  c->ap_free_mask = 0x7F;  // a1 a2 k1 k2 k3 p1 p2
+  c->iop_free_mask = 7;
+  c->empirical_terms = 0;
+  c->noise_sigma = 0.5;
+  c->outlier_fraction = 0.01;
+  c->control_sigma = 10.0;
+  c->free_sigma = 1.0e4;
+  c->control_every = 64;
+  c->perfect_start = 0;
+}
+
+int ba_net_synth(const ba_synth_config *cfg, ba_network **out) {
+  if (!cfg || !out) return fail(BA_ERR_INVALID, "ba_net_synth: null argument");
+  const int32_t C = cfg->n_cam, S = cfg->n_sta, P = cfg->n_pts;
+  if (C < 1 || S < 1 || P < 1 || cfg->rays_per_point < 1) return fail(BA_ERR_INVALID, "ba_net_synth: sizes must be positive");
+  const int32_t K = std::min(cfg->rays_per_point, S);
+  if (static_cast<int64_t>(P) * K > 2000000000LL) return fail(BA_ERR_INVALID, "ba_net_synth: too many observations");
+  ba_network *n = new ba_network();
+  Rng rng(cfg->seed);
+
+  // cameras: image units are pixels, sensor about +-2000 px
+  n->tIOP.resize(3 * static_cast<size_t>(C));
+  n->tAP.assign(16 * static_cast<size_t>(C), 0.0);
+  for (int32_t c = 0; c < C; ++c) {
+    n->iopCamera.push_back(1 + c);
+    n->iopAxis.push_back(1);
+    n->iopXMin.push_back(-2000.0); n->iopYMin.push_back(-2000.0);
+    n->iopXMax.push_back(2000.0); n->iopYMax.push_back(2000.0);
+    n->tIOP[3 * c] = rng.uni(-5, 5);
+    n->tIOP[3 * c + 1] = rng.uni(-5, 5);
+    n->tIOP[3 * c + 2] = 3000.0;
+    double *a = &n->tAP[16 * static_cast<size_t>(c)];
+    a[0] = 1e-2; a[1] = 1e-2; a[2] = 0.5; a[3] = -0.02; a[4] = 5e-4; a[5] = 0.05; a[6] = 0.05;
+    if (cfg->empirical_terms) { a[7] = 1e-5; a[10] = 1e-8; }
+    // parameters that stay fixed keep their true value out of the model: zero them so that the
+    // network is consistent with what will be estimated
+    for (int k = 0; k < 16; ++k)
+      if (!(cfg->ap_free_mask & (1u << k))) a[k] = 0.0;
+  }
+
+  // stations: a gx x gy grid of cells of size D at height H, each looking obliquely at its cell centre
+  const double H = 10000.0;
+  const double D = 0.3 * H / std::sqrt(K / kPi);
+  const int32_t gx = static_cast<int32_t>(std::ceil(std::sqrt(static_cast<double>(S))));
+  n->tEOP.resize(6 * static_cast<size_t>(S));
+  for (int32_t s = 0; s < S; ++s) {
+    const int32_t ix = s % gx, iy = s / gx;
+    const double cx = (ix + 0.5) * D, cy = (iy + 0.5) * D;
+    const double om = rng.uni(-15, 15) * kPi / 180.0, ph = rng.uni(-15, 15) * kPi / 180.0;
+    const double ka = rng.uni(-kPi, kPi);
+    const double h = H * rng.uni(0.9, 1.1);
+    const double t = h / (std::cos(om) * std::cos(ph));
+    double *e = &n->tEOP[6 * static_cast<size_t>(s)];
+    e[0] = om; e[1] = ph; e[2] = ka;
+    e[3] = cx + t * std::sin(ph) + rng.uni(-0.1, 0.1) * D;
+    e[4] = cy - t * std::sin(om) * std::cos(ph) + rng.uni(-0.1, 0.1) * D;
+    e[5] = h;
+    n->eopStation.push_back(101 + s);
+    n->eopCamera.push_back(1 + s % C);
+  }
+
+  // points and their observing stations: the K stations whose cell centres are nearest
+  n->tXYZ.resize(3 * static_cast<size_t>(P));
+  std::vector<int32_t> obsSta(static_cast<size_t>(P) * K);
+  {
+    std::vector<std::pair<double, int32_t>> cand;
+    const int32_t gy = (S + gx - 1) / gx;
+    for (int32_t j = 0; j < P; ++j) {
+      const int32_t home = static_cast<int32_t>(rng.uni() * S) % S;
+      const int32_t hx = home % gx, hy = home / gx;
+      const double X = (hx + rng.uni()) * D, Y = (hy + rng.uni()) * D, Z = rng.uni(-0.1, 0.1) * H;
+      n->tXYZ[3 * static_cast<size_t>(j)] = X;
+      n->tXYZ[3 * static_cast<size_t>(j) + 1] = Y;
+      n->tXYZ[3 * static_cast<size_t>(j) + 2] = Z;
+      int32_t w = static_cast<int32_t>(std::ceil(std::sqrt(static_cast<double>(K)) / 2.0)) + 1;
+      for (;;) {
+        cand.clear();
+        for (int32_t iy = std::max(0, hy - w); iy <= std::min(gy - 1, hy + w); ++iy)
+          for (int32_t ix = std::max(0, hx - w); ix <= std::min(gx - 1, hx + w); ++ix) {
+            const int32_t s = iy * gx + ix;
+            if (s >= S) continue;
+            const double dx = (ix + 0.5) * D - X, dy = (iy + 0.5) * D - Y;
+            cand.emplace_back(dx * dx + dy * dy, s);
+          }
+        if (static_cast<int32_t>(cand.size()) >= K || (w >= gx && w >= gy)) break;
+        ++w;
+      }
+      std::sort(cand.begin(), cand.end());
+      for (int32_t k = 0; k < K; ++k) obsSta[static_cast<size_t>(j) * K + k] = cand[k].second;
+      n->xyzTarget.push_back(1001 + j);
+    }
+  }
+
+  // .pho rows in station-major order (image by image), points ascending inside an image
+  const int64_t N = static_cast<int64_t>(P) * K;
+  std::vector<int64_t> start(S + 1, 0);
+  for (int64_t q = 0; q < N; ++q) start[obsSta[q] + 1]++;
+  for (int32_t s = 0; s < S; ++s) start[s + 1] += start[s];
+  n->imageTarget.resize(N); n->imageStation.resize(N);
+  n->imageX.resize(N); n->imageY.resize(N);
+  n->imageXStdDev.assign(N, cfg->noise_sigma); n->imageYStdDev.assign(N, cfg->noise_sigma);
+  n->imageXCorr.assign(N, 0.0); n->imageYCorr.assign(N, 0.0);
+  {
+    std::vector<int64_t> fill(start.begin(), start.end() - 1);
+    std::vector<double> R(9 * static_cast<size_t>(S));
+    for (int32_t s = 0; s < S; ++s) rotation(&n->tEOP[6 * static_cast<size_t>(s)], &R[9 * static_cast<size_t>(s)]);
+    for (int32_t j = 0; j < P; ++j)
+      for (int32_t k = 0; k < K; ++k) {
+        const int32_t s = obsSta[static_cast<size_t>(j) * K + k];
+        const int64_t row = fill[s]++;
+        const double *e = &n->tEOP[6 * static_cast<size_t>(s)], *r = &R[9 * static_cast<size_t>(s)];
+        const double *p = &n->tXYZ[3 * static_cast<size_t>(j)];
+        const int32_t c = s % C;
+        const double *io = &n->tIOP[3 * static_cast<size_t>(c)], *a = &n->tAP[16 * static_cast<size_t>(c)];
+        const double dX = p[0] - e[3], dY = p[1] - e[4], dZ = p[2] - e[5];
+        const double Xc = r[0] * dX + r[1] * dY + r[2] * dZ, Yc = r[3] * dX + r[4] * dY + r[5] * dZ;
+        const double Zc = r[6] * dX + r[7] * dY + r[8] * dZ;
+        const double x = -io[2] * Xc / Zc, y = -io[2] * Yc / Zc;
+        // the correction is a function of the observed coordinate: solve x_obs = x + xp + dx(x_obs)
+        double xo = x + io[0], yo = y + io[1];
+        for (int it = 0; it < 5; ++it) {
+          double dx, dy;
+          distortion(a, (xo - io[0]) / kApScale, (yo - io[1]) / kApScale, dx, dy);
+          xo = x + io[0] + dx;
+          yo = y + io[1] + dy;
+        }
+        n->imageTarget[row] = n->xyzTarget[j];
+        n->imageStation[row] = n->eopStation[s];
+        n->imageX[row] = xo;
+        n->imageY[row] = yo;
+      }
+    // noise and gross errors in file order, so that they do not depend on the point loop above
+    for (int64_t row = 0; row < N; ++row) {
+      double nx = cfg->noise_sigma * rng.normal(), ny = cfg->noise_sigma * rng.normal();
+      if (rng.uni() < cfg->outlier_fraction) {
+        nx += (rng.uni() < 0.5 ? -1.0 : 1.0) * rng.uni(5, 20) * cfg->noise_sigma;
+        ny += (rng.uni() < 0.5 ? -1.0 : 1.0) * rng.uni(5, 20) * cfg->noise_sigma;
+      }
+      n->imageX[row] += nx;
+      n->imageY[row] += ny;
+    }
+  }
+
+  // start values and priors
+  n->EOP = n->tEOP; n->XYZ = n->tXYZ; n->IOP = n->tIOP;
+  n->AP.assign(16 * static_cast<size_t>(C), 0.0);
+  if (cfg->perfect_start) n->AP = n->tAP;
+  if (!cfg->perfect_start) {
+    for (int32_t s = 0; s < S; ++s) {
+      double *e = &n->EOP[6 * static_cast<size_t>(s)];
+      for (int k = 0; k < 3; ++k) e[k] += 0.05 * kPi / 180.0 * rng.normal();
+      for (int k = 3; k < 6; ++k) e[k] += 5.0 * rng.normal();
+    }
+    for (size_t q = 0; q < n->XYZ.size(); ++q) n->XYZ[q] += 5.0 * rng.normal();
+    for (int32_t c = 0; c < C; ++c)
+      for (int k = 0; k < 3; ++k)
+        if (cfg->iop_free_mask & (1u << k)) n->IOP[3 * static_cast<size_t>(c) + k] += rng.normal();
+  }
+  n->xyzStdDev.resize(3 * static_cast<size_t>(P));
+  const int32_t every = cfg->control_every > 0 ? cfg->control_every : 64;
+  for (int32_t j = 0; j < P; ++j) {
+    const double sg = (j % every == 0) ? cfg->control_sigma : cfg->free_sigma;
+    for (int k = 0; k < 3; ++k) n->xyzStdDev[3 * static_cast<size_t>(j) + k] = sg;
+  }
+  n->apFree.assign(C, cfg->ap_free_mask);
+  n->iopFree.assign(C, cfg->iop_free_mask);
+  const int rc = finish(*n);
+  if (rc) {
+    delete n;
+    return rc;
+  }
+  *out = n;
+  return 0;
+}
+
+void ba_net_free(ba_network *net) { delete net; }
+
+int ba_net_dims(const ba_network *n, ba_dims *d) {
+  if (!n || !d) return fail(BA_ERR_INVALID, "ba_net_dims: null argument");
+  d->n_obs = static_cast<int32_t>(n->imageTarget.size());
+  d->n_sta = static_cast<int32_t>(n->eopStation.size());
+  d->n_pts = static_cast<int32_t>(n->xyzTarget.size());
+  d->n_cam = static_cast<int32_t>(n->iopCamera.size());
+  return 0;
+}
+
+int ba_net_inputs(ba_network *n, ba_inputs *in) {
+  if (!n || !in) return fail(BA_ERR_INVALID, "ba_net_inputs: null argument");
+  in->obs_pt = n->indexPoint.data();
+  in->obs_sta = n->indexPose.data();
+  in->sta_cam = n->staSensor.data();
+  in->obs_x = n->imageX.data(); in->obs_y = n->imageY.data();
+  in->obs_sx = n->imageXStdDev.data(); in->obs_sy = n->imageYStdDev.data();
+  in->obs_cx = n->imageXCorr.data(); in->obs_cy = n->imageYCorr.data();
+  in->pt_prior = n->xyzPrior.data(); in->pt_sigma = n->xyzStdDev.data();
+  in->iop_prior = n->iopPrior.data(); in->iop_sigma = n->iopStdDev.data();
+  in->ap_free_mask = n->apFree.data();
+  in->iop_free_mask = n->iopFree.data();
+  in->huber_a = 1.0;  // src/main.cpp:3810
+  in->model = 0;
+  return 0;
+}
+
+double *ba_net_eop(ba_network *n) { return n->EOP.data(); }
+double *ba_net_xyz(ba_network *n) { return n->XYZ.data(); }
+double *ba_net_iop(ba_network *n) { return n->IOP.data(); }
+double *ba_net_ap(ba_network *n) { return n->AP.data(); }
+const double *ba_net_truth_eop(const ba_network *n) { return n->tEOP.empty() ? nullptr : n->tEOP.data(); }
+const double *ba_net_truth_xyz(const ba_network *n) { return n->tXYZ.empty() ? nullptr : n->tXYZ.data(); }
+const double *ba_net_truth_iop(const ba_network *n) { return n->tIOP.empty() ? nullptr : n->tIOP.data(); }
+const double *ba_net_truth_ap(const ba_network *n) { return n->tAP.empty() ? nullptr : n->tAP.data(); }
+
+const int32_t *ba_net_ids(const ba_network *n, int which) {
+  switch (which) {
+    case 0: return n->imageTarget.data();
+    case 1: return n->imageStation.data();
+    case 2: return n->eopStation.data();
+    case 3: return n->eopCamera.data();
+    case 4: return n->xyzTarget.data();
+    case 5: return n->iopCamera.data();
+  }
+  return nullptr;
+}
+
+int ba_net_set_free(ba_network *n, uint16_t ap_free_mask, uint8_t iop_free_mask) {
+  if (!n) return fail(BA_ERR_INVALID, "ba_net_set_free: null argument");
+  n->apFree.assign(n->iopCamera.size(), ap_free_mask);
+  n->iopFree.assign(n->iopCamera.size(), static_cast<uint8_t>(iop_free_mask & 7u));
+  return 0;
+}
+
+int32_t ba_net_num_ap_correction(const ba_network *n) {
+  // src/main.cpp:4509: fixAP.size() of the last camera processed, not multiplied by the camera count
+  if (!n || n->apFree.empty()) return 0;
+  int fixed = 0;
+  for (int k = 0; k < 16; ++k)
+    if (!(n->apFree.back() & (1u << k))) ++fixed;
+  return fixed;
+}
+
+double ba_sigma0(const ba_summary *s, int32_t n_pts, int32_t num_ap_correction, double *redundancy) {
+  // src/main.cpp:4907-4910
+  const double red = static_cast<double>(s->num_residuals_reduced) - s->num_parameters_reduced - 3.0 * n_pts + 7 +
+                     num_ap_correction;
+  if (redundancy) *redundancy = red;
+  const double aposterioriVariance = 2 * s->final_cost / red;
+  return std::sqrt(aposterioriVariance);
+}
+
+int ba_net_write_inputs(const ba_network *n, const char *dir, const char *stem) {
+  if (!n || !dir || !stem) return fail(BA_ERR_INVALID, "ba_net_write_inputs: null argument");
+  const std::string base = std::string(dir) + "/" + stem;
+  FILE *f = fopen((base + ".pho").c_str(), "w");
+  if (!f) return fail(BA_ERR_INVALID, "cannot write %s.pho", base.c_str());
+  for (size_t i = 0; i < n->imageTarget.size(); ++i)
+    fprintf(f, "%i %i %.17g %.17g %.17g %.17g %.17g %.17g\n", n->imageTarget[i], n->imageStation[i], n->imageX[i],
+            n->imageY[i], n->imageXStdDev[i], n->imageYStdDev[i], n->imageXCorr[i], n->imageYCorr[i]);
+  fclose(f);
+  f = fopen((base + ".eop").c_str(), "w");
+  if (!f) return fail(BA_ERR_INVALID, "cannot write %s.eop", base.c_str());
+  for (size_t i = 0; i < n->eopStation.size(); ++i) {
+    const double *e = &n->EOP[6 * i];
+    fprintf(f, "%i %i %.17g %.17g %.17g %.17g %.17g %.17g\n", n->eopStation[i], n->eopCamera[i], e[3], e[4], e[5],
+            e[0] * 180.0 / kPi, e[1] * 180.0 / kPi, e[2] * 180.0 / kPi);
+  }
+  fclose(f);
+  f = fopen((base + ".iop").c_str(), "w");
+  if (!f) return fail(BA_ERR_INVALID, "cannot write %s.iop", base.c_str());
+  for (size_t i = 0; i < n->iopCamera.size(); ++i) {
+    fprintf(f, "%i %i %.17g %.17g %.17g %.17g", n->iopCamera[i], n->iopAxis[i], n->iopXMin[i], n->iopYMin[i],
+            n->iopXMax[i], n->iopYMax[i]);
+    for (int k = 0; k < 3; ++k) fprintf(f, " %.17g", n->IOP[3 * i + k]);
+    for (int k = 0; k < 16; ++k) fprintf(f, " %.17g", n->AP[16 * i + k]);
+    fprintf(f, "\n");
+  }
+  fclose(f);
+  f = fopen((base + ".xyz").c_str(), "w");
+  if (!f) return fail(BA_ERR_INVALID, "cannot write %s.xyz", base.c_str());
+  for (size_t i = 0; i < n->xyzTarget.size(); ++i)
+    fprintf(f, "%i %.17g %.17g %.17g %.17g %.17g %.17g\n", n->xyzTarget[i], n->xyzPrior[3 * i], n->xyzPrior[3 * i + 1],
+            n->xyzPrior[3 * i + 2], n->xyzStdDev[3 * i], n->xyzStdDev[3 * i + 1], n->xyzStdDev[3 * i + 2]);
+  fclose(f);
+  return 0;
+}
+
+int ba_net_write_results(const ba_network *n, const char *dir, const double *residuals) {
+  if (!n || !dir) return fail(BA_ERR_INVALID, "ba_net_write_results: null argument");
+  const std::string d = std::string(dir) + "/";
+  const double PI = kPi;
+  const double sentinel = std::sqrt(1E6);  // variances default to 1E6 when COMPUTECX is 0 (src/main.cpp:5251-5256)
+  FILE *fout = fopen((d + "temp.pho").c_str(), "w");
+  if (!fout) return fail(BA_ERR_INVALID, "cannot write into %s", dir);
+  for (size_t i = 0; i < n->imageTarget.size(); ++i)  // src/main.cpp:3130
+    fprintf(fout, "%i %i %.6lf %.6lf %.6lf %.6lf %.6lf %.6lf\n", n->imageTarget[i], n->imageStation[i], n->imageX[i],
+            n->imageY[i], n->imageXStdDev[i], n->imageYStdDev[i], n->imageXCorr[i], n->imageYCorr[i]);
+  fclose(fout);
+
+  fout = fopen((d + "EOP.jck").c_str(), "w");
+  for (size_t i = 0; i < n->eopStation.size(); ++i) {  // src/main.cpp:7096
+    const double *E = &n->EOP[6 * i];
+    fprintf(fout, "%i %.6lf %.6lf %.6lf %.6lf %.6lf %.6lf %.6lf %.6lf %.6lf %.6lf %.6lf %.6lf\n", n->eopStation[i],
+            E[0] * 180.0 / PI, E[1] * 180.0 / PI, E[2] * 180.0 / PI, E[3], E[4], E[5], sentinel * 180.0 / PI,
+            sentinel * 180.0 / PI, sentinel * 180.0 / PI, sentinel, sentinel, sentinel);
+  }
+  fclose(fout);
+
+  fout = fopen((d + "temp.eop").c_str(), "w");
+  for (size_t i = 0; i < n->eopStation.size(); ++i) {  // src/main.cpp:4804
+    const double *E = &n->EOP[6 * i];
+    fprintf(fout, "%i %i %.6lf %.6lf %.6lf %.6lf %.6lf %.6lf\n", n->eopStation[i], n->eopCamera[i], E[3], E[4], E[5],
+            E[0] * 180.0 / PI, E[1] * 180.0 / PI, E[2] * 180.0 / PI);
+  }
+  fclose(fout);
+
+  fout = fopen((d + "iop.jck").c_str(), "w");
+  for (size_t i = 0; i < n->iopCamera.size(); ++i)  // src/main.cpp:7107
+    fprintf(fout, "%i %.6lf %.6lf %.6lf %.6lf %.6lf %.6lf\n", n->iopCamera[i], n->IOP[3 * i], n->IOP[3 * i + 1],
+            n->IOP[3 * i + 2], sentinel, sentinel, sentinel);
+  fclose(fout);
+
+  fout = fopen((d + "temp.iop").c_str(), "w");
+  for (size_t i = 0; i < n->iopCamera.size(); ++i) {  // src/main.cpp:4843 (6 decimals, as the reference)
+    fprintf(fout, "%i %i %.6lf %.6lf %.6lf %.6lf", n->iopCamera[i], n->iopAxis[i], n->iopXMin[i], n->iopYMin[i],
+            n->iopXMax[i], n->iopYMax[i]);
+    for (int k = 0; k < 3; ++k) fprintf(fout, " %.6lf", n->IOP[3 * i + k]);
+    for (int k = 0; k < 16; ++k) fprintf(fout, " %.6lf", n->AP[16 * i + k]);
+    fprintf(fout, "\n");
+  }
+  fclose(fout);
+
+  fout = fopen((d + "ap.jck").c_str(), "w");
+  for (size_t i = 0; i < n->iopCamera.size(); ++i) {  // src/main.cpp:7118
+    fprintf(fout, "%i", n->iopCamera[i]);
+    for (int k = 0; k < 16; ++k) fprintf(fout, " %.6lf", n->AP[16 * i + k]);
+    for (int k = 0; k < 16; ++k) fprintf(fout, " %.6lf", sentinel);
+    fprintf(fout, "\n");
+  }
+  fclose(fout);
+
+  fout = fopen((d + "XYZ.jck").c_str(), "w");
+  for (size_t i = 0; i < n->xyzTarget.size(); ++i)  // src/main.cpp:7085
+    fprintf(fout, "%i %.6lf %.6lf %.6lf %.6lf %.6lf %.6lf\n", n->xyzTarget[i], n->XYZ[3 * i], n->XYZ[3 * i + 1],
+            n->XYZ[3 * i + 2], sentinel, sentinel, sentinel);
+  fclose(fout);
+
+  if (residuals) {
+    fout = fopen((d + "image.jck").c_str(), "w");
+    for (size_t i = 0; i < n->imageTarget.size(); ++i) {  // src/main.cpp:6955-6965, 6996
+      const double vx = residuals[2 * i] * n->imageXStdDev[i], vy = residuals[2 * i + 1] * n->imageYStdDev[i];
+      const int32_t pose = n->indexPose[i];
+      // reference ids as the collinearity block fills them (src/main.cpp:3838-3840)
+      const int pointReferenceID = n->xyzTarget[n->indexPoint[i]], frameReferenceID = n->eopStation[pose];
+      const int sensorReferenceID = n->iopCamera[n->staSensor[pose]];
+      // redundancy numbers default to 1E6 (:6670); CvDiag carries the observation variance (:6673-6676)
+      fprintf(fout, "%i %i %i %.6lf %.6lf %.6lf %.6lf %.2lf %.2lf %.6lf %.6lf\n", pointReferenceID, frameReferenceID,
+              sensorReferenceID, n->imageX[i], n->imageY[i], vx, vy, 1E6, 1E6,
+              std::sqrt(n->imageXStdDev[i] * n->imageXStdDev[i]), std::sqrt(n->imageYStdDev[i] * n->imageYStdDev[i]));
+    }
+    fclose(fout);
+  }
+  return 0;
+}
+
+}  // extern "C"

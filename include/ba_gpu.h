@@ -1,0 +1,256 @@
+/*
+ * ba_gpu.h -- C ABI of the MI355X bundle-adjustment solver library (libba_gpu.so).
+ *
+ * The reference program (jckchow/BundleAdjustment, src/main.cpp) has no plugin or FFI
+ * boundary of its own: the only seam around its Levenberg-Marquardt inner loop is the set
+ * of Ceres Solver calls it makes.  Each entry point below replaces one group of those
+ * calls; the comment on each names the reference lines it stands in for.
+ *
+ * Conventions
+ *   - plain C, no C++ or torch types in any signature; all pointers are caller-owned host
+ *     memory unless a comment says "device";
+ *   - every function returns 0 on success and a negative ba_status on error; the text of
+ *     the last error on the calling thread is available from ba_last_error();
+ *   - nothing throws across the boundary;
+ *   - one ba_problem is used from one host thread at a time;
+ *   - all floating point data is IEEE fp64, all indices are 32-bit signed.
+ */
+#ifndef BA_GPU_H
+#define BA_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ba_problem ba_problem; /* opaque */
+
+enum ba_status {
+  BA_OK = 0,
+  BA_ERR_INVALID = -1,     /* bad argument / inconsistent sizes / index out of range */
+  BA_ERR_DEVICE = -2,      /* HIP runtime error */
+  BA_ERR_NUMERIC = -3,     /* Cholesky breakdown / non-finite step */
+  BA_ERR_UNSUPPORTED = -4, /* option value not implemented */
+  BA_ERR_COMM = -5         /* collective failed */
+};
+
+/* Termination types; values follow ceres::TerminationType as used by Solver::Summary. */
+enum ba_termination {
+  BA_CONVERGENCE = 0,
+  BA_NO_CONVERGENCE = 1,
+  BA_FAILURE = 2
+};
+
+/* Which test ended the solve (Ceres only reports this in Summary::message). */
+enum ba_stop_reason {
+  BA_STOP_NONE = 0,
+  BA_STOP_MAX_ITERATIONS = 1,
+  BA_STOP_GRADIENT_TOL = 2,
+  BA_STOP_PARAMETER_TOL = 3,
+  BA_STOP_FUNCTION_TOL = 4,
+  BA_STOP_MIN_RADIUS = 5,
+  BA_STOP_INVALID_STEPS = 6,
+  BA_STOP_LINEAR_SOLVER = 7
+};
+
+enum ba_linear_solver {
+  BA_SOLVER_DENSE_SCHUR = 0, /* point elimination + dense fp64 Cholesky of the reduced system */
+  BA_SOLVER_PCG_SCHUR = 1    /* point elimination + block-Jacobi PCG on the implicit reduced system */
+};
+
+typedef struct {
+  int32_t n_obs; /* rows of the .pho file  */
+  int32_t n_sta; /* rows of the .eop file  */
+  int32_t n_pts; /* rows of the .xyz file  */
+  int32_t n_cam; /* rows of the .iop file  */
+} ba_dims;
+
+/*
+ * Problem definition.  Replaces the problem-assembly calls of the reference:
+ *   AddParameterBlock           src/main.cpp:3793-3800  (column order EOP | XYZ | IOP | AP)
+ *   AddResidualBlock (image)    src/main.cpp:3845-3848 / 4242-4245  (one 2-row block per .pho row)
+ *   AddResidualBlock (XYZ prior) src/main.cpp:4596-4599
+ *   AddResidualBlock (IOP prior) src/main.cpp:4626-4629
+ *   HuberLoss(1.0)              src/main.cpp:3809-3810
+ *   SubsetParameterization      src/main.cpp:4479-4511
+ * The index maps obs_pt / obs_sta / sta_cam are the indexPoint / indexPose / indexSensor
+ * values of src/main.cpp:3821-3831, already resolved by the host (ba_host.h).
+ */
+typedef struct {
+  const int32_t *obs_pt;  /* [n_obs] row of .xyz for each observation */
+  const int32_t *obs_sta; /* [n_obs] row of .eop for each observation */
+  const int32_t *sta_cam; /* [n_sta] row of .iop for each station     */
+  const double *obs_x, *obs_y;   /* [n_obs] .pho columns 3,4  image coordinates          */
+  const double *obs_sx, *obs_sy; /* [n_obs] .pho columns 5,6  standard deviations         */
+  const double *obs_cx, *obs_cy; /* [n_obs] .pho columns 7,8  constant correction (xMLP,yMLP
+                                    of collinearityMachineLearnedSimple, src/main.cpp:2096);
+                                    zeros give the plain collinearity functor :1315-1401)  */
+  const double *pt_prior, *pt_sigma;   /* [3*n_pts] .xyz X,Y,Z and their sigmas (prior, :4598) */
+  const double *iop_prior, *iop_sigma; /* [3*n_cam] xp,yp,c prior mean and sigma (:4612-4628)  */
+  const uint16_t *ap_free_mask; /* [n_cam] bit k set -> AP[k] is estimated; 0 -> block constant */
+  const uint8_t *iop_free_mask; /* [n_cam] bits 0..2 -> xp,yp,c estimated; 0 -> block constant  */
+  double huber_a;               /* 1.0 in the reference; <= 0 disables the robust loss          */
+  int32_t model;                /* 0 = collinearity; other projection models are reserved       */
+} ba_inputs;
+
+/*
+ * Solver options.  Replaces ceres::Solver::Options as set at src/main.cpp:4705-4719; every
+ * field not set there carries the Ceres default (ba_default_options fills them in).
+ */
+typedef struct {
+  double min_lm_diagonal;          /* 1e-150 (src/main.cpp:4713) */
+  double max_lm_diagonal;          /* 1e-150 (src/main.cpp:4712) */
+  double initial_trust_region_radius; /* 1e4  */
+  double max_trust_region_radius;  /* 1e16 */
+  double min_trust_region_radius;  /* 1e-32 */
+  double min_relative_decrease;    /* 1e-3 */
+  double function_tolerance;       /* 1e-6 */
+  double gradient_tolerance;       /* 1e-10 */
+  double parameter_tolerance;      /* 1e-8 */
+  int32_t max_num_iterations;      /* 100 (src/main.cpp:4718) */
+  int32_t max_num_consecutive_invalid_steps; /* 5 */
+  int32_t jacobi_scaling;          /* 1 */
+  int32_t linear_solver;           /* enum ba_linear_solver */
+  double pcg_rtol;                 /* PCG stops when |r|_M^-1 <= pcg_rtol * |b|_M^-1 */
+  int32_t pcg_max_iters;
+  int32_t reserved;
+} ba_options;
+
+/* One row of the iteration log; same columns as Ceres' minimizer_progress_to_stdout table. */
+typedef struct {
+  int32_t iteration;
+  int32_t step_is_successful;
+  int32_t step_is_valid;
+  int32_t linear_iterations; /* PCG iterations (0 for the dense solver) */
+  double cost;
+  double cost_change;
+  double gradient_max_norm;
+  double step_norm;
+  double relative_decrease; /* tr_ratio */
+  double trust_region_radius;
+  double t_linearize_s; /* wall time: residual/Jacobian + point elimination */
+  double t_solve_s;     /* wall time: reduced solve + back substitution     */
+  double t_eval_s;      /* wall time: candidate cost evaluation             */
+} ba_iter_row;
+
+/* Replaces the fields of ceres::Solver::Summary read at src/main.cpp:4722-4723, 4906-4907. */
+typedef struct {
+  double initial_cost;
+  double final_cost;
+  double fixed_cost;
+  int32_t num_iterations;  /* rows logged, including iteration 0 */
+  int32_t termination;     /* enum ba_termination */
+  int32_t stop_reason;     /* enum ba_stop_reason */
+  int32_t num_successful_steps;
+  int32_t num_unsuccessful_steps;
+  int32_t num_residuals_reduced;
+  int32_t num_parameters_reduced;           /* ambient size of the non-constant, referenced blocks */
+  int32_t num_effective_parameters_reduced; /* tangent size of the same                             */
+  int32_t num_parameters;                   /* ambient size of every block                          */
+  int32_t num_residuals;
+  int32_t total_linear_iterations;
+  int32_t reserved;
+  double t_total_s;
+} ba_summary;
+
+/* Fills *opt with the reference's option values (src/main.cpp:4705-4719 over Ceres defaults). */
+void ba_default_options(ba_options *opt);
+
+/*
+ * Builds a problem on the current HIP device: validates the index maps, sorts observations
+ * by point and by station, and copies the constant data to HBM.
+ * Replaces ceres::Problem construction, src/main.cpp:3784-4636.
+ */
+int ba_create(const ba_dims *dims, const ba_inputs *in, ba_problem **out);
+
+/* Releases everything ba_create allocated.  (ceres::Problem destructor.) */
+void ba_destroy(ba_problem *p);
+
+/*
+ * Parameter blocks.  In the reference the parameter memory is owned by the caller and
+ * updated in place by ceres::Solve (src/main.cpp:3153, 3544, 3657, 4721); here the caller
+ * uploads the four arrays, solves on the device, and downloads them.
+ *   eop [6*n_sta] = omega,phi,kappa (radians), Xo,Yo,Zo per station (src/main.cpp:3177-3182)
+ *   xyz [3*n_pts]; iop [3*n_cam] = xp,yp,c; ap [16*n_cam] (src/main.cpp:3581-3604)
+ */
+int ba_set_parameters(ba_problem *p, const double *eop, const double *xyz, const double *iop,
+                      const double *ap);
+int ba_get_parameters(ba_problem *p, double *eop, double *xyz, double *iop, double *ap);
+
+/*
+ * Runs the trust-region Levenberg-Marquardt loop on the parameters resident on the device
+ * and leaves the result there.  Replaces ceres::Solve, src/main.cpp:4721.
+ * rows may be NULL; at most rows_cap rows are written.
+ */
+int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary,
+                      ba_iter_row *rows, int32_t rows_cap);
+
+/* ba_set_parameters + ba_solve_resident + ba_get_parameters: the in-place behaviour of
+ * ceres::Solve on caller-owned arrays (src/main.cpp:4721). */
+int ba_solve(ba_problem *p, const ba_options *opt, double *eop, double *xyz, double *iop,
+             double *ap, ba_summary *summary, ba_iter_row *rows, int32_t rows_cap);
+
+/*
+ * Cost and residual vector at the given parameters.  Replaces
+ * problem.Evaluate(EvaluateOptions(), &cost, &residuals, NULL, NULL), src/main.cpp:4853, 6664.
+ * residuals (may be NULL) has 2*n_obs + 3*n_pts + 3*n_cam entries in the row order of
+ * src/main.cpp:4242-4263, 4596-4603, 4626-4634; with apply_loss != 0 the image rows carry
+ * the robust correction sqrt(rho') as Ceres' default EvaluateOptions do.
+ */
+int ba_evaluate(ba_problem *p, const double *eop, const double *xyz, const double *iop,
+                const double *ap, int apply_loss, double *cost, double *residuals);
+
+/*
+ * Structure of the Jacobian that problem.Evaluate(..., &jacobian) returns at
+ * src/main.cpp:6664 as a ceres::CRSMatrix: rows[] has num_rows+1 offsets, cols[] the column
+ * of every structural non-zero.  Call with rows == cols == NULL to get the sizes.
+ */
+int ba_sparsity(ba_problem *p, int32_t *num_rows, int32_t *num_cols, int64_t *nnz,
+                int32_t *rows, int32_t *cols);
+
+/*
+ * The residual/Jacobian kernel on its own: evaluates every image observation at the
+ * parameters resident on the device.  r [2*n_obs] and the dense per-observation Jacobian
+ * J [n_obs*2*28] (row-major 2x28: EOP 6 | XYZ 3 | IOP 3 | AP 16, fixed columns included,
+ * no robust correction, no column scaling) are written in .pho row order.
+ * This is what ceres::AutoDiffCostFunction<collinearity,2,6,3,3,16>::Evaluate produces per
+ * block (src/main.cpp:3845-3847).  Either output may be NULL.
+ */
+int ba_residual_jacobian(ba_problem *p, double *r, double *J);
+
+/*
+ * Times `repeats` launches of the fused residual/Jacobian/point-elimination kernel at the
+ * resident parameters with HIP events on the solver stream and returns the mean seconds
+ * per launch.  Used for the Jacobian obs/s figure and the roofline line of the benchmark.
+ */
+int ba_time_linearize(ba_problem *p, int32_t repeats, double *seconds_per_launch);
+
+/*
+ * Multi-GPU: a problem built from one shard of the points (and all observations of those
+ * points) takes part in a sum over ranks of the reduced camera system.  Stations and
+ * cameras are replicated, so eop/iop/ap passed to every rank are the full arrays.
+ *   - point priors belong to the shard that owns the point;
+ *   - IOP priors are added once, by the rank with add_camera_priors != 0.
+ * The callback must reduce buf[0..count) over all ranks in place (device memory) with
+ * op 0 = sum or op 1 = max and return 0; it is called on the solver's stream, which it
+ * receives as an opaque hipStream_t.
+ * The reference has no counterpart: it is single-process (src/main.cpp:4705-4721 never sets
+ * num_threads).
+ */
+typedef int (*ba_allreduce_fn)(void *user, double *device_buf, int64_t count, int32_t op,
+                               void *hip_stream);
+int ba_set_allreduce(ba_problem *p, ba_allreduce_fn fn, void *user, int32_t add_camera_priors);
+
+/* RCCL implementation of the callback above.  unique_id is the 128-byte ncclUniqueId made
+ * by ba_rccl_unique_id on rank 0 and distributed by the host. */
+int ba_rccl_unique_id(void *unique_id_128);
+int ba_use_rccl(ba_problem *p, int32_t n_ranks, int32_t rank, const void *unique_id_128,
+                int32_t add_camera_priors);
+
+const char *ba_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BA_GPU_H */

@@ -1,0 +1,95 @@
+/*
+ * ba_host.h -- host side of the bundle adjustment: the reference's drop-in surface around the
+ * solver (libba_host.so, C++ inside, C ABI outside so tests and tools can bind it).
+ *
+ * What each group restates, in /root/reference/src/main.cpp:
+ *   readers      .pho :3046-3095   .eop :3135-3199   .iop :3526-3640   .xyz :3651-3692
+ *   index maps   :3821-3831 (first-match std::find)
+ *   priors       :4596-4599 (XYZ from the .xyz columns), :4612-4628 (IOP, sigma 10,10,1000)
+ *   fixed/free   :4479-4511 (default: every AP fixed except k1)
+ *   sigma0       :4905-4912
+ *   writers      temp.pho :3127-3132, EOP.jck :7093-7098, temp.eop :4801-4806, iop.jck :7104-7109,
+ *                temp.iop :4840-4845, ap.jck :7115-7120, XYZ.jck :7082-7087, image.jck :6993-6998
+ * plus a deterministic synthetic-network generator (no counterpart in the reference, which
+ * ships no data).
+ */
+#ifndef BA_HOST_H
+#define BA_HOST_H
+
+#include <stdint.h>
+
+#include "ba_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ba_network ba_network; /* opaque: the four files, the index maps, the parameters */
+
+/* Reads the four text files.  Record-dropping quirk of the reference's
+ * `while(true){ in >> ...; push_back; if(eof) break; } pop_back()` idiom is kept: a record
+ * whose extraction reaches end-of-file (a last line with no trailing newline) is dropped.
+ * Differences, on purpose: an unreadable file or a malformed token is an error here (the
+ * reference loops forever), and an observation whose target/station/camera id is absent is
+ * an error (the reference indexes out of bounds). */
+int ba_net_read(const char *pho, const char *eop, const char *iop, const char *xyz, ba_network **out);
+
+typedef struct {
+  int32_t n_cam, n_sta, n_pts;
+  int32_t rays_per_point;      /* stations observing each point; n_obs = n_pts * rays_per_point */
+  uint64_t seed;
+  uint16_t ap_free_mask;       /* bit k -> AP[k] free, same for every camera */
+  uint8_t iop_free_mask;       /* bits 0..2 -> xp,yp,c free                   */
+  uint8_t empirical_terms;     /* 1: truth has non-zero AP[7] and AP[10]      */
+  double noise_sigma;          /* image noise = sigma_x = sigma_y, pixels     */
+  double outlier_fraction;     /* share of observations with a gross error    */
+  double control_sigma;        /* prior sigma of control points, mm           */
+  double free_sigma;           /* prior sigma of every other point, mm        */
+  int32_t control_every;       /* every n-th point is a control point         */
+  int32_t perfect_start;       /* 1: initial values = truth (for debugging)   */
+} ba_synth_config;
+
+void ba_synth_default(ba_synth_config *cfg);
+int ba_net_synth(const ba_synth_config *cfg, ba_network **out);
+
+void ba_net_free(ba_network *net);
+int ba_net_dims(const ba_network *net, ba_dims *dims);
+/* Fills *in with pointers into the network's own storage (valid until ba_net_free). */
+int ba_net_inputs(ba_network *net, ba_inputs *in);
+/* Parameter arrays, updated in place by the caller after a solve: [6S], [3P], [3C], [16C]. */
+double *ba_net_eop(ba_network *net);
+double *ba_net_xyz(ba_network *net);
+double *ba_net_iop(ba_network *net);
+double *ba_net_ap(ba_network *net);
+/* Truth of a synthetic network (NULL for a network read from files). */
+const double *ba_net_truth_eop(const ba_network *net);
+const double *ba_net_truth_xyz(const ba_network *net);
+const double *ba_net_truth_iop(const ba_network *net);
+const double *ba_net_truth_ap(const ba_network *net);
+/* File ids, [n_obs] target / station of each .pho row, [n_sta], [n_pts], [n_cam]. */
+const int32_t *ba_net_ids(const ba_network *net, int which /*0 pho target,1 pho station,2 eop station,3 eop camera,4 xyz target,5 iop camera*/);
+int ba_net_set_free(ba_network *net, uint16_t ap_free_mask, uint8_t iop_free_mask);
+
+/* First-match id lookup with a hash map: out[n] = first i with ids[i] == keys[n].
+ * Returns BA_ERR_INVALID and sets out[n] = n_ids for every key that is absent. */
+int ba_index_first_match(const int32_t *ids, int32_t n_ids, const int32_t *keys, int32_t n_keys, int32_t *out);
+
+/* Writes <dir>/<stem>.pho .eop .iop .xyz in the reference's input format (with a trailing newline). */
+int ba_net_write_inputs(const ba_network *net, const char *dir, const char *stem);
+
+/* Writes temp.pho, EOP.jck, temp.eop, iop.jck, temp.iop, ap.jck, XYZ.jck, image.jck into dir.
+ * residuals = the 2*n_obs leading entries of ba_evaluate(..., apply_loss=1, ...). The sigma
+ * columns carry the reference's COMPUTECX=0 sentinels (sqrt(1e6); redundancy 1e6). */
+int ba_net_write_results(const ba_network *net, const char *dir, const double *residuals);
+
+/* src/main.cpp:4907-4910: redundancy and a-posteriori standard deviation.
+ * num_ap_correction = number of AP fixed by the subset parameterisation (:4509). */
+double ba_sigma0(const ba_summary *summary, int32_t n_pts, int32_t num_ap_correction, double *redundancy);
+int32_t ba_net_num_ap_correction(const ba_network *net);
+
+const char *ba_host_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

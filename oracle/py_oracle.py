@@ -1,0 +1,149 @@
+"""ctypes access to the CPU oracle (oracle/libba_oracle.so) and, when built, to the reference's
+own functors (oracle/_ref/libba_ref.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the cpu_baseline leg
+of bench.py.  Nothing under bundleadjustment_amd/ imports this module.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from bundleadjustment_amd.capi import (BaDims, BaInputs, BaIterRow, BaOptions, BaSummary, c_double_p,
+                                       c_int32_p, rows_to_dicts, summary_to_dict)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+FULL_DENSE, SCHUR_DENSE, SCHUR_PCG = 0, 1, 2
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "libba_oracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make -C oracle` (or __graft_entry__.build())")
+        L = C.CDLL(path)
+        L.bao_last_error.restype = C.c_char_p
+        L.bao_linearize_once.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def ref_lib():
+    """The reference functors compiled from /root/reference (None when not built)."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(_HERE, "_ref", "libba_ref.so")
+        if not os.path.exists(path):
+            return None
+        _ref = C.CDLL(path)
+    return _ref
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(f"oracle error {rc}: {lib().bao_last_error().decode()}")
+
+
+def collinearity(eop, xyz, iop, ap, obs, jac=True):
+    eop, xyz, iop, ap, obs = (np.ascontiguousarray(a, dtype=np.float64) for a in (eop, xyz, iop, ap, obs))
+    r = np.zeros(2)
+    J = np.zeros((2, 28)) if jac else None
+    lib().bao_collinearity(_dp(eop), _dp(xyz), _dp(iop), _dp(ap), _dp(obs), _dp(r), _dp(J) if jac else None)
+    return r, J
+
+
+def index_first_match(ids, keys):
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    keys = np.ascontiguousarray(keys, dtype=np.int32)
+    out = np.zeros(len(keys), dtype=np.int32)
+    lib().bao_index_first_match(ids.ctypes.data_as(c_int32_p), len(ids), keys.ctypes.data_as(c_int32_p),
+                                len(keys), out.ctypes.data_as(c_int32_p))
+    return out
+
+
+def residual_jacobian_all(net, eop=None, xyz=None, iop=None, ap=None):
+    eop = net.eop if eop is None else eop
+    xyz = net.xyz if xyz is None else xyz
+    iop = net.iop if iop is None else iop
+    ap = net.ap if ap is None else ap
+    d, inp = net.dims(), net.inputs()
+    r = np.zeros(2 * net.n_obs)
+    J = np.zeros((net.n_obs, 2, 28))
+    _check(lib().bao_residual_jacobian_all(C.byref(d), C.byref(inp), _dp(eop), _dp(xyz), _dp(iop), _dp(ap),
+                                           _dp(r), _dp(J)))
+    return r, J
+
+
+def evaluate(net, eop=None, xyz=None, iop=None, ap=None, apply_loss=True):
+    eop = net.eop if eop is None else eop
+    xyz = net.xyz if xyz is None else xyz
+    iop = net.iop if iop is None else iop
+    ap = net.ap if ap is None else ap
+    d, inp = net.dims(), net.inputs()
+    cost = C.c_double()
+    res = np.zeros(2 * net.n_obs + 3 * net.n_pts + 3 * net.n_cam)
+    _check(lib().bao_evaluate(C.byref(d), C.byref(inp), _dp(eop), _dp(xyz), _dp(iop), _dp(ap),
+                              int(bool(apply_loss)), C.byref(cost), _dp(res)))
+    return cost.value, res
+
+
+def sparsity(net):
+    d, inp = net.dims(), net.inputs()
+    nr, nc, nnz = C.c_int32(), C.c_int32(), C.c_int64()
+    _check(lib().bao_sparsity(C.byref(d), C.byref(inp), C.byref(nr), C.byref(nc), C.byref(nnz), None, None))
+    rows = np.zeros(nr.value + 1, dtype=np.int32)
+    cols = np.zeros(nnz.value, dtype=np.int32)
+    _check(lib().bao_sparsity(C.byref(d), C.byref(inp), C.byref(nr), C.byref(nc), C.byref(nnz),
+                              rows.ctypes.data_as(c_int32_p), cols.ctypes.data_as(c_int32_p)))
+    return nr.value, nc.value, rows, cols
+
+
+def solve(net, options, mode=SCHUR_DENSE, rows_cap=256):
+    """Returns (eop, xyz, iop, ap, summary dict, list of iteration-row dicts)."""
+    d, inp = net.dims(), net.inputs()
+    eop, xyz, iop, ap = net.params_copy()
+    sm = BaSummary()
+    rows = (BaIterRow * rows_cap)()
+    _check(lib().bao_solve(C.byref(d), C.byref(inp), C.byref(options), int(mode), _dp(eop), _dp(xyz), _dp(iop),
+                           _dp(ap), C.byref(sm), rows, rows_cap))
+    return eop, xyz, iop, ap, summary_to_dict(sm), rows_to_dicts(rows, min(sm.num_iterations, rows_cap))
+
+
+def linearize_once(net):
+    d, inp = net.dims(), net.inputs()
+    return lib().bao_linearize_once(C.byref(d), C.byref(inp), _dp(net.eop), _dp(net.xyz), _dp(net.iop), _dp(net.ap))
+
+
+# ---- the reference functors themselves (present only where /root/reference was available at build time)
+
+def ref_collinearity(eop, xyz, iop, ap, obs, mls=True):
+    L = ref_lib()
+    eop, xyz, iop, ap, obs = (np.ascontiguousarray(a, dtype=np.float64) for a in (eop, xyz, iop, ap, obs))
+    r = np.zeros(2)
+    fn = L.ref_collinearity_mls if mls else L.ref_collinearity
+    fn(_dp(eop), _dp(xyz), _dp(iop), _dp(ap), _dp(obs), _dp(r))
+    return r
+
+
+def ref_collinearity_jacobian(eop, xyz, iop, ap, obs, h=1e-30):
+    L = ref_lib()
+    eop, xyz, iop, ap, obs = (np.ascontiguousarray(a, dtype=np.float64) for a in (eop, xyz, iop, ap, obs))
+    J = np.zeros((2, 28))
+    L.ref_collinearity_mls_jacobian(_dp(eop), _dp(xyz), _dp(iop), _dp(ap), _dp(obs), C.c_double(h), _dp(J))
+    return J
+
+
+def ref_constrain_point(p, p0, sigma):
+    L = ref_lib()
+    p, p0, sigma = (np.ascontiguousarray(a, dtype=np.float64) for a in (p, p0, sigma))
+    r = np.zeros(3)
+    L.ref_constrain_point(_dp(p), _dp(p0), _dp(sigma), _dp(r))
+    return r

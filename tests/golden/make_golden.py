@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/collinearity_golden.json from the reference's own cost functors.
+
+Run in the build container, where /root/reference is mounted and `make -C oracle` has built
+oracle/_ref/libba_ref.so out of src/main.cpp:1315-1401, :2033-2120, :1057-1085 (see
+oracle/ref/build_ref.sh).  The fixture holds numbers only: inputs, the residuals of both
+functors evaluated in double, and the 2x28 Jacobian obtained by complex-step differentiation
+of the reference functor (std::complex<double> instantiation, h = 1e-30).
+
+    python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import py_oracle as po  # noqa: E402
+
+SEED = 0xBA5EBA11
+N_PER_CLASS = 48
+
+
+def rot(om, ph, ka):
+    so, co, sp, cp, sk, ck = np.sin(om), np.cos(om), np.sin(ph), np.cos(ph), np.sin(ka), np.cos(ka)
+    return np.array([[cp * ck, co * sk + so * sp * ck, so * sk - co * sp * ck],
+                     [-cp * sk, co * ck - so * sp * sk, so * ck + co * sp * sk],
+                     [sp, -so * cp, co * cp]])
+
+
+def make_case(rng, ap_kind, resid_kind, with_corr):
+    # a station looking roughly down the -Z axis of its own frame at a point 8-12 m away
+    eop = np.array([rng.uniform(-0.4, 0.4), rng.uniform(-0.4, 0.4), rng.uniform(-np.pi, np.pi),
+                    rng.uniform(-5e3, 5e3), rng.uniform(-5e3, 5e3), rng.uniform(8e3, 12e3)])
+    R = rot(*eop[:3])
+    cam = np.array([rng.uniform(-5e3, 5e3), rng.uniform(-5e3, 5e3), -rng.uniform(8e3, 12e3)])
+    xyz = eop[3:] + R.T @ cam
+    iop = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(2500, 3500)])
+    ap = np.zeros(16)
+    if ap_kind in ("brown", "all"):
+        ap[:7] = [rng.normal(0, 1e-2), rng.normal(0, 1e-2), rng.normal(0, 0.5), rng.normal(0, 2e-2),
+                  rng.normal(0, 5e-4), rng.normal(0, 5e-2), rng.normal(0, 5e-2)]
+    if ap_kind == "all":
+        ap[7:] = rng.normal(0, 1.0, 9) * 10.0 ** -np.arange(5, 14)
+        ap[10] = rng.choice([-1, 1]) * rng.uniform(0.5, 2) * 1e-7  # pins the duplicated rr^7 + rr^8 term
+    sx, sy = rng.uniform(0.2, 1.0, 2)
+    corr = rng.normal(0, 0.7, 2) if with_corr else np.zeros(2)
+    obs = np.array([0.0, 0.0, sx, sy, corr[0], corr[1]])
+    # fixed point so that the residual is ~0 (the distortion depends on the observed coordinate)
+    for _ in range(8):
+        r = po.ref_collinearity(eop, xyz, iop, ap, obs, mls=True)
+        obs[0] += r[0] * sx
+        obs[1] += r[1] * sy
+    if resid_kind == "small":   # |r| < 1  -> quadratic branch of Huber(1)
+        t = rng.uniform(0, 2 * np.pi)
+        m = rng.uniform(0.05, 0.7)
+        obs[0] += m * np.cos(t) * sx
+        obs[1] += m * np.sin(t) * sy
+    else:                       # |r| > 1  -> linear branch
+        obs[0] += rng.choice([-1, 1]) * rng.uniform(2, 20) * sx
+        obs[1] += rng.choice([-1, 1]) * rng.uniform(2, 20) * sy
+    return eop, xyz, iop, ap, obs
+
+
+def main():
+    if po.ref_lib() is None:
+        sys.exit("oracle/_ref/libba_ref.so is missing: run `make -C oracle` where /root/reference exists")
+    rng = np.random.default_rng(SEED)
+    cases = []
+    for ap_kind in ("zero", "brown", "all"):
+        for resid_kind in ("small", "large"):
+            for i in range(N_PER_CLASS):
+                with_corr = bool(i % 2)
+                eop, xyz, iop, ap, obs = make_case(rng, ap_kind, resid_kind, with_corr)
+                r_mls = po.ref_collinearity(eop, xyz, iop, ap, obs, mls=True)
+                obs0 = obs.copy()
+                obs0[4:] = 0.0
+                r_plain = po.ref_collinearity(eop, xyz, iop, ap, obs0, mls=False)
+                J = po.ref_collinearity_jacobian(eop, xyz, iop, ap, obs)
+                cases.append({
+                    "ap_kind": ap_kind, "resid_kind": resid_kind,
+                    "eop": eop.tolist(), "xyz": xyz.tolist(), "iop": iop.tolist(), "ap": ap.tolist(),
+                    "obs": obs.tolist(),
+                    "r_mls": r_mls.tolist(),      # collinearityMachineLearnedSimple, src/main.cpp:2033-2120
+                    "r_plain": r_plain.tolist(),  # collinearity (corrections zero), src/main.cpp:1315-1401
+                    "J": J.reshape(-1).tolist(),  # complex step of the former, row-major 2x28
+                })
+    priors = []
+    for _ in range(16):
+        p, p0 = rng.normal(0, 5e3, 3), rng.normal(0, 5e3, 3)
+        sg = 10.0 ** rng.uniform(-1, 4, 3)
+        priors.append({"p": p.tolist(), "p0": p0.tolist(), "sigma": sg.tolist(),
+                       "r": po.ref_constrain_point(p, p0, sg).tolist()})  # src/main.cpp:1057-1085
+    out = {
+        "generator": "tests/golden/make_golden.py",
+        "source": "reference functors src/main.cpp:1315-1401, 2033-2120, 1057-1085 compiled by oracle/ref/build_ref.sh",
+        "jacobian_method": "complex step, std::complex<double>, h=1e-30",
+        "seed": SEED,
+        "collinearity": cases,
+        "constrain_point": priors,
+    }
+    path = os.path.join(ROOT, "tests", "golden", "collinearity_golden.json")
+    with open(path, "w") as f:
+        json.dump(out, f)
+    print(f"wrote {path}: {len(cases)} collinearity cases, {len(priors)} prior cases")
+
+
+if __name__ == "__main__":
+    main()
