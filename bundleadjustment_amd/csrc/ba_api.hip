@@ -1,0 +1,1110 @@
+// ba_api.hip -- the C ABI of include/ba_gpu.h: problem set-up, the trust-region loop that
+// drives the kernels, evaluation, sparsity pattern, multi-GPU reduction hooks.
+//
+// The loop follows Ceres Solver 1.13's TrustRegionMinimizer with the Levenberg-Marquardt
+// strategy as configured at /root/reference/src/main.cpp:4705-4719 (Ceres is not part of the
+// reference tree; the restated steps are marked [Ceres 1.13] below).  Only scalars cross the
+// PCIe bus inside the loop.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "ba_device.h"
+#include "ba_gpu.h"
+#include "ba_kernels.h"
+
+using namespace ba;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_OK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return fail(BA_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+#define BA_TRY(expr)          \
+  do {                        \
+    const int rc_ = (expr);   \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int popcount32(unsigned v) { return __builtin_popcount(v); }
+
+enum Scal {
+  SC_COST = 0, SC_FIXED, SC_GMAX, SC_MCC, SC_STEP2_SC, SC_CNORM2_SC, SC_STEP2_P, SC_CNORM2_P, SC_CCOST, SC_XNORM2_SC,
+  SC_XNORM2_P, SC_GMAX_P, SC_GMAX_SC, SC_COUNT = 32
+};
+
+}  // namespace
+
+struct ba_problem {
+  int N = 0, S = 0, P = 0, C = 0;
+  int ncam = 0, ncmax = 0, nr = 0, n_chunks = 0;
+  double huber_a = 1.0;
+  hipStream_t stream = nullptr;
+  std::vector<void *> allocs;
+  // host copies
+  std::vector<int> pt_file;  // internal point -> .xyz row
+  std::vector<CamRec> cam_h;
+  std::vector<int> sta_cam_h, sta_used_h;
+  std::vector<int32_t> obs_pt_h, obs_sta_h;  // file order, for ba_sparsity
+  std::vector<uint16_t> ap_mask_h;
+  std::vector<uint8_t> iop_mask_h;
+  // device: structure
+  int *d_pt_start = nullptr, *d_obs_pt = nullptr, *d_sta_list = nullptr, *d_chunk_sta = nullptr, *d_chunk_begin = nullptr;
+  int *d_sta_chunk0 = nullptr, *d_sta_cam = nullptr, *d_pt_file = nullptr, *d_sta_used = nullptr, *d_info = nullptr;
+  unsigned *d_flags = nullptr;
+  double *d_obs = nullptr, *d_pt_prior = nullptr, *d_pt_isig = nullptr;
+  // device: parameters (current and candidate)
+  double *d_eop = nullptr, *d_xyz = nullptr, *d_eop_c = nullptr, *d_xyz_c = nullptr;
+  CamRec *d_cam = nullptr, *d_cam_c = nullptr;
+  double *d_sta = nullptr, *d_sta_c = nullptr;
+  // device: scaling, linearisation
+  double *d_scale_pt = nullptr, *d_scale_sta = nullptr, *d_scale_cam = nullptr;
+  double *d_rec = nullptr, *d_Jp = nullptr, *d_Jc = nullptr, *d_Mo = nullptr, *d_Vinv = nullptr, *d_g_pt = nullptr;
+  double *d_y_pt = nullptr, *d_colnorm_pt = nullptr, *d_diag_pt = nullptr;
+  double *d_colnorm_sta = nullptr, *d_diag_sta = nullptr, *d_d2_sta = nullptr;
+  double *d_colnorm_cam = nullptr, *d_colnorm_cam_in = nullptr, *d_diag_cam = nullptr, *d_d2_cam = nullptr, *d_jc2 = nullptr;
+  double *d_diagfull = nullptr;  // [nr] = d2_sta | camdiag
+  double *d_F = nullptr;         // folded station sums [S*39]
+  double *d_part = nullptr;      // chunk partials [n_chunks*39]
+  double *d_partial = nullptr;   // block partials
+  int n_partial = 0;
+  double *d_scal = nullptr, *h_scal = nullptr;
+  // device: reduced system
+  double *d_g = nullptr, *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_p = nullptr, *d_q = nullptr;
+  double *d_Minv = nullptr, *d_Ssc = nullptr, *d_Scc = nullptr, *d_Lcc = nullptr, *d_cgscal = nullptr, *h_cgscal = nullptr;
+  double *d_Sdense = nullptr;
+  // state
+  bool have_params = false;
+  // multi-GPU
+  ba_allreduce_fn ar = nullptr;
+  void *ar_user = nullptr;
+  ncclComm_t comm = nullptr;
+
+  template <class T>
+  int dalloc(T **p, size_t n) {
+    void *q = nullptr;
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(BA_ERR_DEVICE, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+    allocs.push_back(q);
+    *p = static_cast<T *>(q);
+    return 0;
+  }
+  template <class T>
+  int upload(T **p, const std::vector<T> &v) {
+    BA_TRY(dalloc(p, v.size()));
+    if (!v.empty()) HIP_OK(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+  }
+  int allreduce(double *buf, int64_t n, int op) {
+    if (!ar || n <= 0) return 0;
+    if (ar(ar_user, buf, n, op, stream) != 0) return fail(BA_ERR_COMM, "allreduce callback failed");
+    return 0;
+  }
+  int read_scal() {
+    HIP_OK(hipMemcpyAsync(h_scal, d_scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int check_kernels() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(BA_ERR_DEVICE, "kernel launch: %s", hipGetErrorString(e));
+    return 0;
+  }
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// set-up
+// ---------------------------------------------------------------------------------------------
+int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
+  const int N = d->n_obs, S = d->n_sta, P = d->n_pts, C = d->n_cam;
+  if (N < 0 || S < 0 || P < 0 || C < 0) return fail(BA_ERR_INVALID, "negative dimension");
+  if (in->model != 0) return fail(BA_ERR_UNSUPPORTED, "projection model %d is not implemented (0 = collinearity)", in->model);
+  if (N > 0 && (!in->obs_pt || !in->obs_sta || !in->obs_x || !in->obs_y || !in->obs_sx || !in->obs_sy || !in->obs_cx || !in->obs_cy))
+    return fail(BA_ERR_INVALID, "null observation array");
+  if ((S > 0 && !in->sta_cam) || (P > 0 && (!in->pt_prior || !in->pt_sigma)) ||
+      (C > 0 && (!in->iop_prior || !in->iop_sigma || !in->ap_free_mask || !in->iop_free_mask)))
+    return fail(BA_ERR_INVALID, "null station / point / camera array");
+  p->N = N; p->S = S; p->P = P; p->C = C;
+  p->huber_a = in->huber_a;
+  for (int n = 0; n < N; ++n) {
+    if (in->obs_pt[n] < 0 || in->obs_pt[n] >= P) return fail(BA_ERR_INVALID, "observation %d: point index %d out of range [0,%d)", n, in->obs_pt[n], P);
+    if (in->obs_sta[n] < 0 || in->obs_sta[n] >= S) return fail(BA_ERR_INVALID, "observation %d: station index %d out of range [0,%d)", n, in->obs_sta[n], S);
+    if (!(in->obs_sx[n] > 0.0) || !(in->obs_sy[n] > 0.0)) return fail(BA_ERR_INVALID, "observation %d: standard deviation must be positive", n);
+  }
+  for (int i = 0; i < S; ++i)
+    if (in->sta_cam[i] < 0 || in->sta_cam[i] >= C) return fail(BA_ERR_INVALID, "station %d: camera index %d out of range [0,%d)", i, in->sta_cam[i], C);
+  for (int64_t k = 0; k < 3 * (int64_t)P; ++k)
+    if (!(in->pt_sigma[k] > 0.0)) return fail(BA_ERR_INVALID, "point %lld: prior sigma must be positive", (long long)(k / 3));
+  for (int k = 0; k < 3 * C; ++k)
+    if (!(in->iop_sigma[k] > 0.0)) return fail(BA_ERR_INVALID, "camera %d: prior sigma must be positive", k / 3);
+
+  p->obs_pt_h.assign(in->obs_pt, in->obs_pt + N);
+  p->obs_sta_h.assign(in->obs_sta, in->obs_sta + N);
+  p->sta_cam_h.assign(in->sta_cam, in->sta_cam + S);
+  p->ap_mask_h.assign(in->ap_free_mask, in->ap_free_mask + C);
+  p->iop_mask_h.assign(in->iop_free_mask, in->iop_free_mask + C);
+  p->sta_used_h.assign(S, 0);
+  std::vector<int> cam_used(C, 0);
+  std::vector<int> deg(P, 0), sdeg(S, 0);
+  for (int n = 0; n < N; ++n) {
+    p->sta_used_h[in->obs_sta[n]] = 1;
+    cam_used[in->sta_cam[in->obs_sta[n]]] = 1;
+    deg[in->obs_pt[n]]++;
+    sdeg[in->obs_sta[n]]++;
+  }
+  // cameras: free-parameter lists (src/main.cpp:4479-4511 for the AP; an AP block that no
+  // observation references is not part of the reduced program)
+  p->cam_h.assign(C, CamRec());
+  int off = 0;
+  for (int c = 0; c < C; ++c) {
+    CamRec &r = p->cam_h[c];
+    std::memset(&r, 0, sizeof r);
+    unsigned mask = in->iop_free_mask[c] & 7u;
+    if (cam_used[c]) mask |= (unsigned)in->ap_free_mask[c] << 3;
+    r.mask = mask;
+    r.nc = popcount32(mask);
+    r.off = off;
+    off += r.nc;
+    r.in_program = ((in->iop_free_mask[c] & 7u) ? 1 : 0) | ((in->ap_free_mask[c] && cam_used[c]) ? 2 : 0);
+    for (int k = 0; k < BA_NCAMPAR; ++k) r.scale[k] = 1.0;
+    for (int k = 0; k < 3; ++k) {
+      r.prior[k] = in->iop_prior[3 * c + k];
+      r.isig[k] = 1.0 / in->iop_sigma[3 * c + k];
+    }
+    p->ncmax = std::max(p->ncmax, r.nc);
+  }
+  p->ncam = off;
+  p->nr = 6 * S + p->ncam;
+
+  // internal point order: by number of observations (descending, stable) so that the lanes of
+  // a wave walk segments of similar length
+  p->pt_file.resize(P);
+  std::iota(p->pt_file.begin(), p->pt_file.end(), 0);
+  std::stable_sort(p->pt_file.begin(), p->pt_file.end(), [&](int a, int b) { return deg[a] > deg[b]; });
+  std::vector<int> pt_int(P);
+  for (int jj = 0; jj < P; ++jj) pt_int[p->pt_file[jj]] = jj;
+  std::vector<int> pt_start(P + 1, 0);
+  for (int jj = 0; jj < P; ++jj) pt_start[jj + 1] = pt_start[jj] + deg[p->pt_file[jj]];
+  // observations sorted by internal point, file order inside a point
+  std::vector<int> fill(pt_start.begin(), pt_start.end() - 1);
+  std::vector<double> obs((size_t)N * BA_OBS_STRIDE, 0.0);
+  std::vector<int> obs_pt(N), e_sta(N);
+  for (int n = 0; n < N; ++n) {
+    const int jj = pt_int[in->obs_pt[n]];
+    const int e = fill[jj]++;
+    double *o = &obs[(size_t)e * BA_OBS_STRIDE];
+    o[0] = in->obs_x[n]; o[1] = in->obs_y[n]; o[2] = in->obs_sx[n]; o[3] = in->obs_sy[n];
+    o[4] = in->obs_cx[n]; o[5] = in->obs_cy[n];
+    int32_t w[2] = {in->obs_sta[n], n};
+    std::memcpy(&o[6], w, sizeof w);
+    obs_pt[e] = jj;
+    e_sta[e] = in->obs_sta[n];
+  }
+  // station-sorted index list and its chunks
+  std::vector<int> sta_start(S + 1, 0);
+  for (int i = 0; i < S; ++i) sta_start[i + 1] = sta_start[i] + sdeg[i];
+  std::vector<int> sfill(sta_start.begin(), sta_start.end() - 1), sta_list(N);
+  for (int e = 0; e < N; ++e) sta_list[sfill[e_sta[e]]++] = e;
+  std::vector<int> chunk_sta, chunk_begin, sta_chunk0(S + 1, 0);
+  for (int i = 0; i < S; ++i) {
+    sta_chunk0[i] = (int)chunk_sta.size();
+    for (int b = sta_start[i]; b < sta_start[i + 1]; b += BA_CHUNK) {
+      chunk_sta.push_back(i);
+      chunk_begin.push_back(b);
+    }
+  }
+  sta_chunk0[S] = (int)chunk_sta.size();
+  chunk_begin.push_back(N);
+  // a chunk ends where the next begins, except at a station boundary
+  p->n_chunks = (int)chunk_sta.size();
+  std::vector<int> chunk_range(p->n_chunks + 1);
+  for (int ch = 0; ch < p->n_chunks; ++ch) chunk_range[ch] = chunk_begin[ch];
+  chunk_range[p->n_chunks] = N;
+  // (chunks are laid out in station order and stations are contiguous in sta_list, so
+  //  chunk_begin[ch+1] is also the end of chunk ch)
+
+  std::vector<double> prior(3 * (size_t)P), isig(3 * (size_t)P);
+  for (int jj = 0; jj < P; ++jj)
+    for (int k = 0; k < 3; ++k) {
+      prior[3 * (size_t)jj + k] = in->pt_prior[3 * (size_t)p->pt_file[jj] + k];
+      isig[3 * (size_t)jj + k] = 1.0 / in->pt_sigma[3 * (size_t)p->pt_file[jj] + k];
+    }
+
+  HIP_OK(hipStreamCreate(&p->stream));
+  BA_TRY(p->upload(&p->d_pt_start, pt_start));
+  BA_TRY(p->upload(&p->d_obs_pt, obs_pt));
+  BA_TRY(p->upload(&p->d_sta_list, sta_list));
+  BA_TRY(p->upload(&p->d_chunk_sta, chunk_sta));
+  BA_TRY(p->upload(&p->d_chunk_begin, chunk_range));
+  BA_TRY(p->upload(&p->d_sta_chunk0, sta_chunk0));
+  BA_TRY(p->upload(&p->d_sta_cam, p->sta_cam_h));
+  BA_TRY(p->upload(&p->d_pt_file, p->pt_file));
+  BA_TRY(p->upload(&p->d_sta_used, p->sta_used_h));
+  BA_TRY(p->upload(&p->d_obs, obs));
+  BA_TRY(p->upload(&p->d_pt_prior, prior));
+  BA_TRY(p->upload(&p->d_pt_isig, isig));
+  BA_TRY(p->upload(&p->d_cam, p->cam_h));
+  BA_TRY(p->dalloc(&p->d_cam_c, (size_t)C));
+  BA_TRY(p->dalloc(&p->d_info, 4));
+  BA_TRY(p->dalloc(&p->d_flags, 4));
+  BA_TRY(p->dalloc(&p->d_eop, 6 * (size_t)S));
+  BA_TRY(p->dalloc(&p->d_eop_c, 6 * (size_t)S));
+  BA_TRY(p->dalloc(&p->d_xyz, 3 * (size_t)P));
+  BA_TRY(p->dalloc(&p->d_xyz_c, 3 * (size_t)P));
+  BA_TRY(p->dalloc(&p->d_sta, (size_t)BA_STA_STRIDE * S));
+  BA_TRY(p->dalloc(&p->d_sta_c, (size_t)BA_STA_STRIDE * S));
+  BA_TRY(p->dalloc(&p->d_scale_pt, 3 * (size_t)P));
+  BA_TRY(p->dalloc(&p->d_scale_sta, 6 * (size_t)S));
+  BA_TRY(p->dalloc(&p->d_scale_cam, (size_t)p->ncam));
+  BA_TRY(p->dalloc(&p->d_rec, (size_t)BA_REC_STRIDE * N));
+  BA_TRY(p->dalloc(&p->d_Jp, 6 * (size_t)N));
+  BA_TRY(p->dalloc(&p->d_Jc, 2 * (size_t)p->ncmax * N));
+  BA_TRY(p->dalloc(&p->d_Mo, 3 * (size_t)N));
+  BA_TRY(p->dalloc(&p->d_Vinv, 6 * (size_t)P));
+  BA_TRY(p->dalloc(&p->d_g_pt, 3 * (size_t)P));
+  BA_TRY(p->dalloc(&p->d_y_pt, 3 * (size_t)P));
+  BA_TRY(p->dalloc(&p->d_colnorm_pt, 3 * (size_t)P));
+  BA_TRY(p->dalloc(&p->d_diag_pt, 3 * (size_t)P));
+  BA_TRY(p->dalloc(&p->d_colnorm_sta, 6 * (size_t)S));
+  BA_TRY(p->dalloc(&p->d_diag_sta, 6 * (size_t)S));
+  BA_TRY(p->dalloc(&p->d_colnorm_cam, (size_t)p->ncam));
+  BA_TRY(p->dalloc(&p->d_colnorm_cam_in, (size_t)p->ncam));
+  BA_TRY(p->dalloc(&p->d_diag_cam, (size_t)p->ncam));
+  BA_TRY(p->dalloc(&p->d_d2_cam, (size_t)p->ncam));
+  BA_TRY(p->dalloc(&p->d_jc2, (size_t)p->ncam));
+  BA_TRY(p->dalloc(&p->d_diagfull, (size_t)p->nr));
+  p->d_d2_sta = p->d_diagfull;
+  BA_TRY(p->dalloc(&p->d_F, 39 * (size_t)S));
+  BA_TRY(p->dalloc(&p->d_part, 39 * (size_t)p->n_chunks));
+  p->n_partial = 4 * std::max(std::max(linearize_blocks(P), cost_blocks(N)), cost_blocks(6 * (int64_t)S + 3 * (int64_t)P)) + 16;
+  BA_TRY(p->dalloc(&p->d_partial, (size_t)p->n_partial));
+  BA_TRY(p->dalloc(&p->d_scal, (size_t)SC_COUNT));
+  BA_TRY(p->dalloc(&p->d_cgscal, 8));
+  HIP_OK(hipHostMalloc((void **)&p->h_scal, SC_COUNT * sizeof(double)));
+  HIP_OK(hipHostMalloc((void **)&p->h_cgscal, 8 * sizeof(double)));
+  const size_t nr = (size_t)p->nr;
+  BA_TRY(p->dalloc(&p->d_g, nr)); BA_TRY(p->dalloc(&p->d_b, nr)); BA_TRY(p->dalloc(&p->d_x, nr));
+  BA_TRY(p->dalloc(&p->d_r, nr)); BA_TRY(p->dalloc(&p->d_z, nr)); BA_TRY(p->dalloc(&p->d_p, nr));
+  BA_TRY(p->dalloc(&p->d_q, nr));
+  BA_TRY(p->dalloc(&p->d_Minv, 36 * (size_t)S));
+  BA_TRY(p->dalloc(&p->d_Ssc, 6 * (size_t)S * p->ncam));
+  BA_TRY(p->dalloc(&p->d_Scc, (size_t)p->ncam * p->ncam));
+  BA_TRY(p->dalloc(&p->d_Lcc, (size_t)p->ncam * p->ncam));
+  HIP_OK(hipMemsetAsync(p->d_flags, 0, 4 * sizeof(unsigned), p->stream));
+  HIP_OK(hipMemsetAsync(p->d_scal, 0, SC_COUNT * sizeof(double), p->stream));
+  HIP_OK(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+int set_parameters(ba_problem *p, const double *eop, const double *xyz, const double *iop, const double *ap, bool candidate) {
+  if ((p->S && !eop) || (p->P && !xyz) || (p->C && (!iop || !ap))) return fail(BA_ERR_INVALID, "null parameter array");
+  std::vector<double> x(3 * (size_t)p->P);
+  for (int jj = 0; jj < p->P; ++jj)
+    for (int k = 0; k < 3; ++k) x[3 * (size_t)jj + k] = xyz[3 * (size_t)p->pt_file[jj] + k];
+  std::vector<CamRec> cam = p->cam_h;
+  for (int c = 0; c < p->C; ++c) {
+    for (int k = 0; k < 3; ++k) cam[c].iop[k] = iop[3 * c + k];
+    for (int k = 0; k < 16; ++k) cam[c].ap[k] = ap[16 * c + k];
+  }
+  double *de = candidate ? p->d_eop_c : p->d_eop, *dx = candidate ? p->d_xyz_c : p->d_xyz;
+  CamRec *dc = candidate ? p->d_cam_c : p->d_cam;
+  if (p->S) HIP_OK(hipMemcpyAsync(de, eop, 6 * (size_t)p->S * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  if (p->P) HIP_OK(hipMemcpyAsync(dx, x.data(), x.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  if (p->C) HIP_OK(hipMemcpyAsync(dc, cam.data(), cam.size() * sizeof(CamRec), hipMemcpyHostToDevice, p->stream));
+  HIP_OK(hipStreamSynchronize(p->stream));
+  if (!candidate) {
+    p->cam_h = cam;
+    p->have_params = true;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// phases of one LM iteration
+// ---------------------------------------------------------------------------------------------
+struct LmState {
+  double radius, lm_min, lm_max;
+  bool reuse_diag;
+  bool need_norms;  // column norms of the camera block are only needed when they are not clamped away
+};
+
+StationArgs station_args(ba_problem *p, int voff, int stride) {
+  StationArgs a{};
+  a.n_chunks = p->n_chunks; a.ncmax = p->ncmax; a.voff = voff; a.out_stride = stride;
+  a.chunk_sta = p->d_chunk_sta; a.chunk_begin = p->d_chunk_begin; a.sta_list = p->d_sta_list; a.sta_cam = p->d_sta_cam;
+  a.rec = p->d_rec; a.Jc = p->d_Jc; a.Mo = p->d_Mo; a.cam = p->d_cam; a.out = p->d_part;
+  return a;
+}
+
+PointArgs point_args(ba_problem *p, const double *vec) {
+  PointArgs a{};
+  a.P = p->P; a.S = p->S; a.ncmax = p->ncmax;
+  a.pt_start = p->d_pt_start; a.obs = p->d_obs; a.sta = p->d_sta; a.Jp = p->d_Jp; a.Jc = p->d_Jc; a.Vinv = p->d_Vinv;
+  a.vec = vec; a.cam = p->d_cam; a.rec = p->d_rec;
+  a.g_pt = p->d_g_pt; a.xyz = p->d_xyz; a.pt_prior = p->d_pt_prior; a.pt_isig = p->d_pt_isig; a.scale_pt = p->d_scale_pt;
+  a.y_pt = p->d_y_pt; a.partial = p->d_partial;
+  return a;
+}
+
+// camera rows of J^T v for v = rec[voff]: station sweep with the camera columns, fold per camera
+int camera_rows(ba_problem *p, int voff, double *out_cam) {
+  if (p->ncam == 0) return 0;
+  StationArgs sa = station_args(p, voff, 6 + BA_NCAMPAR);
+  launch_station_pass(p->stream, sa, SMODE_GATHER_CAM);
+  launch_camera_fold(p->stream, p->C, p->n_chunks, p->d_chunk_sta, p->d_sta_cam, p->d_cam, p->d_part, 6 + BA_NCAMPAR, 6, out_cam);
+  return p->allreduce(out_cam, p->ncam, 0);
+}
+
+// Residuals, Jacobians, point elimination, station blocks, gradient, reduced right-hand side.
+// Leaves cost in h_scal[SC_COST] (+ SC_FIXED) and the max-norm of the gradient in h_scal[SC_GMAX].
+int linearize(ba_problem *p, const LmState &st) {
+  hipStream_t s = p->stream;
+  launch_station_prep(s, p->S, p->d_eop, p->d_scale_sta, p->d_sta_cam, p->d_sta);
+  LinArgs la{};
+  la.P = p->P; la.ncmax = p->ncmax; la.pt_start = p->d_pt_start; la.obs = p->d_obs; la.sta = p->d_sta; la.xyz = p->d_xyz;
+  la.scale_pt = p->d_scale_pt; la.pt_prior = p->d_pt_prior; la.pt_isig = p->d_pt_isig; la.cam = p->d_cam;
+  la.rec = p->d_rec; la.Jp = p->d_Jp; la.Jc = p->d_Jc; la.Mo = p->d_Mo; la.Vinv = p->d_Vinv; la.g_pt = p->d_g_pt;
+  la.colnorm_pt = p->d_colnorm_pt; la.diag_pt = p->d_diag_pt; la.cost_partial = p->d_partial; la.flags = p->d_flags;
+  la.huber_a = p->huber_a; la.lm_min = st.lm_min; la.lm_max = st.lm_max; la.radius = st.radius; la.reuse_diag = st.reuse_diag;
+  launch_linearize(s, la);
+  launch_sum_partials(s, p->d_partial, linearize_blocks(p->P), p->d_scal, SC_COST);
+  BA_TRY(p->allreduce(p->d_scal + SC_COST, 1, 0));
+  launch_camera_prior_cost(s, p->C, p->d_cam, p->d_scal, SC_COST, SC_FIXED, nullptr);
+  // station blocks
+  StationArgs sa = station_args(p, 6, 39);
+  launch_station_pass(s, sa, SMODE_SETUP);
+  launch_station_fold(s, p->S, p->d_sta_chunk0, p->d_part, 39, 39, p->d_F);
+  BA_TRY(p->allreduce(p->d_F, 39 * (int64_t)p->S, 0));
+  StationFinishArgs fa{};
+  fa.S = p->S; fa.reuse_diag = st.reuse_diag; fa.sta_used = p->d_sta_used; fa.F = p->d_F;
+  fa.lm_min = st.lm_min; fa.lm_max = st.lm_max; fa.radius = st.radius;
+  fa.colnorm_sta = p->d_colnorm_sta; fa.diag_sta = p->d_diag_sta; fa.d2_sta = p->d_d2_sta; fa.g_sta = p->d_g; fa.b_sta = p->d_b;
+  fa.Minv = p->d_Minv; fa.flags = p->d_flags;
+  launch_station_finish(s, fa);
+  // camera rows of the gradient and of the reduced right-hand side
+  if (p->ncam > 0) {
+    BA_TRY(camera_rows(p, 6, p->d_g + 6 * (size_t)p->S));
+    BA_TRY(camera_rows(p, 7, p->d_b + 6 * (size_t)p->S));
+    if (st.need_norms) {
+      StationArgs sn = station_args(p, 6, BA_NCAMPAR);
+      launch_station_pass(s, sn, SMODE_CAMNORM);
+      launch_camera_fold(s, p->C, p->n_chunks, p->d_chunk_sta, p->d_sta_cam, p->d_cam, p->d_part, BA_NCAMPAR, 0, p->d_colnorm_cam_in);
+      BA_TRY(p->allreduce(p->d_colnorm_cam_in, p->ncam, 0));
+    }
+    CamFinishArgs ca{};
+    ca.C = p->C; ca.reuse_diag = st.reuse_diag; ca.need_norms = st.need_norms; ca.cam = p->d_cam;
+    ca.colnorm_in = st.need_norms ? p->d_colnorm_cam_in : nullptr;
+    ca.lm_min = st.lm_min; ca.lm_max = st.lm_max; ca.radius = st.radius;
+    ca.jc2 = p->d_jc2; ca.colnorm_cam = p->d_colnorm_cam; ca.diag_cam = p->d_diag_cam; ca.d2_cam = p->d_d2_cam;
+    ca.camdiag = p->d_diagfull + 6 * (size_t)p->S; ca.g_cam = p->d_g + 6 * (size_t)p->S; ca.b_cam = p->d_b + 6 * (size_t)p->S;
+    launch_camera_finish(s, ca);
+  }
+  // gradient max norm: |g_scaled / scale| over points (local), stations and cameras (replicated)
+  const int bp = cost_blocks(3 * (int64_t)p->P), bs = cost_blocks(6 * (int64_t)p->S);
+  launch_absmax_ratio(s, 3 * (int64_t)p->P, p->d_g_pt, p->d_scale_pt, p->d_partial, bp);
+  launch_max_partials(s, p->d_partial, bp, p->d_scal, SC_GMAX_P);
+  BA_TRY(p->allreduce(p->d_scal + SC_GMAX_P, 1, 1));
+  launch_absmax_ratio(s, 6 * (int64_t)p->S, p->d_g, p->d_scale_sta, p->d_partial + bp, bs);
+  launch_max_partials(s, p->d_partial + bp, bs, p->d_scal, SC_GMAX_SC);
+  if (p->ncam > 0) {
+    launch_absmax_ratio(s, p->ncam, p->d_g + 6 * (size_t)p->S, p->d_scale_cam, p->d_partial + bp + bs, 1);
+    launch_max_partials(s, p->d_partial + bp + bs, 1, p->d_scal, SC_GMAX);
+  } else {
+    HIP_OK(hipMemsetAsync(p->d_scal + SC_GMAX, 0, sizeof(double), s));
+  }
+  BA_TRY(p->check_kernels());
+  BA_TRY(p->read_scal());
+  p->h_scal[SC_GMAX] = std::max(p->h_scal[SC_GMAX], std::max(p->h_scal[SC_GMAX_P], p->h_scal[SC_GMAX_SC]));
+  unsigned flags[4];
+  HIP_OK(hipMemcpy(flags, p->d_flags, sizeof flags, hipMemcpyDeviceToHost));
+  if (flags[0]) {
+    HIP_OK(hipMemset(p->d_flags, 0, sizeof flags));
+    return fail(BA_ERR_NUMERIC, "%s block is not positive definite", (flags[0] & 1) ? "a point" : "a station");
+  }
+  return 0;
+}
+
+// v = S e_k through the implicit operator: point sweep (with camera columns), station sweep
+// (with camera rows), folds, sum over ranks, diagonal entry.  out has nr entries.
+int probe_column(ba_problem *p, int64_t k, double *out) {
+  hipStream_t s = p->stream;
+  launch_unit(s, p->nr, p->d_p, k);
+  PointArgs pa = point_args(p, p->d_p);
+  launch_point_pass(s, pa, MODE_APPLY, p->ncam > 0);
+  if (p->ncam > 0) {
+    StationArgs sa = station_args(p, 7, 6 + BA_NCAMPAR);
+    launch_station_pass(s, sa, SMODE_GATHER_CAM);
+    launch_station_fold(s, p->S, p->d_sta_chunk0, p->d_part, 6 + BA_NCAMPAR, 6, out);
+    launch_camera_fold(s, p->C, p->n_chunks, p->d_chunk_sta, p->d_sta_cam, p->d_cam, p->d_part, 6 + BA_NCAMPAR, 6, out + 6 * (size_t)p->S);
+  } else {
+    StationArgs sa = station_args(p, 7, 6);
+    launch_station_pass(s, sa, SMODE_GATHER);
+    launch_station_fold(s, p->S, p->d_sta_chunk0, p->d_part, 6, 6, out);
+  }
+  BA_TRY(p->allreduce(out, p->nr, 0));
+  launch_add_diag_entry(s, out, p->d_diagfull, k);
+  return 0;
+}
+
+// explicit camera border of the reduced matrix and the Cholesky factor of its camera block
+int build_border(ba_problem *p) {
+  if (p->ncam == 0) return 0;
+  hipStream_t s = p->stream;
+  const size_t ns = 6 * (size_t)p->S;
+  for (int k = 0; k < p->ncam; ++k) {
+    BA_TRY(probe_column(p, (int64_t)ns + k, p->d_q));
+    launch_copy(s, ns, p->d_q, p->d_Ssc + (size_t)k * ns);
+    launch_copy(s, p->ncam, p->d_q + ns, p->d_Scc + (size_t)k * p->ncam);
+  }
+  launch_copy(s, (int64_t)p->ncam * p->ncam, p->d_Scc, p->d_Lcc);
+  launch_cholesky(s, p->d_Lcc, p->ncam, p->d_info);
+  int info = 0;
+  HIP_OK(hipMemcpyAsync(&info, p->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  if (info) return fail(BA_ERR_NUMERIC, "camera block of the reduced system is not positive definite (column %d)", info - 1);
+  return 0;
+}
+
+// block-Jacobi preconditioned conjugate gradients on the reduced system; solution in d_x
+int solve_pcg(ba_problem *p, const ba_options *opt, int *iters) {
+  hipStream_t s = p->stream;
+  BA_TRY(build_border(p));
+  CgArgs ca{};
+  ca.n = p->nr; ca.S = p->S; ca.ncam = p->ncam; ca.b = p->d_b; ca.Minv = p->d_Minv; ca.Lcc = p->d_Lcc; ca.Ssc = p->d_Ssc;
+  ca.Scc = p->d_Scc; ca.d2_sta = p->d_d2_sta; ca.x = p->d_x; ca.r = p->d_r; ca.z = p->d_z; ca.p = p->d_p; ca.q = p->d_q;
+  ca.scal = p->d_cgscal;
+  launch_cg_init(s, ca);
+  HIP_OK(hipMemcpyAsync(p->h_cgscal, p->d_cgscal, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  const double rz0 = p->h_cgscal[1];
+  int it = 0;
+  if (!(rz0 > 0.0)) {
+    *iters = 0;
+    return std::isfinite(rz0) ? 0 : fail(BA_ERR_NUMERIC, "PCG: non-finite right-hand side");
+  }
+  const double target = opt->pcg_rtol * std::sqrt(rz0);
+  StationArgs sa = station_args(p, 7, 6);
+  PointArgs pa = point_args(p, p->d_p);
+  while (it < opt->pcg_max_iters) {
+    launch_point_pass(s, pa, MODE_APPLY, false);
+    launch_station_pass(s, sa, SMODE_GATHER);
+    launch_station_fold(s, p->S, p->d_sta_chunk0, p->d_part, 6, 6, p->d_q);
+    BA_TRY(p->allreduce(p->d_q, 6 * (int64_t)p->S, 0));
+    launch_cg_step(s, ca);
+    HIP_OK(hipMemcpyAsync(p->h_cgscal, p->d_cgscal, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    ++it;
+    const double rz = p->h_cgscal[0], pq = p->h_cgscal[3];
+    if (!std::isfinite(rz) || !(pq > 0.0)) {
+      *iters = it;
+      return fail(BA_ERR_NUMERIC, "PCG breakdown at iteration %d (p.Sp = %g)", it, pq);
+    }
+    if (std::sqrt(std::max(rz, 0.0)) <= target) break;
+  }
+  *iters = it;
+  return p->check_kernels();
+}
+
+// dense reduced matrix (one implicit-operator probe per column), Cholesky on the matrix cores
+int solve_dense(ba_problem *p) {
+  hipStream_t s = p->stream;
+  const size_t nr = (size_t)p->nr;
+  if (!p->d_Sdense) {
+    if ((double)nr * nr * 8.0 > 64e9) return fail(BA_ERR_INVALID, "dense reduced system of order %zu does not fit; use the PCG solver", nr);
+    BA_TRY(p->dalloc(&p->d_Sdense, nr * nr));
+  }
+  for (size_t k = 0; k < nr; ++k) BA_TRY(probe_column(p, (int64_t)k, p->d_Sdense + k * nr));
+  launch_cholesky(s, p->d_Sdense, p->nr, p->d_info);
+  launch_copy(s, p->nr, p->d_b, p->d_x);
+  launch_chol_solve(s, p->d_Sdense, p->nr, p->d_x);
+  int info = 0;
+  HIP_OK(hipMemcpyAsync(&info, p->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  BA_TRY(p->check_kernels());
+  if (info) return fail(BA_ERR_NUMERIC, "reduced Cholesky failed at column %d of %d", info - 1, p->nr);
+  return 0;
+}
+
+// y_p = V^-1 (g_p - W^T y_c); model cost change; candidate = x - y*scale; norms.  Reads d_x.
+int step_and_candidate(ba_problem *p) {
+  hipStream_t s = p->stream;
+  PointArgs pa = point_args(p, p->d_x);
+  launch_point_pass(s, pa, MODE_BACKSUB, p->ncam > 0);
+  launch_sum_partials(s, p->d_partial, linearize_blocks(p->P), p->d_scal, SC_MCC);
+  BA_TRY(p->allreduce(p->d_scal + SC_MCC, 1, 0));
+  launch_camera_mcc(s, p->C, p->d_cam, p->d_x + 6 * (size_t)p->S, p->d_scal, SC_MCC);
+  CandArgs ca{};
+  ca.S = p->S; ca.P = p->P; ca.C = p->C; ca.sta_used = p->d_sta_used; ca.eop = p->d_eop; ca.xyz = p->d_xyz; ca.y_cam = p->d_x;
+  ca.y_pt = p->d_y_pt; ca.scale_sta = p->d_scale_sta; ca.scale_pt = p->d_scale_pt; ca.cam = p->d_cam;
+  ca.eop_c = p->d_eop_c; ca.xyz_c = p->d_xyz_c; ca.cam_c = p->d_cam_c; ca.partial = p->d_partial;
+  const int nb = cost_blocks(6 * (int64_t)p->S + 3 * (int64_t)p->P);
+  launch_candidate(s, ca, nb);
+  launch_sum_partials(s, p->d_partial, nb, p->d_scal, SC_STEP2_SC);
+  launch_sum_partials(s, p->d_partial + nb, nb, p->d_scal, SC_CNORM2_SC);
+  launch_sum_partials(s, p->d_partial + 2 * nb, nb, p->d_scal, SC_STEP2_P);
+  launch_sum_partials(s, p->d_partial + 3 * nb, nb, p->d_scal, SC_CNORM2_P);
+  BA_TRY(p->allreduce(p->d_scal + SC_STEP2_P, 2, 0));
+  return p->check_kernels();
+}
+
+int cost_at(ba_problem *p, const double *eop, const double *xyz, const CamRec *cam, double *sta_buf, int slot, int fixed_slot,
+            int apply_loss, double *res_out) {
+  hipStream_t s = p->stream;
+  launch_station_prep(s, p->S, eop, p->d_scale_sta, p->d_sta_cam, sta_buf);
+  CostArgs ca{};
+  ca.N = p->N; ca.obs = p->d_obs; ca.sta = sta_buf; ca.xyz = xyz; ca.obs_pt = p->d_obs_pt; ca.cam = cam; ca.huber_a = p->huber_a;
+  ca.apply_loss = apply_loss; ca.res_out = res_out; ca.partial = p->d_partial;
+  const int b1 = cost_blocks(p->N), b2 = cost_blocks(3 * (int64_t)p->P);
+  launch_cost_obs(s, ca, b1);
+  launch_cost_prior(s, p->P, xyz, p->d_pt_prior, p->d_pt_isig, p->d_pt_file, res_out ? res_out + 2 * (size_t)p->N : nullptr,
+                    p->d_partial + b1, b2);
+  launch_sum_partials(s, p->d_partial, b1 + b2, p->d_scal, slot);
+  BA_TRY(p->allreduce(p->d_scal + slot, 1, 0));
+  launch_camera_prior_cost(s, p->C, cam, p->d_scal, slot, fixed_slot,
+                           res_out ? res_out + 2 * (size_t)p->N + 3 * (size_t)p->P : nullptr);
+  return p->check_kernels();
+}
+
+int xnorm(ba_problem *p, double *out) {
+  hipStream_t s = p->stream;
+  CandArgs ca{};
+  ca.S = p->S; ca.P = p->P; ca.C = p->C; ca.sta_used = p->d_sta_used; ca.eop = p->d_eop; ca.xyz = p->d_xyz; ca.cam = p->d_cam;
+  ca.partial = p->d_partial;
+  const int nb = cost_blocks(6 * (int64_t)p->S + 3 * (int64_t)p->P);
+  launch_xnorm(s, ca, nb);
+  launch_sum_partials(s, p->d_partial, nb, p->d_scal, SC_XNORM2_SC);
+  launch_sum_partials(s, p->d_partial + nb, nb, p->d_scal, SC_XNORM2_P);
+  BA_TRY(p->allreduce(p->d_scal + SC_XNORM2_P, 1, 0));
+  BA_TRY(p->read_scal());
+  *out = std::sqrt(p->h_scal[SC_XNORM2_SC] + p->h_scal[SC_XNORM2_P]);
+  return 0;
+}
+
+// Jacobi scaling from the column norms of the unscaled Jacobian at the start point
+// [Ceres 1.13 TrustRegionMinimizer::EvaluateGradientAndJacobian, iteration 0]
+int init_scaling(ba_problem *p, const ba_options *opt) {
+  hipStream_t s = p->stream;
+  launch_fill(s, 3 * (int64_t)p->P, p->d_scale_pt, 1.0);
+  launch_fill(s, 6 * (int64_t)p->S, p->d_scale_sta, 1.0);
+  launch_fill(s, p->ncam, p->d_scale_cam, 1.0);
+  for (auto &c : p->cam_h)
+    for (int k = 0; k < BA_NCAMPAR; ++k) c.scale[k] = 1.0;
+  if (p->C) HIP_OK(hipMemcpyAsync(p->d_cam, p->cam_h.data(), p->cam_h.size() * sizeof(CamRec), hipMemcpyHostToDevice, s));
+  HIP_OK(hipStreamSynchronize(s));
+  if (!opt->jacobi_scaling) return 0;
+  LmState st{opt->initial_trust_region_radius, opt->min_lm_diagonal, opt->max_lm_diagonal, false, true};
+  BA_TRY(linearize(p, st));
+  launch_make_scale(s, 3 * (int64_t)p->P, p->d_colnorm_pt, p->d_scale_pt);
+  launch_make_scale(s, 6 * (int64_t)p->S, p->d_colnorm_sta, p->d_scale_sta);
+  if (p->ncam > 0) {
+    launch_make_scale(s, p->ncam, p->d_colnorm_cam, p->d_scale_cam);
+    std::vector<double> sc(p->ncam);
+    HIP_OK(hipMemcpyAsync(sc.data(), p->d_scale_cam, sc.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    for (auto &c : p->cam_h)
+      for (int k = 0; k < c.nc; ++k) c.scale[k] = sc[c.off + k];
+    HIP_OK(hipMemcpyAsync(p->d_cam, p->cam_h.data(), p->cam_h.size() * sizeof(CamRec), hipMemcpyHostToDevice, s));
+    HIP_OK(hipStreamSynchronize(s));
+  }
+  return p->check_kernels();
+}
+
+void fill_sizes(const ba_problem *p, ba_summary *sm) {
+  // [Ceres 1.13] reduced program: constant and unreferenced parameter blocks are removed,
+  // and with them the residual blocks that depend on constant blocks only
+  int nsu = 0;
+  for (int i = 0; i < p->S; ++i) nsu += p->sta_used_h[i];
+  int npar = 6 * nsu + 3 * p->P, nres = 2 * p->N + 3 * p->P;
+  for (int c = 0; c < p->C; ++c) {
+    if (p->cam_h[c].in_program & 1) { npar += 3; nres += 3; }
+    if (p->cam_h[c].in_program & 2) npar += 16;
+  }
+  sm->num_parameters = 6 * p->S + 3 * p->P + 19 * p->C;
+  sm->num_residuals = 2 * p->N + 3 * p->P + 3 * p->C;
+  sm->num_parameters_reduced = npar;
+  sm->num_effective_parameters_reduced = 6 * nsu + 3 * p->P + p->ncam;
+  sm->num_residuals_reduced = nres;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char *ba_last_error(void) { return g_err.c_str(); }
+
+void ba_default_options(ba_options *o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof *o);
+  o->min_lm_diagonal = 1.0E-150;  // src/main.cpp:4713
+  o->max_lm_diagonal = 1.0E-150;  // src/main.cpp:4712
+  o->initial_trust_region_radius = 1e4;
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+  o->max_num_iterations = 100;  // src/main.cpp:4718
+  o->max_num_consecutive_invalid_steps = 5;
+  o->jacobi_scaling = 1;
+  o->linear_solver = BA_SOLVER_DENSE_SCHUR;
+  o->pcg_rtol = 1e-12;
+  o->pcg_max_iters = 2000;
+}
+
+int ba_create(const ba_dims *dims, const ba_inputs *in, ba_problem **out) {
+  if (!dims || !in || !out) return fail(BA_ERR_INVALID, "ba_create: null argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(BA_ERR_DEVICE, "no HIP device is visible: this library has no CPU path");
+  ba_problem *p = new ba_problem();
+  const int rc = build_problem(p, dims, in);
+  if (rc) {
+    ba_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return 0;
+}
+
+void ba_destroy(ba_problem *p) {
+  if (!p) return;
+  if (p->stream) hipStreamSynchronize(p->stream);
+  if (p->comm) ncclCommDestroy(p->comm);
+  for (void *q : p->allocs) hipFree(q);
+  if (p->h_scal) hipHostFree(p->h_scal);
+  if (p->h_cgscal) hipHostFree(p->h_cgscal);
+  if (p->stream) hipStreamDestroy(p->stream);
+  delete p;
+}
+
+int ba_set_parameters(ba_problem *p, const double *eop, const double *xyz, const double *iop, const double *ap) {
+  if (!p) return fail(BA_ERR_INVALID, "ba_set_parameters: null problem");
+  return set_parameters(p, eop, xyz, iop, ap, false);
+}
+
+int ba_get_parameters(ba_problem *p, double *eop, double *xyz, double *iop, double *ap) {
+  if (!p) return fail(BA_ERR_INVALID, "ba_get_parameters: null problem");
+  if (!p->have_params) return fail(BA_ERR_INVALID, "ba_get_parameters: no parameters were set");
+  HIP_OK(hipStreamSynchronize(p->stream));
+  if (eop && p->S) HIP_OK(hipMemcpy(eop, p->d_eop, 6 * (size_t)p->S * sizeof(double), hipMemcpyDeviceToHost));
+  if (xyz && p->P) {
+    std::vector<double> x(3 * (size_t)p->P);
+    HIP_OK(hipMemcpy(x.data(), p->d_xyz, x.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int jj = 0; jj < p->P; ++jj)
+      for (int k = 0; k < 3; ++k) xyz[3 * (size_t)p->pt_file[jj] + k] = x[3 * (size_t)jj + k];
+  }
+  if ((iop || ap) && p->C) {
+    std::vector<CamRec> cam(p->C);
+    HIP_OK(hipMemcpy(cam.data(), p->d_cam, cam.size() * sizeof(CamRec), hipMemcpyDeviceToHost));
+    for (int c = 0; c < p->C; ++c) {
+      if (iop) for (int k = 0; k < 3; ++k) iop[3 * c + k] = cam[c].iop[k];
+      if (ap) for (int k = 0; k < 16; ++k) ap[16 * c + k] = cam[c].ap[k];
+    }
+  }
+  return 0;
+}
+
+// [Ceres 1.13] TrustRegionMinimizer::Minimize with LevenbergMarquardtStrategy and the monotonic
+// TrustRegionStepEvaluator; options as at src/main.cpp:4705-4719.
+int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary, ba_iter_row *rows, int32_t rows_cap) {
+  if (!p || !opt) return fail(BA_ERR_INVALID, "ba_solve_resident: null argument");
+  if (!p->have_params) return fail(BA_ERR_INVALID, "ba_solve_resident: call ba_set_parameters first");
+  if (opt->linear_solver != BA_SOLVER_DENSE_SCHUR && opt->linear_solver != BA_SOLVER_PCG_SCHUR)
+    return fail(BA_ERR_UNSUPPORTED, "linear_solver %d", opt->linear_solver);
+  if (!(opt->initial_trust_region_radius > 0.0)) return fail(BA_ERR_INVALID, "initial_trust_region_radius must be positive");
+  const double t_begin = now_s();
+  ba_summary sm;
+  std::memset(&sm, 0, sizeof sm);
+  fill_sizes(p, &sm);
+  int n_rows = 0;
+  LmState st{opt->initial_trust_region_radius, opt->min_lm_diagonal, opt->max_lm_diagonal, false,
+             opt->min_lm_diagonal != opt->max_lm_diagonal};
+  double decrease_factor = 2.0;
+  int num_invalid = 0;
+
+  // ---- IterationZero ----
+  double t0 = now_s();
+  BA_TRY(init_scaling(p, opt));
+  double x_norm = 0.0;
+  BA_TRY(xnorm(p, &x_norm));
+  BA_TRY(linearize(p, st));
+  double x_cost = p->h_scal[SC_COST];
+  const double fixed_cost = p->h_scal[SC_FIXED];
+  sm.initial_cost = x_cost + fixed_cost;
+  sm.fixed_cost = fixed_cost;
+  double min_iter_cost = sm.initial_cost;
+  ba_iter_row it;
+  std::memset(&it, 0, sizeof it);
+  it.step_is_valid = 1;
+  it.step_is_successful = 1;
+  it.cost = x_cost + fixed_cost;
+  it.gradient_max_norm = p->h_scal[SC_GMAX];
+  it.t_linearize_s = now_s() - t0;
+  sm.termination = BA_NO_CONVERGENCE;
+  bool linearized_for_radius = true;  // point/station blocks carry the LM diagonal of st.radius
+
+  for (;;) {
+    // ---- FinalizeIterationAndCheckIfMinimizerCanContinue ----
+    if (it.step_is_successful) sm.num_successful_steps++; else sm.num_unsuccessful_steps++;
+    it.trust_region_radius = st.radius;
+    if (rows && n_rows < rows_cap) rows[n_rows] = it;
+    n_rows++;
+    if (it.cost < min_iter_cost) min_iter_cost = it.cost;
+    if (it.iteration >= opt->max_num_iterations) { sm.termination = BA_NO_CONVERGENCE; sm.stop_reason = BA_STOP_MAX_ITERATIONS; break; }
+    if (it.step_is_successful && it.gradient_max_norm <= opt->gradient_tolerance) { sm.termination = BA_CONVERGENCE; sm.stop_reason = BA_STOP_GRADIENT_TOL; break; }
+    if (st.radius <= opt->min_trust_region_radius) { sm.termination = BA_CONVERGENCE; sm.stop_reason = BA_STOP_MIN_RADIUS; break; }
+
+    const int iter_no = it.iteration + 1;
+    const double prev_gmax = it.gradient_max_norm;
+    std::memset(&it, 0, sizeof it);
+    it.iteration = iter_no;
+    it.gradient_max_norm = prev_gmax;
+
+    // ---- LevenbergMarquardtStrategy::ComputeStep ----
+    t0 = now_s();
+    if (!linearized_for_radius) {
+      // same point, smaller radius: the eliminated blocks depend on the radius through D
+      st.reuse_diag = true;
+      BA_TRY(linearize(p, st));
+      it.t_linearize_s += now_s() - t0;
+      t0 = now_s();
+      linearized_for_radius = true;
+    }
+    int lin_iters = 0;
+    int lrc = (opt->linear_solver == BA_SOLVER_PCG_SCHUR) ? solve_pcg(p, opt, &lin_iters) : solve_dense(p);
+    it.linear_iterations = lin_iters;
+    sm.total_linear_iterations += lin_iters;
+    if (lrc != 0 && lrc != BA_ERR_NUMERIC) return lrc;
+    bool step_ok = (lrc == 0);
+    double mcc = 0.0;
+    if (step_ok) {
+      BA_TRY(step_and_candidate(p));
+      BA_TRY(p->read_scal());
+      mcc = -p->h_scal[SC_MCC];
+      it.step_norm = std::sqrt(p->h_scal[SC_STEP2_SC] + p->h_scal[SC_STEP2_P]);
+      step_ok = std::isfinite(mcc) && std::isfinite(it.step_norm);
+    }
+    it.t_solve_s = now_s() - t0;
+    // ---- ComputeTrustRegionStep: the step is valid when the model predicts a decrease ----
+    it.step_is_valid = step_ok && (mcc > 0.0);
+    if (!it.step_is_valid) {
+      // ---- HandleInvalidStep ----
+      if (++num_invalid >= opt->max_num_consecutive_invalid_steps) {
+        sm.termination = BA_FAILURE;
+        sm.stop_reason = BA_STOP_INVALID_STEPS;
+        break;
+      }
+      st.radius = st.radius / decrease_factor;
+      decrease_factor *= 2.0;
+      linearized_for_radius = false;
+      it.cost = x_cost + fixed_cost;
+      it.step_norm = 0.0;
+      it.step_is_successful = 0;
+      continue;
+    }
+    num_invalid = 0;
+
+    // ---- ComputeCandidatePointAndEvaluateCost ----
+    t0 = now_s();
+    BA_TRY(cost_at(p, p->d_eop_c, p->d_xyz_c, p->d_cam_c, p->d_sta_c, SC_CCOST, -1, 0, nullptr));
+    BA_TRY(p->read_scal());
+    double cand_cost = p->h_scal[SC_CCOST];
+    if (!std::isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
+    it.t_eval_s = now_s() - t0;
+
+    // ---- ParameterToleranceReached ----
+    if (it.step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) {
+      sm.termination = BA_CONVERGENCE;
+      sm.stop_reason = BA_STOP_PARAMETER_TOL;
+      break;
+    }
+    // ---- FunctionToleranceReached ----
+    it.cost_change = x_cost - cand_cost;
+    if (std::fabs(it.cost_change) <= opt->function_tolerance * x_cost) {
+      sm.termination = BA_CONVERGENCE;
+      sm.stop_reason = BA_STOP_FUNCTION_TOL;
+      break;
+    }
+    // ---- IsStepSuccessful ----
+    it.relative_decrease = it.cost_change / mcc;
+    if (it.relative_decrease > opt->min_relative_decrease) {
+      // ---- HandleSuccessfulStep ----
+      std::swap(p->d_eop, p->d_eop_c);
+      std::swap(p->d_xyz, p->d_xyz_c);
+      std::swap(p->d_cam, p->d_cam_c);
+      x_norm = std::sqrt(p->h_scal[SC_CNORM2_SC] + p->h_scal[SC_CNORM2_P]);
+      // LevenbergMarquardtStrategy::StepAccepted
+      st.radius = st.radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3.0));
+      st.radius = std::min(opt->max_trust_region_radius, st.radius);
+      decrease_factor = 2.0;
+      st.reuse_diag = false;
+      t0 = now_s();
+      BA_TRY(linearize(p, st));
+      it.t_linearize_s += now_s() - t0;
+      linearized_for_radius = true;
+      x_cost = p->h_scal[SC_COST];
+      it.gradient_max_norm = p->h_scal[SC_GMAX];
+      it.cost = x_cost + fixed_cost;
+      it.step_is_successful = 1;
+    } else {
+      // ---- HandleUnsuccessfulStep / StepRejected ----
+      it.step_is_successful = 0;
+      st.radius = st.radius / decrease_factor;
+      decrease_factor *= 2.0;
+      linearized_for_radius = false;
+      it.cost = cand_cost + fixed_cost;
+    }
+  }
+  // [Ceres 1.13 solver.cc SetSummaryFinalCost] minimum over the logged iterations
+  sm.final_cost = min_iter_cost;
+  sm.num_iterations = n_rows;
+  sm.t_total_s = now_s() - t_begin;
+  if (p->C) {
+    HIP_OK(hipMemcpy(p->cam_h.data(), p->d_cam, p->cam_h.size() * sizeof(CamRec), hipMemcpyDeviceToHost));
+  }
+  if (summary) *summary = sm;
+  return 0;
+}
+
+int ba_solve(ba_problem *p, const ba_options *opt, double *eop, double *xyz, double *iop, double *ap, ba_summary *summary,
+             ba_iter_row *rows, int32_t rows_cap) {
+  BA_TRY(ba_set_parameters(p, eop, xyz, iop, ap));
+  BA_TRY(ba_solve_resident(p, opt, summary, rows, rows_cap));
+  return ba_get_parameters(p, eop, xyz, iop, ap);
+}
+
+int ba_evaluate(ba_problem *p, const double *eop, const double *xyz, const double *iop, const double *ap, int apply_loss,
+                double *cost, double *residuals) {
+  if (!p) return fail(BA_ERR_INVALID, "ba_evaluate: null problem");
+  BA_TRY(set_parameters(p, eop, xyz, iop, ap, true));
+  double *d_res = nullptr;
+  const size_t nres = 2 * (size_t)p->N + 3 * (size_t)p->P + 3 * (size_t)p->C;
+  if (residuals) HIP_OK(hipMalloc((void **)&d_res, std::max<size_t>(nres, 1) * sizeof(double)));
+  // column scales do not enter the residuals; the station records only need valid memory
+  int rc = cost_at(p, p->d_eop_c, p->d_xyz_c, p->d_cam_c, p->d_sta_c, SC_CCOST, SC_FIXED, apply_loss, d_res);
+  if (!rc) rc = p->read_scal();
+  if (!rc && residuals && nres) {
+    if (hipMemcpy(residuals, d_res, nres * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(BA_ERR_DEVICE, "residual download failed");
+  }
+  if (d_res) hipFree(d_res);
+  if (rc) return rc;
+  if (cost) *cost = p->h_scal[SC_CCOST] + p->h_scal[SC_FIXED];
+  return 0;
+}
+
+int ba_residual_jacobian(ba_problem *p, double *r, double *J) {
+  if (!p) return fail(BA_ERR_INVALID, "ba_residual_jacobian: null problem");
+  if (!p->have_params) return fail(BA_ERR_INVALID, "ba_residual_jacobian: call ba_set_parameters first");
+  double *d_r = nullptr, *d_J = nullptr;
+  const size_t N = (size_t)p->N;
+  if (r) HIP_OK(hipMalloc((void **)&d_r, std::max<size_t>(2 * N, 1) * sizeof(double)));
+  if (J) {
+    hipError_t e = hipMalloc((void **)&d_J, std::max<size_t>(56 * N, 1) * sizeof(double));
+    if (e != hipSuccess) {
+      if (d_r) hipFree(d_r);
+      return fail(BA_ERR_DEVICE, "hipMalloc for the dense Jacobian (%zu bytes): %s", 56 * N * 8, hipGetErrorString(e));
+    }
+  }
+  launch_fill(p->stream, 6 * (int64_t)p->S, p->d_scale_sta, 1.0);
+  launch_station_prep(p->stream, p->S, p->d_eop, p->d_scale_sta, p->d_sta_cam, p->d_sta_c);
+  CostArgs ca{};
+  ca.N = p->N; ca.obs = p->d_obs; ca.sta = p->d_sta_c; ca.xyz = p->d_xyz; ca.obs_pt = p->d_obs_pt; ca.cam = p->d_cam;
+  ca.huber_a = p->huber_a;
+  launch_resjac_dense(p->stream, ca, d_r, d_J);
+  int rc = p->check_kernels();
+  if (!rc && hipStreamSynchronize(p->stream) != hipSuccess) rc = fail(BA_ERR_DEVICE, "residual/Jacobian kernel failed");
+  if (!rc && r && N && hipMemcpy(r, d_r, 2 * N * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(BA_ERR_DEVICE, "download failed");
+  if (!rc && J && N && hipMemcpy(J, d_J, 56 * N * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(BA_ERR_DEVICE, "download failed");
+  if (d_r) hipFree(d_r);
+  if (d_J) hipFree(d_J);
+  return rc;
+}
+
+int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *seconds_per_launch) {
+  if (!p || !seconds_per_launch || repeats < 1) return fail(BA_ERR_INVALID, "ba_time_kernel: bad argument");
+  if (!p->have_params) return fail(BA_ERR_INVALID, "ba_time_kernel: call ba_set_parameters first");
+  hipStream_t s = p->stream;
+  ba_options opt;
+  ba_default_options(&opt);
+  // a valid linearisation (scales, station records, Jacobians) for the kernels to run on
+  BA_TRY(init_scaling(p, &opt));
+  LmState st{opt.initial_trust_region_radius, opt.min_lm_diagonal, opt.max_lm_diagonal, false, false};
+  BA_TRY(linearize(p, st));
+  launch_copy(s, p->nr, p->d_b, p->d_p);
+  LinArgs la{};
+  la.P = p->P; la.ncmax = p->ncmax; la.pt_start = p->d_pt_start; la.obs = p->d_obs; la.sta = p->d_sta; la.xyz = p->d_xyz;
+  la.scale_pt = p->d_scale_pt; la.pt_prior = p->d_pt_prior; la.pt_isig = p->d_pt_isig; la.cam = p->d_cam;
+  la.rec = p->d_rec; la.Jp = p->d_Jp; la.Jc = p->d_Jc; la.Mo = p->d_Mo; la.Vinv = p->d_Vinv; la.g_pt = p->d_g_pt;
+  la.colnorm_pt = p->d_colnorm_pt; la.diag_pt = p->d_diag_pt; la.cost_partial = p->d_partial; la.flags = p->d_flags;
+  la.huber_a = p->huber_a; la.lm_min = st.lm_min; la.lm_max = st.lm_max; la.radius = st.radius; la.reuse_diag = 0;
+  PointArgs pa = point_args(p, p->d_p);
+  StationArgs sa = station_args(p, 7, 6);
+  CostArgs ca{};
+  ca.N = p->N; ca.obs = p->d_obs; ca.sta = p->d_sta; ca.xyz = p->d_xyz; ca.obs_pt = p->d_obs_pt; ca.cam = p->d_cam;
+  ca.huber_a = p->huber_a; ca.partial = p->d_partial;
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0));
+  HIP_OK(hipEventCreate(&e1));
+  auto run = [&]() {
+    switch (which) {
+      case 0: launch_linearize(s, la); break;
+      case 1: launch_point_pass(s, pa, MODE_APPLY, false); break;
+      case 2: launch_station_pass(s, sa, SMODE_GATHER); break;
+      case 3: launch_cost_obs(s, ca, cost_blocks(p->N)); break;
+      default: break;
+    }
+  };
+  if (which < 0 || which > 3) return fail(BA_ERR_INVALID, "ba_time_kernel: unknown kernel %d", which);
+  run();  // warm-up
+  HIP_OK(hipEventRecord(e0, s));
+  for (int k = 0; k < repeats; ++k) run();
+  HIP_OK(hipEventRecord(e1, s));
+  HIP_OK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  *seconds_per_launch = 1e-3 * ms / repeats;
+  return p->check_kernels();
+}
+
+// Structure of the Jacobian that problem.Evaluate returns (src/main.cpp:6664).  [Ceres 1.13
+// CompressedRowJacobianWriter]: one column range per parameter block in the order the blocks
+// were added (src/main.cpp:3793-3800), as wide as the block's tangent space; every
+// (residual block, variable parameter block) pair is written as a full block; a constant
+// parameter block keeps its columns and gets no entries.
+int ba_sparsity(ba_problem *p, int32_t *num_rows, int32_t *num_cols, int64_t *nnz, int32_t *rows, int32_t *cols) {
+  if (!p) return fail(BA_ERR_INVALID, "ba_sparsity: null problem");
+  const int N = p->N, S = p->S, P = p->P, C = p->C;
+  std::vector<int> iop_w(C), ap_w(C), iop_col(C), ap_col(C);
+  int col = 6 * S + 3 * P;
+  for (int c = 0; c < C; ++c) {
+    const unsigned m = p->iop_mask_h[c] & 7u;
+    iop_w[c] = m ? popcount32(m) : 3;
+    iop_col[c] = col;
+    col += iop_w[c];
+  }
+  for (int c = 0; c < C; ++c) {
+    const unsigned m = p->ap_mask_h[c];
+    ap_w[c] = m ? popcount32(m) : 16;
+    ap_col[c] = col;
+    col += ap_w[c];
+  }
+  int64_t z = 0;
+  int row = 0;
+  auto put = [&](int c0, int w) {
+    if (cols) for (int k = 0; k < w; ++k) cols[z + k] = c0 + k;
+    z += w;
+  };
+  auto end_row = [&]() {
+    ++row;
+    if (rows) rows[row] = (int32_t)z;
+  };
+  if (rows) rows[0] = 0;
+  for (int n = 0; n < N; ++n) {
+    const int i = p->obs_sta_h[n], j = p->obs_pt_h[n], c = p->sta_cam_h[i];
+    for (int r = 0; r < 2; ++r) {
+      put(6 * i, 6);
+      put(6 * S + 3 * j, 3);
+      if (p->iop_mask_h[c] & 7u) put(iop_col[c], iop_w[c]);
+      if (p->ap_mask_h[c]) put(ap_col[c], ap_w[c]);
+      end_row();
+    }
+  }
+  for (int j = 0; j < P; ++j)
+    for (int r = 0; r < 3; ++r) {
+      put(6 * S + 3 * j, 3);
+      end_row();
+    }
+  for (int c = 0; c < C; ++c)
+    for (int r = 0; r < 3; ++r) {
+      if (p->iop_mask_h[c] & 7u) put(iop_col[c], iop_w[c]);
+      end_row();
+    }
+  if (num_rows) *num_rows = row;
+  if (num_cols) *num_cols = col;
+  if (nnz) *nnz = z;
+  return 0;
+}
+
+// ---- multi-GPU ------------------------------------------------------------------------------
+static int sync_station_usage(ba_problem *p) {
+  // a station may be observed only from points of another shard
+  if (!p->ar || p->S == 0) return 0;
+  std::vector<double> u(p->S);
+  for (int i = 0; i < p->S; ++i) u[i] = p->sta_used_h[i];
+  HIP_OK(hipMemcpy(p->d_F, u.data(), u.size() * sizeof(double), hipMemcpyHostToDevice));
+  BA_TRY(p->allreduce(p->d_F, p->S, 1));
+  HIP_OK(hipStreamSynchronize(p->stream));
+  HIP_OK(hipMemcpy(u.data(), p->d_F, u.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int i = 0; i < p->S; ++i) p->sta_used_h[i] = u[i] > 0.0;
+  HIP_OK(hipMemcpy(p->d_sta_used, p->sta_used_h.data(), p->sta_used_h.size() * sizeof(int), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int ba_set_allreduce(ba_problem *p, ba_allreduce_fn fn, void *user) {
+  if (!p) return fail(BA_ERR_INVALID, "ba_set_allreduce: null problem");
+  p->ar = fn;
+  p->ar_user = user;
+  return sync_station_usage(p);
+}
+
+static int rccl_allreduce(void *user, double *buf, int64_t count, int32_t op, void *stream) {
+  ba_problem *p = static_cast<ba_problem *>(user);
+  const ncclResult_t r = ncclAllReduce(buf, buf, (size_t)count, ncclDouble, op == 1 ? ncclMax : ncclSum, p->comm,
+                                       static_cast<hipStream_t>(stream));
+  return r == ncclSuccess ? 0 : -1;
+}
+
+int ba_rccl_unique_id(void *unique_id_128) {
+  if (!unique_id_128) return fail(BA_ERR_INVALID, "ba_rccl_unique_id: null argument");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return fail(BA_ERR_COMM, "ncclGetUniqueId failed");
+  std::memcpy(unique_id_128, &id, sizeof id);
+  return 0;
+}
+
+int ba_use_rccl(ba_problem *p, int32_t n_ranks, int32_t rank, const void *unique_id_128) {
+  if (!p || !unique_id_128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(BA_ERR_INVALID, "ba_use_rccl: bad argument");
+  ncclUniqueId id;
+  std::memcpy(&id, unique_id_128, sizeof id);
+  const ncclResult_t r = ncclCommInitRank(&p->comm, n_ranks, id, rank);
+  if (r != ncclSuccess) return fail(BA_ERR_COMM, "ncclCommInitRank: %s", ncclGetErrorString(r));
+  return ba_set_allreduce(p, rccl_allreduce, p);
+}
+
+}  // extern "C"

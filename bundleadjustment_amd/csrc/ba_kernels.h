@@ -1,0 +1,126 @@
+// ba_kernels.h -- argument blocks and launch wrappers of the kernels in ba_kernels.hip and
+// ba_chol.hip.  Host-side code (ba_api.hip) only sees these.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct CamRec;
+
+namespace ba {
+
+enum { MODE_APPLY = 0, MODE_BACKSUB = 1 };
+enum { SMODE_GATHER = 0, SMODE_GATHER_CAM = 1, SMODE_SETUP = 2, SMODE_CAMNORM = 3 };
+enum { BA_CHUNK = 1024 };  // observations of one station handled by one workgroup
+
+struct LinArgs {
+  int P, ncmax;
+  const int *pt_start;
+  const double *obs, *sta, *xyz, *scale_pt, *pt_prior, *pt_isig;
+  const CamRec *cam;
+  double *rec, *Jp, *Jc, *Mo, *Vinv, *g_pt, *colnorm_pt, *diag_pt, *cost_partial;
+  unsigned *flags;
+  double huber_a, lm_min, lm_max, radius;
+  int reuse_diag;
+};
+
+struct PointArgs {
+  int P, S, ncmax;
+  const int *pt_start;
+  const double *obs, *sta, *Jp, *Jc, *Vinv, *vec;
+  const CamRec *cam;
+  double *rec;
+  // back substitution only
+  const double *g_pt, *xyz, *pt_prior, *pt_isig, *scale_pt;
+  double *y_pt, *partial;
+};
+
+struct StationArgs {
+  int n_chunks, ncmax, voff, out_stride;
+  const int *chunk_sta, *chunk_begin, *sta_list, *sta_cam;
+  const double *rec, *Jc, *Mo;
+  const CamRec *cam;
+  double *out;
+};
+
+struct StationFinishArgs {
+  int S, reuse_diag;
+  const int *sta_used;
+  const double *F;  // folded SMODE_SETUP sums, 39 per station
+  double lm_min, lm_max, radius;
+  double *colnorm_sta, *diag_sta, *d2_sta, *g_sta, *b_sta, *Minv;
+  unsigned *flags;
+};
+
+struct CamFinishArgs {
+  int C, reuse_diag, need_norms;
+  const CamRec *cam;
+  const double *colnorm_in;  // image-row column norms (null when not computed)
+  double lm_min, lm_max, radius;
+  double *jc2, *colnorm_cam, *diag_cam, *d2_cam, *camdiag, *g_cam, *b_cam;
+};
+
+struct CostArgs {
+  int64_t N;
+  const double *obs, *sta, *xyz;
+  const int *obs_pt;
+  const CamRec *cam;
+  double huber_a;
+  int apply_loss;
+  double *res_out;  // file order, may be null
+  double *partial;
+};
+
+struct CandArgs {
+  int S, P, C;
+  const int *sta_used;
+  const double *eop, *xyz, *y_cam, *y_pt, *scale_sta, *scale_pt;
+  const CamRec *cam;
+  double *eop_c, *xyz_c;
+  CamRec *cam_c;
+  double *partial;
+};
+
+struct CgArgs {
+  int n, S, ncam;
+  const double *b, *Minv, *Lcc, *Ssc, *Scc, *d2_sta;
+  double *x, *r, *z, *p, *q, *scal;
+};
+
+void launch_station_prep(hipStream_t s, int S, const double *eop, const double *scale_sta, const int *sta_cam, double *sta);
+int linearize_blocks(int P);
+void launch_linearize(hipStream_t s, const LinArgs &a);
+void launch_point_pass(hipStream_t s, const PointArgs &a, int mode, bool withcam);
+void launch_station_pass(hipStream_t s, const StationArgs &a, int smode);
+void launch_station_fold(hipStream_t s, int S, const int *sta_chunk0, const double *part, int stride, int ncols, double *out);
+void launch_camera_fold(hipStream_t s, int C, int n_chunks, const int *chunk_sta, const int *sta_cam, const CamRec *cam,
+                        const double *part, int stride, int coloff, double *out_cam);
+void launch_add_diag_entry(hipStream_t s, double *v, const double *diag, int64_t k);
+void launch_camera_prior_cost(hipStream_t s, int C, const CamRec *cam, double *out, int slot, int fixed_slot, double *res_out);
+void launch_station_finish(hipStream_t s, const StationFinishArgs &a);
+int cost_blocks(int64_t n);
+void launch_cost_obs(hipStream_t s, const CostArgs &a, int blocks);
+void launch_cost_prior(hipStream_t s, int P, const double *xyz, const double *prior, const double *isig, const int *pt_file,
+                       double *res_out, double *partial, int blocks);
+void launch_sum_partials(hipStream_t s, const double *partial, int n, double *out, int slot);
+void launch_max_partials(hipStream_t s, const double *partial, int n, double *out, int slot);
+void launch_absmax_ratio(hipStream_t s, int64_t n, const double *g, const double *scale, double *partial, int blocks);
+void launch_make_scale(hipStream_t s, int64_t n, const double *colnorm, double *scale);
+void launch_fill(hipStream_t s, int64_t n, double *v, double val);
+void launch_candidate(hipStream_t s, const CandArgs &a, int blocks);
+void launch_xnorm(hipStream_t s, const CandArgs &a, int blocks);
+void launch_camera_finish(hipStream_t s, const CamFinishArgs &a);
+void launch_camera_mcc(hipStream_t s, int C, const CamRec *cam, const double *y_cam, double *out, int slot);
+void launch_cg_init(hipStream_t s, const CgArgs &a);
+void launch_cg_step(hipStream_t s, const CgArgs &a);
+void launch_copy(hipStream_t s, int64_t n, const double *src, double *dst);
+void launch_unit(hipStream_t s, int64_t n, double *v, int64_t k);
+void launch_resjac_dense(hipStream_t s, const CostArgs &a, double *r_out, double *J_out);
+
+// ba_chol.hip: in-place lower Cholesky of a dense row-major n x n matrix (ld = n) and the
+// solve L L^T x = b (b overwritten).  info[0] != 0 after the factorisation when a pivot was
+// not positive.
+void launch_cholesky(hipStream_t s, double *A, int n, int *info);
+void launch_chol_solve(hipStream_t s, const double *L, int n, double *b);
+
+}  // namespace ba

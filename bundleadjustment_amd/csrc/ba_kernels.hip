@@ -1,0 +1,956 @@
+// ba_kernels.hip -- fp64 HIP kernels (gfx950) of the Levenberg-Marquardt inner loop.
+//
+// Two sweeps carry all per-observation work:
+//   point sweep   : one lane per object point, walking that point's observations, which are
+//                   contiguous because observations are stored sorted by point.  Everything
+//                   that is summed per point (the 3x3 block V, its gradient, W^T p) stays in
+//                   registers; no cross-lane traffic, no atomics.
+//   station sweep : one 256-thread workgroup per chunk of one station's observations (taken
+//                   through the station-sorted index list); per-lane partial sums are folded by
+//                   wave shuffles and an LDS stage, then written once per chunk.  A second tiny
+//                   kernel adds the chunks of a station in a fixed order, so results are
+//                   bitwise reproducible and no global atomics are used.
+// The reduced (camera-side) operator is never formed in the PCG path: S p is evaluated as
+//   Jc^T (I - Jp V^-1 Jp^T) Jc p   through one point sweep and one station sweep,
+// with the few camera (IOP/AP) columns kept as an explicit dense border.
+#include "ba_kernels.h"
+
+#include "ba_device.h"
+
+namespace ba {
+
+// ------------------------------------------------------------------------------------------
+// station records
+// ------------------------------------------------------------------------------------------
+// rotation of src/main.cpp:1325-1335 evaluated once per station instead of once per observation
+__global__ void k_station_prep(int S, const double *__restrict__ eop, const double *__restrict__ scale_sta,
+                               const int *__restrict__ sta_cam, double *__restrict__ sta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S) return;
+  const double *e = eop + 6 * (int64_t)i;
+  const double so = sin(e[0]), co = cos(e[0]), sp = sin(e[1]), cp = cos(e[1]), sk = sin(e[2]), ck = cos(e[2]);
+  double *o = sta + (int64_t)BA_STA_STRIDE * i;
+  o[0] = cp * ck;  o[1] = co * sk + so * sp * ck;  o[2] = so * sk - co * sp * ck;
+  o[3] = -cp * sk; o[4] = co * ck - so * sp * sk;  o[5] = so * ck + co * sp * sk;
+  o[6] = sp;       o[7] = -so * cp;                o[8] = co * cp;
+  o[9] = e[3]; o[10] = e[4]; o[11] = e[5];
+  o[12] = sk; o[13] = ck;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) o[14 + k] = scale_sta[6 * (int64_t)i + k];
+  o[20] = __hiloint2double(0, sta_cam[i]);
+  o[21] = o[22] = o[23] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// point sweep 1: residuals, Jacobians, point elimination
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_linearize(LinArgs a) {
+  __shared__ double lds[8];
+  const int jj = blockIdx.x * blockDim.x + threadIdx.x;
+  double cost = 0.0;
+  int bad = 0;
+  if (jj < a.P) {
+    const int e0 = a.pt_start[jj], e1 = a.pt_start[jj + 1];
+    const double X = a.xyz[3 * (int64_t)jj], Y = a.xyz[3 * (int64_t)jj + 1], Z = a.xyz[3 * (int64_t)jj + 2];
+    const double s0 = a.scale_pt[3 * (int64_t)jj], s1 = a.scale_pt[3 * (int64_t)jj + 1], s2 = a.scale_pt[3 * (int64_t)jj + 2];
+    double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    for (int e = e0; e < e1; ++e) {
+      const ObsIn o = load_obs(a.obs, e);
+      const double *st = a.sta + (int64_t)BA_STA_STRIDE * o.sta;
+      const int c = __double2loint(st[20]);
+      const CamIn cm = load_cam(a.cam, c);
+      double r0, r1, Js[12], Jp[6], dc0[BA_NCAMPAR], dc1[BA_NCAMPAR];
+      eval_obs<true>(o, st, X, Y, Z, cm, r0, r1, Js, Jp, dc0, dc1);
+      double sc;
+      cost += 0.5 * huber_rho(a.huber_a, r0 * r0 + r1 * r1, sc);
+      r0 *= sc;
+      r1 *= sc;
+      // rows of the scaled, corrected Jacobian
+      double2 *rec = reinterpret_cast<double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const double cs = sc * st[14 + k];
+        Js[k] *= cs;
+        Js[6 + k] *= cs;
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) rec[k] = make_double2(Js[2 * k], Js[2 * k + 1]);
+      rec[6] = make_double2(r0, r1);
+      Jp[0] *= sc * s0; Jp[1] *= sc * s1; Jp[2] *= sc * s2;
+      Jp[3] *= sc * s0; Jp[4] *= sc * s1; Jp[5] *= sc * s2;
+      double2 *jp = reinterpret_cast<double2 *>(a.Jp + 6 * (int64_t)e);
+      jp[0] = make_double2(Jp[0], Jp[1]);
+      jp[1] = make_double2(Jp[2], Jp[3]);
+      jp[2] = make_double2(Jp[4], Jp[5]);
+      V[0] += Jp[0] * Jp[0] + Jp[3] * Jp[3];
+      V[1] += Jp[0] * Jp[1] + Jp[3] * Jp[4];
+      V[2] += Jp[0] * Jp[2] + Jp[3] * Jp[5];
+      V[3] += Jp[1] * Jp[1] + Jp[4] * Jp[4];
+      V[4] += Jp[1] * Jp[2] + Jp[4] * Jp[5];
+      V[5] += Jp[2] * Jp[2] + Jp[5] * Jp[5];
+      g[0] += Jp[0] * r0 + Jp[3] * r1;
+      g[1] += Jp[1] * r0 + Jp[4] * r1;
+      g[2] += Jp[2] * r0 + Jp[5] * r1;
+      if (a.ncmax > 0) {
+        const CamRec &cr = a.cam[c];
+        double *jc = a.Jc + 2 * (int64_t)a.ncmax * e;
+        int pos = 0;
+#pragma unroll
+        for (int p = 0; p < BA_NCAMPAR; ++p) {
+          if (cr.mask & (1u << p)) {
+            const double cs = sc * cr.scale[pos];
+            jc[pos] = dc0[p] * cs;
+            jc[a.ncmax + pos] = dc1[p] * cs;
+            ++pos;
+          }
+        }
+      }
+    }
+    // prior rows (src/main.cpp:1064-1071, 4596-4599): r = (p - p0)/sigma, J = 1/sigma
+    const double *pr = a.pt_prior + 3 * (int64_t)jj, *is = a.pt_isig + 3 * (int64_t)jj;
+    const double rp0 = (X - pr[0]) * is[0], rp1 = (Y - pr[1]) * is[1], rp2 = (Z - pr[2]) * is[2];
+    cost += 0.5 * (rp0 * rp0 + rp1 * rp1 + rp2 * rp2);
+    const double j0 = is[0] * s0, j1 = is[1] * s1, j2 = is[2] * s2;
+    V[0] += j0 * j0; V[3] += j1 * j1; V[5] += j2 * j2;
+    g[0] += j0 * rp0; g[1] += j1 * rp1; g[2] += j2 * rp2;
+    double *cn = a.colnorm_pt + 3 * (int64_t)jj;
+    cn[0] = V[0]; cn[1] = V[3]; cn[2] = V[5];
+    // Levenberg-Marquardt diagonal [Ceres 1.13 LevenbergMarquardtStrategy::ComputeStep]
+    double *dg = a.diag_pt + 3 * (int64_t)jj;
+    double d0, d1, d2;
+    if (a.reuse_diag) {
+      d0 = dg[0]; d1 = dg[1]; d2 = dg[2];
+    } else {
+      d0 = fmin(fmax(V[0], a.lm_min), a.lm_max);
+      d1 = fmin(fmax(V[3], a.lm_min), a.lm_max);
+      d2 = fmin(fmax(V[5], a.lm_min), a.lm_max);
+      dg[0] = d0; dg[1] = d1; dg[2] = d2;
+    }
+    const double l0 = sqrt(d0 / a.radius), l1 = sqrt(d1 / a.radius), l2 = sqrt(d2 / a.radius);
+    V[0] += l0 * l0; V[3] += l1 * l1; V[5] += l2 * l2;
+    double Vi[6];
+    if (!inv_sym3(V, Vi)) bad = 1;
+    double *vo = a.Vinv + 6 * (int64_t)jj;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vo[k] = Vi[k];
+    double *go = a.g_pt + 3 * (int64_t)jj;
+    go[0] = g[0]; go[1] = g[1]; go[2] = g[2];
+    double u0, u1, u2;
+    sym3_mul(Vi, g[0], g[1], g[2], u0, u1, u2);
+    // second walk: M = I - Jp Vinv Jp^T and the reduced residual r - Jp Vinv g
+    for (int e = e0; e < e1; ++e) {
+      const double2 *jp = reinterpret_cast<const double2 *>(a.Jp + 6 * (int64_t)e);
+      const double2 q0 = jp[0], q1 = jp[1], q2 = jp[2];
+      const double p0 = q0.x, p1 = q0.y, p2 = q1.x, p3 = q1.y, p4 = q2.x, p5 = q2.y;
+      double t0, t1, t2, w0, w1, w2;
+      sym3_mul(Vi, p0, p1, p2, t0, t1, t2);
+      sym3_mul(Vi, p3, p4, p5, w0, w1, w2);
+      double *mo = a.Mo + 3 * (int64_t)e;
+      mo[0] = 1.0 - (p0 * t0 + p1 * t1 + p2 * t2);
+      mo[1] = -(p0 * w0 + p1 * w1 + p2 * w2);
+      mo[2] = 1.0 - (p3 * w0 + p4 * w1 + p5 * w2);
+      double2 *rec = reinterpret_cast<double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
+      const double2 r = rec[6];
+      rec[7] = make_double2(r.x - (p0 * u0 + p1 * u1 + p2 * u2), r.y - (p3 * u0 + p4 * u1 + p5 * u2));
+    }
+  }
+  const double t = block_sum(cost, lds);
+  if (threadIdx.x == 0) a.cost_partial[blockIdx.x] = t;
+  if (bad) atomicOr(a.flags, 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// point sweep 2: the point half of the reduced operator, or back substitution
+// ------------------------------------------------------------------------------------------
+//   MODE_APPLY   : a = Js p_i (+ Jc p_c);  t = sum Jp^T a;  u = Vinv t;  slot = a - Jp u
+//   MODE_BACKSUB : a = Js y_i + Jc y_c;    y_p = Vinv (g - sum Jp^T a);
+//                  partial sums of (J step).(r + J step / 2) for step = -y  [model cost change]
+template <int MODE, bool WITHCAM>
+__global__ void __launch_bounds__(256)
+k_point_pass(PointArgs a) {
+  __shared__ double lds[8];
+  const int jj = blockIdx.x * blockDim.x + threadIdx.x;
+  double acc = 0.0;
+  if (jj < a.P) {
+    const int e0 = a.pt_start[jj], e1 = a.pt_start[jj + 1];
+    double t0 = 0, t1 = 0, t2 = 0;
+    for (int e = e0; e < e1; ++e) {
+      double2 *rec = reinterpret_cast<double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
+      const int sta = __double2loint(a.obs[(int64_t)BA_OBS_STRIDE * e + 6]);
+      const double2 *pv = reinterpret_cast<const double2 *>(a.vec + 6 * (int64_t)sta);
+      const double2 v0 = pv[0], v1 = pv[1], v2 = pv[2];
+      const double2 j0 = rec[0], j1 = rec[1], j2 = rec[2], j3 = rec[3], j4 = rec[4], j5 = rec[5];
+      double a0 = j0.x * v0.x + j0.y * v0.y + j1.x * v1.x + j1.y * v1.y + j2.x * v2.x + j2.y * v2.y;
+      double a1 = j3.x * v0.x + j3.y * v0.y + j4.x * v1.x + j4.y * v1.y + j5.x * v2.x + j5.y * v2.y;
+      if (WITHCAM) {
+        const int c = __double2loint(a.sta[(int64_t)BA_STA_STRIDE * sta + 20]);
+        const int nc = a.cam[c].nc, off = a.cam[c].off;
+        const double *jc = a.Jc + 2 * (int64_t)a.ncmax * e;
+        const double *vc = a.vec + 6 * (int64_t)a.S + off;
+        for (int k = 0; k < nc; ++k) {
+          a0 += jc[k] * vc[k];
+          a1 += jc[a.ncmax + k] * vc[k];
+        }
+      }
+      const double2 *jp = reinterpret_cast<const double2 *>(a.Jp + 6 * (int64_t)e);
+      const double2 q0 = jp[0], q1 = jp[1], q2 = jp[2];
+      t0 += q0.x * a0 + q1.y * a1;
+      t1 += q0.y * a0 + q2.x * a1;
+      t2 += q1.x * a0 + q2.y * a1;
+      rec[7] = make_double2(a0, a1);
+    }
+    const double *vi = a.Vinv + 6 * (int64_t)jj;
+    const double Vi[6] = {vi[0], vi[1], vi[2], vi[3], vi[4], vi[5]};
+    double u0, u1, u2;
+    if (MODE == MODE_APPLY) {
+      sym3_mul(Vi, t0, t1, t2, u0, u1, u2);
+      for (int e = e0; e < e1; ++e) {
+        double2 *rec = reinterpret_cast<double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
+        const double2 *jp = reinterpret_cast<const double2 *>(a.Jp + 6 * (int64_t)e);
+        const double2 q0 = jp[0], q1 = jp[1], q2 = jp[2];
+        const double2 s = rec[7];
+        rec[7] = make_double2(s.x - (q0.x * u0 + q0.y * u1 + q1.x * u2), s.y - (q1.y * u0 + q2.x * u1 + q2.y * u2));
+      }
+    } else {
+      const double *g = a.g_pt + 3 * (int64_t)jj;
+      sym3_mul(Vi, g[0] - t0, g[1] - t1, g[2] - t2, u0, u1, u2);
+      double *yo = a.y_pt + 3 * (int64_t)jj;
+      yo[0] = u0; yo[1] = u1; yo[2] = u2;
+      for (int e = e0; e < e1; ++e) {
+        const double2 *rec = reinterpret_cast<const double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
+        const double2 *jp = reinterpret_cast<const double2 *>(a.Jp + 6 * (int64_t)e);
+        const double2 q0 = jp[0], q1 = jp[1], q2 = jp[2];
+        const double2 s = rec[7], r = rec[6];
+        const double m0 = -(s.x + q0.x * u0 + q0.y * u1 + q1.x * u2);
+        const double m1 = -(s.y + q1.y * u0 + q2.x * u1 + q2.y * u2);
+        acc += m0 * (r.x + 0.5 * m0) + m1 * (r.y + 0.5 * m1);
+      }
+      // prior rows of this point
+      const double *pr = a.pt_prior + 3 * (int64_t)jj, *is = a.pt_isig + 3 * (int64_t)jj;
+      const double *x = a.xyz + 3 * (int64_t)jj, *sp = a.scale_pt + 3 * (int64_t)jj;
+      const double m0 = -is[0] * sp[0] * u0, m1 = -is[1] * sp[1] * u1, m2 = -is[2] * sp[2] * u2;
+      acc += m0 * ((x[0] - pr[0]) * is[0] + 0.5 * m0) + m1 * ((x[1] - pr[1]) * is[1] + 0.5 * m1) +
+             m2 * ((x[2] - pr[2]) * is[2] + 0.5 * m2);
+    }
+  }
+  if (MODE == MODE_BACKSUB) {
+    const double t = block_sum(acc, lds);
+    if (threadIdx.x == 0) a.partial[blockIdx.x] = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// station sweep
+// ------------------------------------------------------------------------------------------
+// One workgroup per chunk (<= BA_CHUNK observations of one station).
+//   SMODE_GATHER     out[chunk][0..5]            = sum Js^T v          (v = rec[voff..voff+1])
+//   SMODE_GATHER_CAM out[chunk][0..5], [6..6+nc) = sum Js^T v, sum Jc^T v
+//   SMODE_SETUP      out[chunk][0..20]  = upper triangle of sum Js^T M Js   (preconditioner block)
+//                    out[chunk][21..26] = diag of sum Js^T Js                (column norms)
+//                    out[chunk][27..32] = sum Js^T r      (gradient)
+//                    out[chunk][33..38] = sum Js^T rhat   (reduced right-hand side)
+//   SMODE_CAMNORM    out[chunk][0..nc)  = sum of squares of the Jc columns
+template <int SMODE>
+__global__ void __launch_bounds__(256)
+k_station_pass(StationArgs a) {
+  constexpr int NACC = SMODE == SMODE_GATHER ? 6 : SMODE == SMODE_GATHER_CAM ? 6 + BA_NCAMPAR
+                       : SMODE == SMODE_SETUP ? 39 : BA_NCAMPAR;
+  __shared__ double lds[4 * NACC];
+  const int ch = blockIdx.x;
+  const int sta = a.chunk_sta[ch];
+  const int b0 = a.chunk_begin[ch], b1 = a.chunk_begin[ch + 1];
+  double acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+  int nc = 0;
+  if (SMODE == SMODE_GATHER_CAM || SMODE == SMODE_CAMNORM) nc = a.cam[a.sta_cam[sta]].nc;
+  for (int q = b0 + threadIdx.x; q < b1; q += blockDim.x) {
+    const int e = a.sta_list[q];
+    const double2 *rec = reinterpret_cast<const double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
+    if (SMODE == SMODE_GATHER || SMODE == SMODE_GATHER_CAM) {
+      const double2 v = rec[a.voff];
+      const double2 j0 = rec[0], j1 = rec[1], j2 = rec[2], j3 = rec[3], j4 = rec[4], j5 = rec[5];
+      acc[0] += j0.x * v.x + j3.x * v.y;
+      acc[1] += j0.y * v.x + j3.y * v.y;
+      acc[2] += j1.x * v.x + j4.x * v.y;
+      acc[3] += j1.y * v.x + j4.y * v.y;
+      acc[4] += j2.x * v.x + j5.x * v.y;
+      acc[5] += j2.y * v.x + j5.y * v.y;
+      if (SMODE == SMODE_GATHER_CAM) {
+        const double *jc = a.Jc + 2 * (int64_t)a.ncmax * e;
+#pragma unroll
+        for (int k = 0; k < BA_NCAMPAR; ++k)
+          if (k < nc) acc[6 + k] += jc[k] * v.x + jc[a.ncmax + k] * v.y;
+      }
+    } else if (SMODE == SMODE_SETUP) {
+      double r0[6], r1[6];
+      {
+        const double2 j0 = rec[0], j1 = rec[1], j2 = rec[2], j3 = rec[3], j4 = rec[4], j5 = rec[5];
+        r0[0] = j0.x; r0[1] = j0.y; r0[2] = j1.x; r0[3] = j1.y; r0[4] = j2.x; r0[5] = j2.y;
+        r1[0] = j3.x; r1[1] = j3.y; r1[2] = j4.x; r1[3] = j4.y; r1[4] = j5.x; r1[5] = j5.y;
+      }
+      const double2 rr = rec[6], rh = rec[7];
+      const double *mo = a.Mo + 3 * (int64_t)e;
+      const double m00 = mo[0], m01 = mo[1], m11 = mo[2];
+      int idx = 0;
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        const double w0 = m00 * r0[p] + m01 * r1[p], w1 = m01 * r0[p] + m11 * r1[p];
+#pragma unroll
+        for (int q2 = p; q2 < 6; ++q2) acc[idx++] += w0 * r0[q2] + w1 * r1[q2];
+      }
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        acc[21 + p] += r0[p] * r0[p] + r1[p] * r1[p];
+        acc[27 + p] += r0[p] * rr.x + r1[p] * rr.y;
+        acc[33 + p] += r0[p] * rh.x + r1[p] * rh.y;
+      }
+    } else {
+      const double *jc = a.Jc + 2 * (int64_t)a.ncmax * e;
+#pragma unroll
+      for (int k = 0; k < BA_NCAMPAR; ++k)
+        if (k < nc) acc[k] += jc[k] * jc[k] + jc[a.ncmax + k] * jc[a.ncmax + k];
+    }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) lds[w * NACC + k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    const int k = threadIdx.x;
+    a.out[(int64_t)a.out_stride * ch + k] = lds[k] + lds[NACC + k] + lds[2 * NACC + k] + lds[3 * NACC + k];
+  }
+}
+
+// Folds the chunks of each station in a fixed order: out[i][0..ncols) = sum_chunks part[ch][0..ncols)
+__global__ void k_station_fold(int S, const int *__restrict__ sta_chunk0, const double *__restrict__ part, int stride,
+                               int ncols, double *__restrict__ out) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= (int64_t)ncols * S) return;
+  const int i = (int)(t / ncols), k = (int)(t - (int64_t)ncols * i);
+  double s = 0.0;
+  for (int ch = sta_chunk0[i]; ch < sta_chunk0[i + 1]; ++ch) s += part[(int64_t)stride * ch + k];
+  out[t] = s;
+}
+
+// Camera rows after SMODE_GATHER_CAM / SMODE_CAMNORM: one workgroup per camera sums, in chunk
+// order, the partials of the chunks whose station uses that camera.
+__global__ void __launch_bounds__(256)
+k_camera_fold(int n_chunks, const int *__restrict__ chunk_sta, const int *__restrict__ sta_cam,
+              const CamRec *__restrict__ cam, const double *__restrict__ part, int stride, int coloff,
+              double *__restrict__ out_cam) {
+  __shared__ double lds[8];
+  const int c = blockIdx.x;
+  const int nc = cam[c].nc, off = cam[c].off;
+  for (int k = 0; k < nc; ++k) {
+    double s = 0.0;
+    for (int ch = threadIdx.x; ch < n_chunks; ch += blockDim.x)
+      if (sta_cam[chunk_sta[ch]] == c) s += part[(int64_t)stride * ch + coloff + k];
+    const double t = block_sum(s, lds);
+    if (threadIdx.x == 0) out_cam[off + k] = t;
+  }
+}
+
+// v[k] += diag[k]: the diagonal term of column k of the reduced matrix after a unit-vector probe
+__global__ void k_add_diag_entry(double *__restrict__ v, const double *__restrict__ diag, int64_t k) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) v[k] += diag[k];
+}
+
+// After SMODE_SETUP and the fold: per station, add the LM diagonal, invert the 6x6
+// preconditioner block, and emit gradient / rhs / column norms.
+__global__ void k_station_finish(StationFinishArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.S) return;
+  double acc[39];
+#pragma unroll
+  for (int k = 0; k < 39; ++k) acc[k] = a.F[39 * (int64_t)i + k];
+  const bool used = a.sta_used[i] != 0;
+  double d2[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    a.colnorm_sta[6 * (int64_t)i + k] = acc[21 + k];
+    double dg;
+    if (a.reuse_diag) {
+      dg = a.diag_sta[6 * (int64_t)i + k];
+    } else {
+      dg = fmin(fmax(acc[21 + k], a.lm_min), a.lm_max);
+      a.diag_sta[6 * (int64_t)i + k] = dg;
+    }
+    const double l = sqrt(dg / a.radius);
+    d2[k] = l * l;
+    a.d2_sta[6 * (int64_t)i + k] = d2[k];
+    a.g_sta[6 * (int64_t)i + k] = acc[27 + k];
+    a.b_sta[6 * (int64_t)i + k] = used ? acc[33 + k] : 0.0;
+  }
+  // symmetric 6x6 from its upper triangle, Cholesky, inverse
+  double A[6][6];
+  {
+    int idx = 0;
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+      for (int q = p; q < 6; ++q) {
+        A[p][q] = acc[idx];
+        A[q][p] = acc[idx];
+        ++idx;
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) A[k][k] += d2[k];
+  double L[6][6];
+  bool ok = used;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double d = A[j][j];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      if (k < j) d -= L[j][k] * L[j][k];
+    if (!(d > 0.0)) ok = false;
+    const double ld = sqrt(d);
+    L[j][j] = ld;
+    const double il = 1.0 / ld;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+      if (r > j) {
+        double s = A[r][j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          if (k < j) s -= L[r][k] * L[j][k];
+        L[r][j] = s * il;
+      }
+  }
+  double *mi = a.Minv + 36 * (int64_t)i;
+  if (!ok) {
+#pragma unroll
+    for (int k = 0; k < 36; ++k) mi[k] = 0.0;
+    if (used) atomicOr(a.flags, 2);
+    return;
+  }
+  // inverse column by column: solve L L^T x = e_c
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    double y[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      double s = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (k < r) s -= L[r][k] * y[k];
+      y[r] = s / L[r][r];
+    }
+#pragma unroll
+    for (int r = 5; r >= 0; --r) {
+      double s = y[r];
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (k > r) s -= L[k][r] * y[k];
+      y[r] = s / L[r][r];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) mi[6 * r + c] = y[r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// cost at a candidate point (residuals only), src/main.cpp:1322-1388 + Huber
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_cost_obs(CostArgs a) {
+  __shared__ double lds[8];
+  double cost = 0.0;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < a.N; e += (int64_t)gridDim.x * blockDim.x) {
+    const ObsIn o = load_obs(a.obs, e);
+    const double *st = a.sta + (int64_t)BA_STA_STRIDE * o.sta;
+    const CamIn cm = load_cam(a.cam, __double2loint(st[20]));
+    const int jj = a.obs_pt[e];
+    const double *x = a.xyz + 3 * (int64_t)jj;
+    double r0, r1;
+    eval_obs<false>(o, st, x[0], x[1], x[2], cm, r0, r1, nullptr, nullptr, nullptr, nullptr);
+    double sc;
+    const double rho = huber_rho(a.huber_a, r0 * r0 + r1 * r1, sc);
+    cost += 0.5 * rho;
+    if (a.res_out) {
+      const double f = a.apply_loss ? sc : 1.0;
+      a.res_out[2 * (int64_t)o.row] = f * r0;
+      a.res_out[2 * (int64_t)o.row + 1] = f * r1;
+    }
+  }
+  const double t = block_sum(cost, lds);
+  if (threadIdx.x == 0) a.partial[blockIdx.x] = t;
+}
+
+__global__ void __launch_bounds__(256)
+k_cost_prior(int P, const double *__restrict__ xyz, const double *__restrict__ prior, const double *__restrict__ isig,
+             const int *__restrict__ pt_file, double *__restrict__ res_out /* file order, may be null */,
+             double *__restrict__ partial) {
+  __shared__ double lds[8];
+  double cost = 0.0;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < 3 * (int64_t)P; t += (int64_t)gridDim.x * blockDim.x) {
+    const double r = (xyz[t] - prior[t]) * isig[t];
+    cost += 0.5 * r * r;
+    if (res_out) {
+      const int64_t jj = t / 3;
+      res_out[3 * (int64_t)pt_file[jj] + (t - 3 * jj)] = r;
+    }
+  }
+  const double s = block_sum(cost, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// out[slot] = sum partial[0..n)
+__global__ void __launch_bounds__(1024)
+k_sum_partials(const double *__restrict__ partial, int n, double *__restrict__ out, int slot) {
+  __shared__ double lds[16];
+  double s = 0.0;
+  for (int k = threadIdx.x; k < n; k += blockDim.x) s += partial[k];
+  const double t = block_sum(s, lds);
+  if (threadIdx.x == 0) out[slot] = t;
+}
+
+// IOP prior blocks (src/main.cpp:4626-4629): out[slot] += cost of the variable blocks,
+// out[fixed_slot] = cost of the constant ones; residuals (file order) optionally written.
+__global__ void k_camera_prior_cost(int C, const CamRec *__restrict__ cam, double *__restrict__ out, int slot,
+                                    int fixed_slot, double *__restrict__ res_out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  double v = 0.0, fx = 0.0;
+  for (int c = 0; c < C; ++c) {
+    double q = 0.0;
+    for (int k = 0; k < 3; ++k) {
+      const double r = (cam[c].iop[k] - cam[c].prior[k]) * cam[c].isig[k];
+      q += 0.5 * r * r;
+      if (res_out) res_out[3 * c + k] = r;
+    }
+    if (cam[c].in_program & 1) v += q; else fx += q;
+  }
+  out[slot] += v;
+  if (fixed_slot >= 0) out[fixed_slot] = fx;
+}
+
+__global__ void __launch_bounds__(1024)
+k_max_partials(const double *__restrict__ partial, int n, double *__restrict__ out, int slot) {
+  __shared__ double lds[16];
+  double s = 0.0;
+  for (int k = threadIdx.x; k < n; k += blockDim.x) s = fmax(s, partial[k]);
+  const double t = block_max(s, lds);
+  if (threadIdx.x == 0) out[slot] = t;
+}
+
+// max |g_scaled / scale| over a vector
+__global__ void __launch_bounds__(256)
+k_absmax_ratio(int64_t n, const double *__restrict__ g, const double *__restrict__ scale, double *__restrict__ partial) {
+  __shared__ double lds[8];
+  double m = 0.0;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+    m = fmax(m, fabs(g[t] / scale[t]));
+  const double r = block_max(m, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// scale = 1 / (1 + sqrt(colnorm))   [Ceres 1.13 TrustRegionMinimizer::EvaluateGradientAndJacobian]
+__global__ void k_make_scale(int64_t n, const double *__restrict__ colnorm, double *__restrict__ scale) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t < n) scale[t] = 1.0 / (1.0 + sqrt(colnorm[t]));
+}
+
+__global__ void k_fill(int64_t n, double *__restrict__ v, double val) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t < n) v[t] = val;
+}
+
+// ------------------------------------------------------------------------------------------
+// candidate point  x + delta,  delta = -y * scale  on the free coordinates
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_candidate(CandArgs a) {
+  __shared__ double lds[8];
+  // sums over the points (local to a shard) and over stations + cameras (replicated) are kept apart
+  double step2 = 0.0, norm2 = 0.0, pstep2 = 0.0, pnorm2 = 0.0;
+  const int64_t n_s = 6 * (int64_t)a.S, n_p = 3 * (int64_t)a.P;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n_s + n_p; t += (int64_t)gridDim.x * blockDim.x) {
+    if (t < n_s) {
+      const int i = (int)(t / 6);
+      const bool used = a.sta_used[i] != 0;
+      const double d = used ? -a.y_cam[t] * a.scale_sta[t] : 0.0;
+      const double v = a.eop[t] + d;
+      a.eop_c[t] = v;
+      if (used) { step2 += d * d; norm2 += v * v; }
+    } else {
+      const int64_t u = t - n_s;
+      const double d = -a.y_pt[u] * a.scale_pt[u];
+      const double v = a.xyz[u] + d;
+      a.xyz_c[u] = v;
+      pstep2 += d * d;
+      pnorm2 += v * v;
+    }
+  }
+  // cameras: a handful of values, done by one thread
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int c = 0; c < a.C; ++c) {
+      CamRec r = a.cam[c];
+      int pos = 0;
+      for (int p = 0; p < BA_NCAMPAR; ++p) {
+        if (r.mask & (1u << p)) {
+          const double d = -a.y_cam[n_s + r.off + pos] * r.scale[pos];
+          if (p < 3) r.iop[p] += d; else r.ap[p - 3] += d;
+          step2 += d * d;
+          ++pos;
+        }
+      }
+      if (r.in_program & 1) for (int k = 0; k < 3; ++k) norm2 += r.iop[k] * r.iop[k];
+      if (r.in_program & 2) for (int k = 0; k < 16; ++k) norm2 += r.ap[k] * r.ap[k];
+      a.cam_c[c] = r;
+    }
+  }
+  const double s = block_sum(step2, lds);
+  const double n = block_sum(norm2, lds);
+  const double ps = block_sum(pstep2, lds);
+  const double pn = block_sum(pnorm2, lds);
+  if (threadIdx.x == 0) {
+    a.partial[blockIdx.x] = s;
+    a.partial[gridDim.x + blockIdx.x] = n;
+    a.partial[2 * gridDim.x + blockIdx.x] = ps;
+    a.partial[3 * gridDim.x + blockIdx.x] = pn;
+  }
+}
+
+// |x|^2 over the ambient coordinates of the blocks in the reduced program
+__global__ void __launch_bounds__(256)
+k_xnorm(CandArgs a) {
+  __shared__ double lds[8];
+  double norm2 = 0.0, pnorm2 = 0.0;
+  const int64_t n_s = 6 * (int64_t)a.S, n_p = 3 * (int64_t)a.P;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n_s + n_p; t += (int64_t)gridDim.x * blockDim.x) {
+    if (t < n_s) {
+      const int i = (int)(t / 6);
+      if (a.sta_used[i]) norm2 += a.eop[t] * a.eop[t];
+    } else {
+      pnorm2 += a.xyz[t - n_s] * a.xyz[t - n_s];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int c = 0; c < a.C; ++c) {
+      const CamRec &r = a.cam[c];
+      if (r.in_program & 1) for (int k = 0; k < 3; ++k) norm2 += r.iop[k] * r.iop[k];
+      if (r.in_program & 2) for (int k = 0; k < 16; ++k) norm2 += r.ap[k] * r.ap[k];
+    }
+  }
+  const double n = block_sum(norm2, lds);
+  const double pn = block_sum(pnorm2, lds);
+  if (threadIdx.x == 0) {
+    a.partial[blockIdx.x] = n;
+    a.partial[gridDim.x + blockIdx.x] = pn;
+  }
+}
+
+// camera prior rows: column norms, gradient, rhs, LM diagonal.  One thread; a few values.
+__global__ void k_camera_finish(CamFinishArgs a) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  for (int c = 0; c < a.C; ++c) {
+    const CamRec &r = a.cam[c];
+    int pos = 0;
+    for (int p = 0; p < BA_NCAMPAR; ++p) {
+      if (!(r.mask & (1u << p))) continue;
+      const int col = r.off + pos;
+      double jc = 0.0, rc = 0.0;
+      if (p < 3) {
+        jc = r.isig[p] * r.scale[pos];
+        rc = (r.iop[p] - r.prior[p]) * r.isig[p];
+      }
+      a.jc2[col] = jc * jc;
+      const double cn = (a.colnorm_in ? a.colnorm_in[col] : 0.0) + jc * jc;
+      a.colnorm_cam[col] = cn;
+      double dg;
+      if (a.reuse_diag) {
+        dg = a.diag_cam[col];
+      } else {
+        dg = a.need_norms ? fmin(fmax(cn, a.lm_min), a.lm_max) : a.lm_min;
+        a.diag_cam[col] = dg;
+      }
+      const double l = sqrt(dg / a.radius);
+      a.d2_cam[col] = l * l;
+      a.camdiag[col] = jc * jc + l * l;
+      a.g_cam[col] += jc * rc;  // g_cam / b_cam hold the image-row sums on entry
+      a.b_cam[col] += jc * rc;
+      ++pos;
+    }
+  }
+}
+
+// model cost change contribution of the camera prior rows, added to out[slot]
+__global__ void k_camera_mcc(int C, const CamRec *__restrict__ cam, const double *__restrict__ y_cam,
+                             double *__restrict__ out, int slot) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  double acc = 0.0;
+  for (int c = 0; c < C; ++c) {
+    const CamRec &r = cam[c];
+    int pos = 0;
+    for (int p = 0; p < BA_NCAMPAR; ++p) {
+      if (!(r.mask & (1u << p))) continue;
+      if (p < 3) {
+        const double m = -r.isig[p] * r.scale[pos] * y_cam[r.off + pos];
+        acc += m * ((r.iop[p] - r.prior[p]) * r.isig[p] + 0.5 * m);
+      }
+      ++pos;
+    }
+  }
+  out[slot] += acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// PCG vector phase: one 1024-thread workgroup does everything between two operator
+// applications (the vectors have 6S + ncam entries: a few hundred KB at most).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void precond(const CgArgs &a, const double *__restrict__ r, double *__restrict__ z) {
+  for (int i = threadIdx.x; i < a.S; i += blockDim.x) {
+    const double *m = a.Minv + 36 * (int64_t)i;
+    const double *ri = r + 6 * (int64_t)i;
+    const double r0 = ri[0], r1 = ri[1], r2 = ri[2], r3 = ri[3], r4 = ri[4], r5 = ri[5];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      z[6 * (int64_t)i + k] = m[6 * k] * r0 + m[6 * k + 1] * r1 + m[6 * k + 2] * r2 + m[6 * k + 3] * r3 +
+                              m[6 * k + 4] * r4 + m[6 * k + 5] * r5;
+  }
+  if (a.ncam > 0 && threadIdx.x == 0) {
+    // dense Cholesky factor L (row-major, lower) of the camera block
+    const int n = a.ncam;
+    const double *L = a.Lcc;
+    double *zc = z + 6 * (int64_t)a.S;
+    const double *rc = r + 6 * (int64_t)a.S;
+    for (int i = 0; i < n; ++i) {
+      double s = rc[i];
+      for (int k = 0; k < i; ++k) s -= L[i * n + k] * zc[k];
+      zc[i] = s / L[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double s = zc[i];
+      for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * zc[k];
+      zc[i] = s / L[i * n + i];
+    }
+  }
+}
+
+__device__ __forceinline__ double block_dot(const double *__restrict__ x, const double *__restrict__ y, int n, double *lds,
+                                            double *bcast) {
+  double s = 0.0;
+  for (int k = threadIdx.x; k < n; k += blockDim.x) s += x[k] * y[k];
+  const double t = block_sum(s, lds);
+  if (threadIdx.x == 0) *bcast = t;
+  __syncthreads();
+  const double v = *bcast;
+  __syncthreads();
+  return v;
+}
+
+// x = 0, r = b, z = M^-1 r, p = z, rz = r.z
+__global__ void __launch_bounds__(1024)
+k_cg_init(CgArgs a) {
+  __shared__ double lds[16];
+  __shared__ double bc;
+  const int n = a.n;
+  for (int k = threadIdx.x; k < n; k += blockDim.x) {
+    a.x[k] = 0.0;
+    a.r[k] = a.b[k];
+  }
+  __syncthreads();
+  precond(a, a.r, a.z);
+  __syncthreads();
+  const double rz = block_dot(a.r, a.z, n, lds, &bc);
+  for (int k = threadIdx.x; k < n; k += blockDim.x) a.p[k] = a.z[k];
+  if (threadIdx.x == 0) {
+    a.scal[0] = rz;   // current r.z
+    a.scal[1] = rz;   // initial r.z
+    a.scal[2] = 0.0;  // iterations done
+  }
+}
+
+// q holds the implicit station part of S p; add the explicit camera border, then one CG update.
+__global__ void __launch_bounds__(1024)
+k_cg_step(CgArgs a) {
+  __shared__ double lds[16];
+  __shared__ double bc;
+  const int n = a.n, ns = 6 * a.S, nc = a.ncam;
+  // LM diagonal of the station columns (the implicit operator carries only Js^T M Js)
+  for (int t = threadIdx.x; t < ns; t += blockDim.x) a.q[t] += a.d2_sta[t] * a.p[t];
+  __syncthreads();
+  // border:  q_s += Ssc p_c ;  q_c = Ssc^T p_s + Scc p_c      (Ssc column-major [ns x nc])
+  if (nc > 0) {
+    const double *pc = a.p + ns;
+    for (int k = 0; k < nc; ++k) {
+      const double *col = a.Ssc + (int64_t)k * ns;
+      double s = 0.0;
+      for (int t = threadIdx.x; t < ns; t += blockDim.x) s += col[t] * a.p[t];
+      const double d = block_sum(s, lds);
+      if (threadIdx.x == 0) {
+        double v = d;
+        for (int m = 0; m < nc; ++m) v += a.Scc[k * nc + m] * pc[m];
+        a.q[ns + k] = v;
+      }
+    }
+    for (int t = threadIdx.x; t < ns; t += blockDim.x) {
+      double s = a.q[t];
+      for (int k = 0; k < nc; ++k) s += a.Ssc[(int64_t)k * ns + t] * pc[k];
+      a.q[t] = s;
+    }
+    __syncthreads();
+  }
+  const double rz = a.scal[0];
+  const double pq = block_dot(a.p, a.q, n, lds, &bc);
+  const double alpha = rz / pq;
+  for (int k = threadIdx.x; k < n; k += blockDim.x) {
+    a.x[k] += alpha * a.p[k];
+    a.r[k] -= alpha * a.q[k];
+  }
+  __syncthreads();
+  precond(a, a.r, a.z);
+  __syncthreads();
+  const double rzn = block_dot(a.r, a.z, n, lds, &bc);
+  const double beta = rzn / rz;
+  for (int k = threadIdx.x; k < n; k += blockDim.x) a.p[k] = a.z[k] + beta * a.p[k];
+  if (threadIdx.x == 0) {
+    a.scal[0] = rzn;
+    a.scal[2] += 1.0;
+    a.scal[3] = pq;
+  }
+}
+
+// copy helpers ------------------------------------------------------------------------------
+__global__ void k_copy(int64_t n, const double *__restrict__ src, double *__restrict__ dst) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t < n) dst[t] = src[t];
+}
+__global__ void k_unit(int64_t n, double *__restrict__ v, int64_t k) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t < n) v[t] = (t == k) ? 1.0 : 0.0;
+}
+
+// Per-observation residuals and dense 2x28 Jacobians in file order (no loss, no scaling):
+// the counterpart of AutoDiffCostFunction<collinearity,2,6,3,3,16>::Evaluate, src/main.cpp:3845-3847.
+__global__ void __launch_bounds__(256)
+k_resjac_dense(CostArgs a, double *__restrict__ r_out, double *__restrict__ J_out) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= a.N) return;
+  const ObsIn o = load_obs(a.obs, e);
+  const double *st = a.sta + (int64_t)BA_STA_STRIDE * o.sta;
+  const CamIn cm = load_cam(a.cam, __double2loint(st[20]));
+  const double *x = a.xyz + 3 * (int64_t)a.obs_pt[e];
+  double r0, r1, Js[12], Jp[6], dc0[BA_NCAMPAR], dc1[BA_NCAMPAR];
+  eval_obs<true>(o, st, x[0], x[1], x[2], cm, r0, r1, Js, Jp, dc0, dc1);
+  if (r_out) {
+    r_out[2 * (int64_t)o.row] = r0;
+    r_out[2 * (int64_t)o.row + 1] = r1;
+  }
+  if (J_out) {
+    double *J = J_out + 56 * (int64_t)o.row;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { J[k] = Js[k]; J[28 + k] = Js[6 + k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { J[6 + k] = Jp[k]; J[28 + 6 + k] = Jp[3 + k]; }
+#pragma unroll
+    for (int k = 0; k < BA_NCAMPAR; ++k) { J[9 + k] = dc0[k]; J[28 + 9 + k] = dc1[k]; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------
+static inline int nblk(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
+
+void launch_station_prep(hipStream_t s, int S, const double *eop, const double *scale_sta, const int *sta_cam, double *sta) {
+  if (S > 0) hipLaunchKernelGGL(k_station_prep, dim3(nblk(S, 128)), dim3(128), 0, s, S, eop, scale_sta, sta_cam, sta);
+}
+int linearize_blocks(int P) { return nblk(P, 256); }
+void launch_linearize(hipStream_t s, const LinArgs &a) {
+  if (a.P > 0) hipLaunchKernelGGL(k_linearize, dim3(nblk(a.P, 256)), dim3(256), 0, s, a);
+}
+void launch_point_pass(hipStream_t s, const PointArgs &a, int mode, bool withcam) {
+  if (a.P <= 0) return;
+  const dim3 g(nblk(a.P, 256)), b(256);
+  if (mode == MODE_APPLY) {
+    if (withcam) hipLaunchKernelGGL((k_point_pass<MODE_APPLY, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_point_pass<MODE_APPLY, false>), g, b, 0, s, a);
+  } else {
+    if (withcam) hipLaunchKernelGGL((k_point_pass<MODE_BACKSUB, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_point_pass<MODE_BACKSUB, false>), g, b, 0, s, a);
+  }
+}
+void launch_station_pass(hipStream_t s, const StationArgs &a, int smode) {
+  if (a.n_chunks <= 0) return;
+  const dim3 g(a.n_chunks), b(256);
+  switch (smode) {
+    case SMODE_GATHER: hipLaunchKernelGGL((k_station_pass<SMODE_GATHER>), g, b, 0, s, a); break;
+    case SMODE_GATHER_CAM: hipLaunchKernelGGL((k_station_pass<SMODE_GATHER_CAM>), g, b, 0, s, a); break;
+    case SMODE_SETUP: hipLaunchKernelGGL((k_station_pass<SMODE_SETUP>), g, b, 0, s, a); break;
+    default: hipLaunchKernelGGL((k_station_pass<SMODE_CAMNORM>), g, b, 0, s, a); break;
+  }
+}
+void launch_station_fold(hipStream_t s, int S, const int *sta_chunk0, const double *part, int stride, int ncols, double *out) {
+  if (S > 0) hipLaunchKernelGGL(k_station_fold, dim3(nblk((int64_t)ncols * S, 256)), dim3(256), 0, s, S, sta_chunk0, part, stride, ncols, out);
+}
+void launch_camera_fold(hipStream_t s, int C, int n_chunks, const int *chunk_sta, const int *sta_cam, const CamRec *cam,
+                        const double *part, int stride, int coloff, double *out_cam) {
+  if (C > 0) hipLaunchKernelGGL(k_camera_fold, dim3(C), dim3(256), 0, s, n_chunks, chunk_sta, sta_cam, cam, part, stride, coloff, out_cam);
+}
+void launch_add_diag_entry(hipStream_t s, double *v, const double *diag, int64_t k) {
+  hipLaunchKernelGGL(k_add_diag_entry, dim3(1), dim3(1), 0, s, v, diag, k);
+}
+void launch_camera_prior_cost(hipStream_t s, int C, const CamRec *cam, double *out, int slot, int fixed_slot, double *res_out) {
+  hipLaunchKernelGGL(k_camera_prior_cost, dim3(1), dim3(1), 0, s, C, cam, out, slot, fixed_slot, res_out);
+}
+void launch_station_finish(hipStream_t s, const StationFinishArgs &a) {
+  if (a.S > 0) hipLaunchKernelGGL(k_station_finish, dim3(nblk(a.S, 64)), dim3(64), 0, s, a);
+}
+int cost_blocks(int64_t n) {
+  const int b = nblk(n, 256);
+  return b < 1 ? 1 : (b > 4096 ? 4096 : b);
+}
+void launch_cost_obs(hipStream_t s, const CostArgs &a, int blocks) {
+  hipLaunchKernelGGL(k_cost_obs, dim3(blocks), dim3(256), 0, s, a);
+}
+void launch_cost_prior(hipStream_t s, int P, const double *xyz, const double *prior, const double *isig, const int *pt_file,
+                       double *res_out, double *partial, int blocks) {
+  hipLaunchKernelGGL(k_cost_prior, dim3(blocks), dim3(256), 0, s, P, xyz, prior, isig, pt_file, res_out, partial);
+}
+void launch_sum_partials(hipStream_t s, const double *partial, int n, double *out, int slot) {
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, partial, n, out, slot);
+}
+void launch_max_partials(hipStream_t s, const double *partial, int n, double *out, int slot) {
+  hipLaunchKernelGGL(k_max_partials, dim3(1), dim3(1024), 0, s, partial, n, out, slot);
+}
+void launch_absmax_ratio(hipStream_t s, int64_t n, const double *g, const double *scale, double *partial, int blocks) {
+  hipLaunchKernelGGL(k_absmax_ratio, dim3(blocks), dim3(256), 0, s, n, g, scale, partial);
+}
+void launch_make_scale(hipStream_t s, int64_t n, const double *colnorm, double *scale) {
+  if (n > 0) hipLaunchKernelGGL(k_make_scale, dim3(nblk(n, 256)), dim3(256), 0, s, n, colnorm, scale);
+}
+void launch_fill(hipStream_t s, int64_t n, double *v, double val) {
+  if (n > 0) hipLaunchKernelGGL(k_fill, dim3(nblk(n, 256)), dim3(256), 0, s, n, v, val);
+}
+void launch_candidate(hipStream_t s, const CandArgs &a, int blocks) {
+  hipLaunchKernelGGL(k_candidate, dim3(blocks), dim3(256), 0, s, a);
+}
+void launch_xnorm(hipStream_t s, const CandArgs &a, int blocks) {
+  hipLaunchKernelGGL(k_xnorm, dim3(blocks), dim3(256), 0, s, a);
+}
+void launch_camera_finish(hipStream_t s, const CamFinishArgs &a) {
+  hipLaunchKernelGGL(k_camera_finish, dim3(1), dim3(1), 0, s, a);
+}
+void launch_camera_mcc(hipStream_t s, int C, const CamRec *cam, const double *y_cam, double *out, int slot) {
+  hipLaunchKernelGGL(k_camera_mcc, dim3(1), dim3(1), 0, s, C, cam, y_cam, out, slot);
+}
+void launch_cg_init(hipStream_t s, const CgArgs &a) { hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(1024), 0, s, a); }
+void launch_cg_step(hipStream_t s, const CgArgs &a) { hipLaunchKernelGGL(k_cg_step, dim3(1), dim3(1024), 0, s, a); }
+void launch_copy(hipStream_t s, int64_t n, const double *src, double *dst) {
+  if (n > 0) hipLaunchKernelGGL(k_copy, dim3(nblk(n, 256)), dim3(256), 0, s, n, src, dst);
+}
+void launch_unit(hipStream_t s, int64_t n, double *v, int64_t k) {
+  if (n > 0) hipLaunchKernelGGL(k_unit, dim3(nblk(n, 256)), dim3(256), 0, s, n, v, k);
+}
+void launch_resjac_dense(hipStream_t s, const CostArgs &a, double *r_out, double *J_out) {
+  if (a.N > 0) hipLaunchKernelGGL(k_resjac_dense, dim3(nblk(a.N, 256)), dim3(256), 0, s, a, r_out, J_out);
+}
+
+}  // namespace ba

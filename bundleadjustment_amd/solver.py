@@ -1,0 +1,186 @@
+"""Python binding of the HIP solver library (include/ba_gpu.h, libba_gpu.so).
+
+Every call goes through the C ABI; there is no fallback: if the shared library is missing or
+no HIP device is visible the calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .capi import (BaDims, BaInputs, BaIterRow, BaOptions, BaSummary, Network, c_double_p, c_int32_p,
+                   rows_to_dicts, summary_to_dict)
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, c_double_p, C.c_int64, C.c_int32, C.c_void_p)
+
+KERNEL_LINEARIZE, KERNEL_POINT_APPLY, KERNEL_STATION_GATHER, KERNEL_COST = 0, 1, 2, 3
+
+# every entry point include/ba_gpu.h declares
+EXPORTS = ("ba_default_options", "ba_create", "ba_destroy", "ba_set_parameters", "ba_get_parameters",
+           "ba_solve_resident", "ba_solve", "ba_evaluate", "ba_sparsity", "ba_residual_jacobian", "ba_time_kernel",
+           "ba_set_allreduce", "ba_rccl_unique_id", "ba_use_rccl", "ba_last_error")
+
+
+def lib_path():
+    return os.path.join(_PKG, "libba_gpu.so")
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `python -m bundleadjustment_amd.build` (there is no CPU path)")
+        L = C.CDLL(path)
+        L.ba_last_error.restype = C.c_char_p
+        L.ba_create.argtypes = [C.POINTER(BaDims), C.POINTER(BaInputs), C.POINTER(C.c_void_p)]
+        L.ba_destroy.argtypes = [C.c_void_p]
+        L.ba_destroy.restype = None
+        L.ba_default_options.argtypes = [C.POINTER(BaOptions)]
+        L.ba_default_options.restype = None
+        L.ba_set_parameters.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]
+        L.ba_get_parameters.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]
+        L.ba_solve_resident.argtypes = [C.c_void_p, C.POINTER(BaOptions), C.POINTER(BaSummary), C.POINTER(BaIterRow), C.c_int32]
+        L.ba_solve.argtypes = [C.c_void_p, C.POINTER(BaOptions), c_double_p, c_double_p, c_double_p, c_double_p,
+                               C.POINTER(BaSummary), C.POINTER(BaIterRow), C.c_int32]
+        L.ba_evaluate.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, c_double_p, c_double_p]
+        L.ba_sparsity.argtypes = [C.c_void_p, c_int32_p, c_int32_p, C.POINTER(C.c_int64), c_int32_p, c_int32_p]
+        L.ba_residual_jacobian.argtypes = [C.c_void_p, c_double_p, c_double_p]
+        L.ba_time_kernel.argtypes = [C.c_void_p, C.c_int32, C.c_int32, c_double_p]
+        L.ba_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+        L.ba_rccl_unique_id.argtypes = [C.c_void_p]
+        L.ba_use_rccl.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class BaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ba_gpu error {code}: {msg}")
+        self.code = code
+
+
+def _check(rc):
+    if rc != 0:
+        raise BaError(rc, lib().ba_last_error().decode())
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def default_options():
+    o = BaOptions()
+    lib().ba_default_options(C.byref(o))
+    return o
+
+
+class Problem:
+    """One bundle-adjustment problem resident on the current HIP device (ba_create ... ba_destroy)."""
+
+    def __init__(self, net: Network):
+        self.net = net
+        self._h = C.c_void_p()
+        d, inp = net.dims(), net.inputs()
+        _check(lib().ba_create(C.byref(d), C.byref(inp), C.byref(self._h)))
+        self._cb = None
+
+    def close(self):
+        if self._h:
+            lib().ba_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_parameters(self, eop=None, xyz=None, iop=None, ap=None):
+        n = self.net
+        eop, xyz, iop, ap = (np.ascontiguousarray(a if a is not None else b, dtype=np.float64)
+                             for a, b in ((eop, n.eop), (xyz, n.xyz), (iop, n.iop), (ap, n.ap)))
+        _check(lib().ba_set_parameters(self._h, _dp(eop), _dp(xyz), _dp(iop), _dp(ap)))
+
+    def get_parameters(self):
+        n = self.net
+        eop, xyz, iop, ap = (np.zeros_like(a) for a in (n.eop, n.xyz, n.iop, n.ap))
+        _check(lib().ba_get_parameters(self._h, _dp(eop), _dp(xyz), _dp(iop), _dp(ap)))
+        return eop, xyz, iop, ap
+
+    def solve_resident(self, options, rows_cap=256):
+        sm = BaSummary()
+        rows = (BaIterRow * rows_cap)()
+        _check(lib().ba_solve_resident(self._h, C.byref(options), C.byref(sm), rows, rows_cap))
+        self.last_summary = sm
+        return summary_to_dict(sm), rows_to_dicts(rows, min(sm.num_iterations, rows_cap))
+
+    def solve(self, options, rows_cap=256):
+        """ceres::Solve semantics: starts from the network's parameters, returns the adjusted copies."""
+        eop, xyz, iop, ap = self.net.params_copy()
+        sm = BaSummary()
+        rows = (BaIterRow * rows_cap)()
+        _check(lib().ba_solve(self._h, C.byref(options), _dp(eop), _dp(xyz), _dp(iop), _dp(ap), C.byref(sm), rows, rows_cap))
+        self.last_summary = sm
+        return eop, xyz, iop, ap, summary_to_dict(sm), rows_to_dicts(rows, min(sm.num_iterations, rows_cap))
+
+    def evaluate(self, eop=None, xyz=None, iop=None, ap=None, apply_loss=True, residuals=True):
+        n = self.net
+        eop, xyz, iop, ap = (np.ascontiguousarray(a if a is not None else b, dtype=np.float64)
+                             for a, b in ((eop, n.eop), (xyz, n.xyz), (iop, n.iop), (ap, n.ap)))
+        cost = C.c_double()
+        res = np.zeros(2 * n.n_obs + 3 * n.n_pts + 3 * n.n_cam) if residuals else None
+        _check(lib().ba_evaluate(self._h, _dp(eop), _dp(xyz), _dp(iop), _dp(ap), int(bool(apply_loss)), C.byref(cost),
+                                 _dp(res) if residuals else None))
+        return cost.value, res
+
+    def sparsity(self):
+        nr, nc, nnz = C.c_int32(), C.c_int32(), C.c_int64()
+        _check(lib().ba_sparsity(self._h, C.byref(nr), C.byref(nc), C.byref(nnz), None, None))
+        rows = np.zeros(nr.value + 1, dtype=np.int32)
+        cols = np.zeros(nnz.value, dtype=np.int32)
+        _check(lib().ba_sparsity(self._h, C.byref(nr), C.byref(nc), C.byref(nnz), rows.ctypes.data_as(c_int32_p),
+                                 cols.ctypes.data_as(c_int32_p)))
+        return nr.value, nc.value, rows, cols
+
+    def residual_jacobian(self, jacobian=True):
+        n = self.net
+        r = np.zeros(2 * n.n_obs)
+        J = np.zeros((n.n_obs, 2, 28)) if jacobian else None
+        _check(lib().ba_residual_jacobian(self._h, _dp(r), _dp(J) if jacobian else None))
+        return r, J
+
+    def time_kernel(self, which, repeats=10):
+        t = C.c_double()
+        _check(lib().ba_time_kernel(self._h, which, repeats, C.byref(t)))
+        return t.value
+
+    def set_allreduce(self, fn):
+        """fn(device_ptr:int, count:int, op:int, stream:int) -> int, called on the solver's stream."""
+        def tramp(user, buf, count, op, stream):
+            try:
+                return int(fn(C.cast(buf, C.c_void_p).value, int(count), int(op), stream or 0))
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return -1
+        self._cb = ALLREDUCE_FN(tramp)
+        _check(lib().ba_set_allreduce(self._h, self._cb, None))
+
+    def use_rccl(self, n_ranks, rank, unique_id: bytes):
+        buf = C.create_string_buffer(unique_id, 128)
+        _check(lib().ba_use_rccl(self._h, n_ranks, rank, buf))
+
+
+def rccl_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    _check(lib().ba_rccl_unique_id(buf))
+    return buf.raw

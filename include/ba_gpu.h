@@ -220,18 +220,23 @@ int ba_sparsity(ba_problem *p, int32_t *num_rows, int32_t *num_cols, int64_t *nn
 int ba_residual_jacobian(ba_problem *p, double *r, double *J);
 
 /*
- * Times `repeats` launches of the fused residual/Jacobian/point-elimination kernel at the
- * resident parameters with HIP events on the solver stream and returns the mean seconds
- * per launch.  Used for the Jacobian obs/s figure and the roofline line of the benchmark.
+ * Times `repeats` launches of one kernel at the resident parameters with HIP events on the
+ * solver's stream and returns the mean seconds per launch.  Used for the Jacobian obs/s figure
+ * and the roofline line of the benchmark.  which:
+ *   0  fused residual + Jacobian + point elimination (one lane per point)
+ *   1  point half of the reduced operator  S p   (PCG inner loop)
+ *   2  station half of the reduced operator      (PCG inner loop)
+ *   3  residual-only cost evaluation at a candidate point
+ * No counterpart in the reference (its timers are wall-clock prints, src/main.cpp:3027, 4703).
  */
-int ba_time_linearize(ba_problem *p, int32_t repeats, double *seconds_per_launch);
+int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *seconds_per_launch);
 
 /*
  * Multi-GPU: a problem built from one shard of the points (and all observations of those
  * points) takes part in a sum over ranks of the reduced camera system.  Stations and
  * cameras are replicated, so eop/iop/ap passed to every rank are the full arrays.
  *   - point priors belong to the shard that owns the point;
- *   - IOP priors are added once, by the rank with add_camera_priors != 0.
+ *   - IOP priors are added by every rank after the sums over ranks, so they count once.
  * The callback must reduce buf[0..count) over all ranks in place (device memory) with
  * op 0 = sum or op 1 = max and return 0; it is called on the solver's stream, which it
  * receives as an opaque hipStream_t.
@@ -240,13 +245,12 @@ int ba_time_linearize(ba_problem *p, int32_t repeats, double *seconds_per_launch
  */
 typedef int (*ba_allreduce_fn)(void *user, double *device_buf, int64_t count, int32_t op,
                                void *hip_stream);
-int ba_set_allreduce(ba_problem *p, ba_allreduce_fn fn, void *user, int32_t add_camera_priors);
+int ba_set_allreduce(ba_problem *p, ba_allreduce_fn fn, void *user);
 
 /* RCCL implementation of the callback above.  unique_id is the 128-byte ncclUniqueId made
  * by ba_rccl_unique_id on rank 0 and distributed by the host. */
 int ba_rccl_unique_id(void *unique_id_128);
-int ba_use_rccl(ba_problem *p, int32_t n_ranks, int32_t rank, const void *unique_id_128,
-                int32_t add_camera_priors);
+int ba_use_rccl(ba_problem *p, int32_t n_ranks, int32_t rank, const void *unique_id_128);
 
 const char *ba_last_error(void);
 
