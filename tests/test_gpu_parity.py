@@ -1,0 +1,239 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle on the same inputs.
+Tolerances: index/sparsity data bit-exact; floating point 1e-9 relative (stated in util.RTOL)
+on per-iteration cost, final parameters and sigma0; the per-observation kernel is held to
+1e-11 (it has no accumulated sums)."""
+import numpy as np
+import pytest
+
+from bundleadjustment_amd import capi, host, solver
+from oracle import py_oracle as po
+
+from util import RTOL, assert_solve_parity, modified, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_solve(net, opt):
+    with solver.Problem(net) as P:
+        return P.solve(opt)
+
+
+def options(linear_solver, **kw):
+    o = solver.default_options()
+    o.linear_solver = linear_solver
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+# ------------------------------------------------------------------------------------------------
+# per-observation kernel
+# ------------------------------------------------------------------------------------------------
+def golden_network(golden):
+    """Every golden case as its own station, point and camera (all parameters differ per observation)."""
+    cs = golden["collinearity"]
+    n = len(cs)
+    obs = np.array([c["obs"] for c in cs])
+    return capi.Network(
+        obs_pt=np.arange(n), obs_sta=np.arange(n), sta_cam=np.arange(n),
+        obs_x=obs[:, 0], obs_y=obs[:, 1], obs_sx=obs[:, 2], obs_sy=obs[:, 3], obs_cx=obs[:, 4], obs_cy=obs[:, 5],
+        pt_prior=np.array([c["xyz"] for c in cs]), pt_sigma=np.full((n, 3), 10.0),
+        iop_prior=np.array([c["iop"] for c in cs]), iop_sigma=np.tile([10.0, 10.0, 1000.0], (n, 1)),
+        ap_free_mask=np.full(n, 0xFFFF), iop_free_mask=np.full(n, 7),
+        eop=np.array([c["eop"] for c in cs]), xyz=np.array([c["xyz"] for c in cs]),
+        iop=np.array([c["iop"] for c in cs]), ap=np.array([c["ap"] for c in cs]))
+
+
+def test_residual_jacobian_kernel_vs_golden(golden):
+    # golden = the reference's functors (src/main.cpp:2033-2120) and their complex-step derivative
+    net = golden_network(golden)
+    with solver.Problem(net) as P:
+        P.set_parameters()
+        r, J = P.residual_jacobian()
+    rg = np.array([c["r_mls"] for c in golden["collinearity"]]).reshape(-1)
+    Jg = np.array([c["J"] for c in golden["collinearity"]]).reshape(-1, 2, 28)
+    # residuals are differences of numbers ~1e3: absolute 1e-11 in units of sigma
+    assert np.max(np.abs(r - rg)) < 1e-10
+    scale = np.maximum(np.abs(Jg), 1e-9 * np.max(np.abs(Jg), axis=(1, 2), keepdims=True))
+    assert np.max(np.abs(J - Jg) / scale) < 1e-9
+    assert np.array_equal(J[:, 1, 12:14], np.zeros((len(r) // 2, 2)))  # a1, a2 do not enter y (:2090)
+
+
+def test_residual_jacobian_kernel_vs_oracle():
+    net = host.synth_config("cfg2", scale=0.02).net
+    with solver.Problem(net) as P:
+        P.set_parameters()
+        r, J = P.residual_jacobian()
+    ro, Jo = po.residual_jacobian_all(net)
+    assert np.max(np.abs(r - ro)) < 1e-10
+    scale = np.maximum(np.abs(Jo), 1e-9 * np.max(np.abs(Jo), axis=(1, 2), keepdims=True))
+    assert np.max(np.abs(J - Jo) / scale) < 1e-10
+
+
+@pytest.mark.parametrize("apply_loss", [True, False])
+def test_evaluate_cost_and_residual_order(apply_loss):
+    # problem.Evaluate, src/main.cpp:4853: rows = image (file order) | XYZ priors | IOP priors
+    net = host.synth(n_cam=2, n_sta=9, n_pts=50, rays_per_point=5, seed=9, outlier_fraction=0.3).net
+    with solver.Problem(net) as P:
+        c, r = P.evaluate(apply_loss=apply_loss)
+    co, ro = po.evaluate(net, apply_loss=apply_loss)
+    assert abs(c - co) <= 1e-13 * co
+    assert np.max(np.abs(r - ro)) < 1e-10
+
+
+# ------------------------------------------------------------------------------------------------
+# sparsity pattern / index maps: bit-exact
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("masks", [(host.AP_REFERENCE_DEFAULT, 7), (host.AP_ALL16, 7), (0, 0), (host.AP_BROWN7, 5), (0, 7)])
+def test_sparsity_bit_exact(masks):
+    net = host.synth(n_cam=3, n_sta=7, n_pts=30, rays_per_point=4, seed=2, ap_free_mask=masks[0], iop_free_mask=masks[1]).net
+    with solver.Problem(net) as P:
+        nr, nc, rows, cols = P.sparsity()
+    onr, onc, orows, ocols = po.sparsity(net)
+    assert (nr, nc) == (onr, onc)
+    assert np.array_equal(rows, orows) and np.array_equal(cols, ocols)
+
+
+# ------------------------------------------------------------------------------------------------
+# full solves
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ls", [capi.SOLVER_DENSE_SCHUR, capi.SOLVER_PCG_SCHUR])
+def test_cfg1_solve_parity_and_sigma0(ls):
+    # configs[0]: the reference's CPU-runnable case, full size; oracle in its most literal mode
+    hn = host.synth_config("cfg1")
+    net = hn.net
+    opt = options(ls)
+    g = gpu_solve(net, opt)
+    o = po.solve(net, opt, po.FULL_DENSE)
+    assert o[4]["termination"] == capi.CONVERGENCE
+    assert_solve_parity(g, o)
+    sg, so = capi.BaSummary(), capi.BaSummary()
+    for s, d in ((sg, g[4]), (so, o[4])):
+        for k, v in d.items():
+            if hasattr(s, k):
+                setattr(s, k, v)
+    s0g, redg = host.sigma0(sg, net.n_pts, hn.num_ap_correction())
+    s0o, redo = host.sigma0(so, net.n_pts, hn.num_ap_correction())
+    assert redg == redo and abs(s0g - s0o) <= RTOL * s0o
+    # the adjustment recovers the truth: better than the start values
+    assert np.sqrt(np.mean((g[1] - net.truth["xyz"]) ** 2)) < 0.6 * np.sqrt(np.mean((net.xyz - net.truth["xyz"]) ** 2))
+
+
+@pytest.mark.parametrize("name,scale", [("cfg2", 0.05), ("cfg3", 0.01), ("cfg4", 0.005)])
+@pytest.mark.parametrize("ls", [capi.SOLVER_DENSE_SCHUR, capi.SOLVER_PCG_SCHUR])
+def test_scaled_configs_solve_parity(name, scale, ls):
+    net = host.synth_config(name, scale=scale).net
+    opt = options(ls)
+    g = gpu_solve(net, opt)
+    o = po.solve(net, opt, po.SCHUR_DENSE)
+    assert o[4]["termination"] == capi.CONVERGENCE
+    assert_solve_parity(g, o)
+
+
+@pytest.mark.parametrize("ls", [capi.SOLVER_DENSE_SCHUR, capi.SOLVER_PCG_SCHUR])
+@pytest.mark.parametrize("clamp", [True, False])
+def test_rejected_steps(ls, clamp):
+    toy = host.synth(n_cam=1, n_sta=3, n_pts=8, rays_per_point=3, ap_free_mask=host.ap_mask("k1"), control_every=1,
+                     control_sigma=10.0, outlier_fraction=0.2, seed=11).net
+    bad = modified(toy, eop=toy.eop + np.array([0.8, -0.8, 1.5, 2000.0, -2000.0, 3000.0]))
+    kw = dict(max_num_iterations=12)
+    if not clamp:
+        kw.update(min_lm_diagonal=1e-6, max_lm_diagonal=1e32)  # Ceres' own defaults: real LM damping
+    opt = options(ls, **kw)
+    g = gpu_solve(bad, opt)
+    o = po.solve(bad, opt, po.FULL_DENSE)
+    assert any(r["step_is_successful"] == 0 for r in o[5])
+    # far from the solution the problem is badly conditioned: 1e-7 on the costs
+    assert_solve_parity(g, o, cost_rtol=1e-7, par_rtol=1e-6)
+
+
+def test_edge_cases_unused_blocks():
+    # a station nobody observes from, a point nobody observes, a camera without stations' observations
+    base = host.synth(n_cam=1, n_sta=6, n_pts=40, rays_per_point=4, seed=4, control_every=4).net
+    S, P = base.n_sta, base.n_pts
+    net = modified(
+        base,
+        sta_cam=np.concatenate([base.sta_cam, [1]]),           # extra station using camera 1
+        eop=np.vstack([base.eop, base.eop[:1] + 1.0]),
+        xyz=np.vstack([base.xyz, [[1.0, 2.0, 3.0]]]),          # extra point, prior only
+        pt_prior=np.vstack([base.pt_prior, [[1.5, 2.5, 2.0]]]),
+        pt_sigma=np.vstack([base.pt_sigma, [[10.0, 20.0, 30.0]]]),
+        iop=np.vstack([base.iop, [[1.0, -1.0, 3100.0]]]),      # camera 1: never observed through
+        iop_prior=np.vstack([base.iop_prior, [[0.0, 0.0, 3000.0]]]),
+        iop_sigma=np.vstack([base.iop_sigma, [[10.0, 10.0, 1000.0]]]),
+        ap=np.vstack([base.ap, np.zeros((1, 16))]),
+        ap_free_mask=np.array([host.AP_BROWN7, host.AP_BROWN7]), iop_free_mask=np.array([7, 7]))
+    assert net.n_sta == S + 1 and net.n_pts == P + 1 and net.n_cam == 2
+    for ls in (capi.SOLVER_DENSE_SCHUR, capi.SOLVER_PCG_SCHUR):
+        opt = options(ls)
+        g = gpu_solve(net, opt)
+        o = po.solve(net, opt, po.FULL_DENSE)
+        assert_solve_parity(g, o)
+        assert np.array_equal(g[0][S], net.eop[S])                    # unobserved station untouched
+        assert np.allclose(g[1][P], net.pt_prior[P], atol=1e-6)        # prior-only point goes to its prior
+        assert np.allclose(g[2][1], net.iop_prior[1], atol=1e-6)       # prior-only camera goes to its prior
+        assert np.array_equal(g[3][1], net.ap[1])                      # its AP block is not in the program
+        assert g[4]["num_parameters_reduced"] == 6 * S + 3 * (P + 1) + 19 + 3
+
+
+def test_constant_blocks_and_partial_masks():
+    net = host.synth(n_cam=2, n_sta=8, n_pts=60, rays_per_point=6, seed=6, control_every=4,
+                     ap_free_mask=host.ap_mask("k1", "p1"), iop_free_mask=4).net  # only c free
+    net = modified(net, ap_free_mask=np.array([host.ap_mask("k1", "p1"), 0]), iop_free_mask=np.array([4, 0]))
+    for ls in (capi.SOLVER_DENSE_SCHUR, capi.SOLVER_PCG_SCHUR):
+        opt = options(ls)
+        g = gpu_solve(net, opt)
+        o = po.solve(net, opt, po.FULL_DENSE)
+        assert_solve_parity(g, o)
+        assert np.array_equal(g[2][1], net.iop[1]) and np.array_equal(g[3][1], net.ap[1])
+        assert np.array_equal(g[2][0][:2], net.iop[0][:2])
+
+
+def test_no_observations_and_empty_problem():
+    net = host.synth(n_cam=1, n_sta=3, n_pts=5, rays_per_point=2, seed=8).net
+    empty = modified(net, obs_pt=np.zeros(0, np.int32), obs_sta=np.zeros(0, np.int32), obs_x=np.zeros(0),
+                     obs_y=np.zeros(0), obs_sx=np.zeros(0), obs_sy=np.zeros(0), obs_cx=np.zeros(0), obs_cy=np.zeros(0))
+    with solver.Problem(empty) as P:
+        c, r = P.evaluate()
+        co, ro = po.evaluate(empty)
+        assert c == pytest.approx(co, abs=1e-15) and np.allclose(r, ro)
+        out = P.solve(options(capi.SOLVER_PCG_SCHUR))
+    o = po.solve(empty, options(capi.SOLVER_PCG_SCHUR), po.SCHUR_DENSE)
+    assert out[4]["stop_reason"] == o[4]["stop_reason"]
+    assert np.array_equal(out[0], empty.eop)
+
+
+def test_error_behaviour():
+    net = host.synth(n_cam=1, n_sta=3, n_pts=5, rays_per_point=2, seed=8).net
+    bad = modified(net, obs_pt=np.where(np.arange(net.n_obs) == 1, 99, net.obs_pt))
+    with pytest.raises(solver.BaError, match="point index 99"):
+        solver.Problem(bad)
+    with pytest.raises(solver.BaError, match="standard deviation"):
+        solver.Problem(modified(net, obs_sx=np.zeros(net.n_obs)))
+    with pytest.raises(solver.BaError, match="model"):
+        solver.Problem(capi.Network(**{k: getattr(net, k) for k in __import__("util").FIELDS}, model=3))
+    with solver.Problem(net) as P:
+        with pytest.raises(solver.BaError, match="ba_set_parameters"):
+            P.solve_resident(options(capi.SOLVER_DENSE_SCHUR))
+        o = options(capi.SOLVER_DENSE_SCHUR)
+        o.linear_solver = 7
+        P.set_parameters()
+        with pytest.raises(solver.BaError, match="linear_solver"):
+            P.solve_resident(o)
+
+
+def test_resident_solve_equals_in_place_solve():
+    net = host.synth_config("cfg1", scale=0.5).net
+    opt = options(capi.SOLVER_PCG_SCHUR)
+    with solver.Problem(net) as P:
+        a = P.solve(opt)
+        P.set_parameters()
+        sm, rows = P.solve_resident(opt)
+        b = P.get_parameters()
+        for x, y in zip(a[:4], b):
+            assert np.array_equal(x, y)  # same kernels, same order: bitwise
+        assert sm["final_cost"] == a[4]["final_cost"]
+        # solving again from the solution stops at once and changes nothing
+        sm2, rows2 = P.solve_resident(opt)
+        assert sm2["num_iterations"] <= 2
+        assert rel(P.get_parameters()[1], b[1]) < 1e-12

@@ -1,0 +1,141 @@
+"""Readers, writers, index maps and sigma0 of the C++ host library (include/ba_host.h) against
+the behaviour of the reference's main() (src/main.cpp line numbers in the test names' comments)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from bundleadjustment_amd import capi, host
+from oracle import py_oracle as po
+
+
+@pytest.fixture()
+def net_files(tmp_path):
+    hn = host.synth(n_cam=2, n_sta=5, n_pts=12, rays_per_point=4, seed=21)
+    hn.write_inputs(str(tmp_path), "t")
+    return hn, tmp_path
+
+
+def paths(d, stem="t"):
+    return [os.path.join(str(d), f"{stem}.{e}") for e in ("pho", "eop", "iop", "xyz")]
+
+
+def test_round_trip(net_files):
+    hn, d = net_files
+    rd = host.read_network(*paths(d))
+    a, b = hn.net, rd.net
+    for k in ("obs_pt", "obs_sta", "sta_cam"):
+        assert np.array_equal(getattr(a, k), getattr(b, k))
+    for k in ("obs_x", "obs_y", "obs_sx", "obs_sy", "obs_cx", "obs_cy", "pt_prior", "pt_sigma", "iop", "ap", "xyz"):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    # angles go through degrees (src/main.cpp:3161-3163): equal to rounding
+    assert np.allclose(a.eop, b.eop, rtol=0, atol=1e-15 * 10)
+    # reference defaults: only k1 free (src/main.cpp:4487-4504), IOP free, priors 10,10,1000 (:4612-4623)
+    assert np.all(b.ap_free_mask == host.AP_REFERENCE_DEFAULT) and np.all(b.iop_free_mask == 7)
+    assert np.array_equal(b.iop_sigma, np.tile([10.0, 10.0, 1000.0], (2, 1)))
+    assert np.array_equal(b.iop_prior, b.iop) and np.array_equal(b.pt_prior, b.xyz)
+    assert rd.num_ap_correction() == 15  # src/main.cpp:4509
+
+
+def test_last_record_without_trailing_newline_is_dropped(net_files):
+    # `inp >> ...; push_back; if (inp.eof()) break;` then pop_back (src/main.cpp:3061-3094)
+    hn, d = net_files
+    pho = paths(d)[0]
+    txt = open(pho).read()
+    assert txt.endswith("\n")
+    open(pho, "w").write(txt.rstrip("\n"))
+    rd = host.read_network(*paths(d))
+    assert rd.net.n_obs == hn.net.n_obs - 1
+    open(pho, "w").write(txt + "  \n\n")  # extra trailing whitespace changes nothing
+    assert host.read_network(*paths(d)).net.n_obs == hn.net.n_obs
+
+
+def test_empty_and_ragged_files(net_files, tmp_path):
+    hn, d = net_files
+    pho = paths(d)[0]
+    txt = open(pho).read()
+    open(pho, "w").write("")  # empty .pho: zero observations, not an error
+    assert host.read_network(*paths(d)).net.n_obs == 0
+    lines = txt.splitlines()
+    open(pho, "w").write("\n".join(lines[:-1]) + "\n" + " ".join(lines[-1].split()[:5]) + "\n")  # ragged last record
+    assert host.read_network(*paths(d)).net.n_obs == hn.net.n_obs - 1
+    open(pho, "w").write(lines[0].replace(lines[0].split()[3], "abc") + "\n")
+    with pytest.raises(RuntimeError, match="malformed"):
+        host.read_network(*paths(d))
+    with pytest.raises(RuntimeError, match="cannot open"):
+        host.read_network(str(tmp_path / "nope.pho"), *paths(d)[1:])
+
+
+def test_missing_ids_are_errors(net_files):
+    hn, d = net_files
+    pho = paths(d)[0]
+    lines = open(pho).read().splitlines()
+    f = lines[0].split()
+    f[0] = "999999"
+    open(pho, "w").write("\n".join([" ".join(f)] + lines[1:]) + "\n")
+    with pytest.raises(RuntimeError, match="target id"):
+        host.read_network(*paths(d))
+
+
+def test_index_first_match_equals_linear_search():
+    # src/main.cpp:3821-3831: first occurrence wins on duplicate ids
+    rng = np.random.default_rng(3)
+    ids = rng.integers(0, 50, 200).astype(np.int32)
+    keys = rng.choice(ids, 500).astype(np.int32)
+    rc, out = host.index_first_match(ids, keys)
+    assert rc == 0
+    assert np.array_equal(out, po.index_first_match(ids, keys))
+    keys[7] = 1000
+    rc, out = host.index_first_match(ids, keys)
+    assert rc != 0 and out[7] == len(ids)
+    assert np.array_equal(out, po.index_first_match(ids, keys))
+    rc, out = host.index_first_match(np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert rc == 0 and len(out) == 0
+
+
+def test_result_files_format(net_files, tmp_path):
+    hn, d = net_files
+    net = hn.net
+    out = tmp_path / "out"
+    out.mkdir()
+    _, res = po.evaluate(net, apply_loss=True)
+    hn.write_results(str(out), res)
+    num = r"-?\d+\.\d{6}"
+    # image.jck (src/main.cpp:6996): ids, x y vx vy, redundancy sentinels 1e6 (%.2lf), sigma_v = observation sigma
+    lines = open(out / "image.jck").read().splitlines()
+    assert len(lines) == net.n_obs
+    pat = re.compile(rf"^\d+ \d+ \d+ {num} {num} {num} {num} 1000000\.00 1000000\.00 {num} {num}$")
+    assert all(pat.match(l) for l in lines)
+    f = lines[3].split()
+    assert int(f[0]) == hn.ids("pho_target")[3] and int(f[1]) == hn.ids("pho_station")[3]
+    assert float(f[5]) == pytest.approx(res[6] * net.obs_sx[3], abs=5e-7)
+    assert float(f[9]) == pytest.approx(net.obs_sx[3], abs=5e-7)
+    # EOP.jck (src/main.cpp:7096): angles in degrees, sentinel sigmas sqrt(1e6) (degrees: *180/pi)
+    f = open(out / "EOP.jck").read().splitlines()[0].split()
+    assert len(f) == 13 and float(f[1]) == pytest.approx(np.degrees(net.eop[0, 0]), abs=5e-7)
+    assert f[10] == "1000.000000" and float(f[7]) == pytest.approx(1000 * 180 / np.pi, abs=1e-6)
+    # temp.eop (src/main.cpp:4804): station camera Xo Yo Zo omega phi kappa
+    f = open(out / "temp.eop").read().splitlines()[1].split()
+    assert len(f) == 8 and float(f[2]) == pytest.approx(net.eop[1, 3], abs=5e-7)
+    # iop.jck / temp.iop / ap.jck / XYZ.jck / temp.pho column counts (src/main.cpp:7107, 4843, 7118, 7085, 3130)
+    assert len(open(out / "iop.jck").read().splitlines()[0].split()) == 7
+    assert len(open(out / "temp.iop").read().splitlines()[0].split()) == 25
+    assert len(open(out / "ap.jck").read().splitlines()[0].split()) == 33
+    assert len(open(out / "XYZ.jck").read().splitlines()[0].split()) == 7
+    assert len(open(out / "temp.pho").read().splitlines()) == net.n_obs
+    # temp.* can be read back as inputs (the reference's outer loop does, src/main.cpp:3056)
+    rd = host.read_network(str(out / "temp.pho"), str(out / "temp.eop"), str(out / "temp.iop"), paths(d)[3])
+    assert rd.net.n_obs == net.n_obs
+    assert np.allclose(rd.net.obs_x, net.obs_x, atol=5e-7)
+
+
+def test_synth_is_deterministic_and_shaped():
+    a = host.synth_config("cfg1").net
+    b = host.synth_config("cfg1").net
+    assert a.n_obs == 10000 and a.n_sta == 24 and a.n_pts == 500 and a.n_cam == 1
+    assert np.array_equal(a.obs_x, b.obs_x) and np.array_equal(a.xyz, b.xyz)
+    assert np.abs(a.obs_x).max() < 2600 and np.abs(a.obs_y).max() < 2600
+    # every point is observed rays_per_point times, .pho is in station-major order
+    assert np.all(np.bincount(a.obs_pt, minlength=500) == 20)
+    assert np.all(np.diff(a.obs_sta) >= 0)
