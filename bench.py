@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Benchmark of the Levenberg-Marquardt inner loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step is one LM iteration (linearise + reduced solve + candidate evaluation) of the 10M-observation
+synthetic network ("cfg4": 1 camera, 10k stations, 2M points, IOP + k1 k2 p1 p2 free) with the
+parameters resident in HBM.  With N > 1 the same network is split by points over the ranks
+(strong scaling) and the reduced camera system is summed with RCCL.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def kernel_bytes(which, net_obs, net_pts, net_sta):
+    """Algorithmic bytes one launch must move (per-observation figures x observations).
+    0 linearize     : obs record 56 + station 48 + point 24 + residual 16 + W-equivalent 144 per observation,
+                      72 per point (V, g), 216 per station (U, g)
+    1 point_apply   : Js 96 + Jp 48 + station index 4 + p_i 48 + b 16 per observation, Vinv 48 per point
+    2 station_gather: Js 96 + b 16 + index 4 per observation, q 48 per station"""
+    if which == 0:
+        return 288.0 * net_obs + 72.0 * net_pts + 216.0 * net_sta
+    if which == 1:
+        return 212.0 * net_obs + 48.0 * net_pts
+    if which == 2:
+        return 116.0 * net_obs + 48.0 * net_sta
+    return 80.0 * net_obs  # cost: obs record 56 + point 24 (station table stays in L2)
+
+
+KERNEL_NAMES = {0: "k_linearize", 1: "k_point_pass<APPLY>", 2: "k_station_pass<GATHER>", 3: "k_cost_obs"}
+
+
+def cpu_baseline(config, cpu_scale, pcg_rtol):
+    """The CPU oracle (plain C, one thread) on a shrunk copy of the same network."""
+    from bundleadjustment_amd import capi, host
+    from oracle import py_oracle as po
+    hn = host.synth_config(config, scale=cpu_scale)
+    net = hn.net
+    opt = capi.default_options(linear_solver=capi.SOLVER_PCG_SCHUR, pcg_rtol=pcg_rtol, pcg_max_iters=5000)
+    opt.max_num_iterations = 2
+    opt.function_tolerance = 0.0
+    opt.parameter_tolerance = 0.0
+    opt.gradient_tolerance = 0.0
+    t0 = time.time()
+    *_, sm, rows = po.solve(net, opt, po.SCHUR_PCG)
+    t_solve = time.time() - t0
+    iters = max(1, sm["num_iterations"] - 1)
+    t0 = time.time()
+    po.linearize_once(net)
+    t_lin = time.time() - t0
+    return net.n_obs, iters / t_solve, net.n_obs / t_lin, sm["total_linear_iterations"] / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="cfg4")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the network (stations and points) for quick runs")
+    ap.add_argument("--pcg-rtol", type=float, default=1e-12, help="PCG stopping tolerance; 1e-12 is what the parity tests use")
+    ap.add_argument("--cpu-scale", type=float, default=0.02, help="size of the CPU-baseline sample relative to the config")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the solver has no CPU path")
+    torch.cuda.set_device(local_rank)
+    from bundleadjustment_amd import capi, host, sharding, solver
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    hn = host.synth_config(args.config, scale=args.scale)
+    full = hn.net
+    net, _ = sharding.shard_network(full, rank, world)
+    P = solver.Problem(net)
+    if world > 1:
+        ids = [solver.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        P.use_rccl(world, rank, ids[0])
+    P.set_parameters()
+
+    def options(iters):
+        o = solver.default_options()
+        o.linear_solver = capi.SOLVER_PCG_SCHUR
+        o.pcg_rtol = args.pcg_rtol
+        o.pcg_max_iters = 20000
+        o.max_num_iterations = iters
+        # run exactly `iters` iterations: the stopping tests are off, the arithmetic is unchanged
+        o.function_tolerance = 0.0
+        o.parameter_tolerance = 0.0
+        o.gradient_tolerance = 0.0
+        return o
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        P.solve_resident(options(args.warmup))
+        P.set_parameters()
+    barrier()
+    t0 = time.perf_counter()
+    sm, rows = P.solve_resident(options(args.steps))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    steps_done = sm["num_iterations"] - 1
+    if steps_done != args.steps:
+        sys.exit(f"solver ran {steps_done} iterations instead of {args.steps}: {sm}")
+
+    # per-kernel timing with HIP events on the solver's stream (live, same process)
+    ktime = {w: P.time_kernel(w, 10) for w in (0, 1, 2, 3)}
+    if world > 1:
+        t = torch.tensor([ktime[w] for w in (0, 1, 2, 3)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ktime = {w: float(t[i].item()) for i, w in enumerate((0, 1, 2, 3))}
+    lin_iters = sm["total_linear_iterations"]
+    n_lin = sum(1 for r in rows if r["step_is_successful"]) + 1
+    share = {0: ktime[0] * n_lin, 1: ktime[1] * lin_iters, 2: ktime[2] * lin_iters, 3: ktime[3] * args.steps}
+    dom = max(share, key=share.get)
+    nbytes = kernel_bytes(dom, net.n_obs, net.n_pts, net.n_sta)
+    achieved = nbytes / ktime[dom] / 1e9
+    kernels = []
+    for w in (0, 1, 2, 3):
+        b = kernel_bytes(w, net.n_obs, net.n_pts, net.n_sta)
+        kernels.append({"kernel": KERNEL_NAMES[w], "ms": ktime[w] * 1e3, "algorithmic_GB": b / 1e9,
+                        "GBps": b / ktime[w] / 1e9, "frac": b / ktime[w] / 1e9 / HBM_PEAK_GBS,
+                        "share_of_step_time": share[w] / max(sum(share.values()), 1e-30)})
+
+    out = {
+        "metric": "LM iter/s (10M-obs synthetic network)",
+        "value": args.steps / elapsed,
+        "unit": "iter/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{args.config}: {full.n_cam} camera(s), {full.n_sta} stations, {full.n_pts} points, "
+                               f"{full.n_obs} observations, self-calibrating (IOP + k1 k2 p1 p2), Schur + block-Jacobi PCG",
+                   "scale": args.scale, "pcg_rtol": args.pcg_rtol, "sharding": f"points/{world}"},
+        "jacobian_obs_per_s": full.n_obs / ktime[0],
+        "pcg_iterations_per_step": lin_iters / args.steps,
+        "final_cost": sm["final_cost"],
+        "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None},
+        "kernels": kernels,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        n_cpu, it_s, obs_s, cg = cpu_baseline(args.config, args.cpu_scale * args.scale, args.pcg_rtol)
+        out["cpu_baseline"] = {
+            "value": it_s * n_cpu / full.n_obs, "unit": "iter/s", "cores": 1, "kind": "port",
+            "sample": f"oracle (C, 1 thread), same generator at {n_cpu} observations: {it_s:.3f} LM iter/s measured with "
+                      f"{cg:.0f} PCG iterations per step, scaled linearly in observations to {full.n_obs}; "
+                      f"Jacobian pass {obs_s:.3e} obs/s",
+            "jacobian_obs_per_s": obs_s, "measured_iter_per_s_on_sample": it_s, "sample_observations": n_cpu}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    P.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

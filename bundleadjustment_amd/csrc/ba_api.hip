@@ -687,8 +687,10 @@ void ba_default_options(ba_options *o) {
 int ba_create(const ba_dims *dims, const ba_inputs *in, ba_problem **out) {
   if (!dims || !in || !out) return fail(BA_ERR_INVALID, "ba_create: null argument");
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
-    return fail(BA_ERR_DEVICE, "no HIP device is visible: this library has no CPU path");
+  const hipError_t de = hipGetDeviceCount(&ndev);
+  if (de != hipSuccess || ndev < 1)
+    return fail(BA_ERR_DEVICE, "no HIP device is visible (%s, %d devices): this library has no CPU path",
+                hipGetErrorString(de), ndev);
   ba_problem *p = new ba_problem();
   const int rc = build_problem(p, dims, in);
   if (rc) {

@@ -1,0 +1,96 @@
+// ba_main.cpp -- command-line driver with the flow of the reference's main() for one
+// adjustment (src/main.cpp:3040-7135 without the machine-learning outer loop):
+//   read .pho/.eop/.iop/.xyz -> build the problem -> solve on the GPU -> sigma0 -> *.jck files.
+// The reference takes its file names and fixed/free choices from #defines (src/main.cpp:467-479,
+// 4487-4504); here they are arguments.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ba_gpu.h"
+#include "ba_host.h"
+
+static void usage() {
+  fprintf(stderr,
+          "usage: ba_main <file.pho> <file.eop> <file.iop> <file.xyz> [--out DIR] [--free-ap MASK] [--free-iop MASK]\n"
+          "               [--solver dense|pcg] [--pcg-rtol X] [--max-iter N]\n"
+          "       ba_main --synth C S P RAYS [same options]\n"
+          "  MASK: bit k of --free-ap frees AP[k] (a1 a2 k1 k2 k3 p1 p2 ep1..ep9); default 0x4 = k1 only,\n"
+          "        the reference's choice (src/main.cpp:4487-4504).  --free-iop: bits xp yp c, default 7.\n");
+}
+
+int main(int argc, char **argv) {
+  std::vector<std::string> pos;
+  std::string out = ".";
+  unsigned ap_mask = 0x4, iop_mask = 7;
+  bool synth = false;
+  ba_options opt;
+  ba_default_options(&opt);
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    auto next = [&]() -> const char * { return (i + 1 < argc) ? argv[++i] : ""; };
+    if (a == "--out") out = next();
+    else if (a == "--free-ap") ap_mask = (unsigned)strtoul(next(), nullptr, 0);
+    else if (a == "--free-iop") iop_mask = (unsigned)strtoul(next(), nullptr, 0);
+    else if (a == "--solver") opt.linear_solver = (std::string(next()) == "pcg") ? BA_SOLVER_PCG_SCHUR : BA_SOLVER_DENSE_SCHUR;
+    else if (a == "--pcg-rtol") opt.pcg_rtol = atof(next());
+    else if (a == "--max-iter") opt.max_num_iterations = atoi(next());
+    else if (a == "--synth") synth = true;
+    else pos.push_back(a);
+  }
+  ba_network *net = nullptr;
+  if (synth) {
+    if (pos.size() != 4) { usage(); return 2; }
+    ba_synth_config cfg;
+    ba_synth_default(&cfg);
+    cfg.n_cam = atoi(pos[0].c_str()); cfg.n_sta = atoi(pos[1].c_str()); cfg.n_pts = atoi(pos[2].c_str());
+    cfg.rays_per_point = atoi(pos[3].c_str());
+    cfg.ap_free_mask = (uint16_t)ap_mask; cfg.iop_free_mask = (uint8_t)iop_mask;
+    if (ba_net_synth(&cfg, &net)) { fprintf(stderr, "error: %s\n", ba_host_last_error()); return 1; }
+  } else {
+    if (pos.size() != 4) { usage(); return 2; }
+    if (ba_net_read(pos[0].c_str(), pos[1].c_str(), pos[2].c_str(), pos[3].c_str(), &net)) {
+      fprintf(stderr, "error: %s\n", ba_host_last_error());
+      return 1;
+    }
+    ba_net_set_free(net, (uint16_t)ap_mask, (uint8_t)iop_mask);
+  }
+  ba_dims d;
+  ba_inputs in;
+  ba_net_dims(net, &d);
+  ba_net_inputs(net, &in);
+  printf("    Number of observations read: %d\n    Number of EOPs read: %d\n    Number of IOPs read: %d\n    Number of XYZ read: %d\n",
+         d.n_obs, d.n_sta, d.n_cam, d.n_pts);
+  ba_problem *p = nullptr;
+  if (ba_create(&d, &in, &p)) { fprintf(stderr, "error: %s\n", ba_last_error()); return 1; }
+  ba_summary sm;
+  std::vector<ba_iter_row> rows(opt.max_num_iterations + 2);
+  if (ba_solve(p, &opt, ba_net_eop(net), ba_net_xyz(net), ba_net_iop(net), ba_net_ap(net), &sm, rows.data(), (int32_t)rows.size())) {
+    fprintf(stderr, "error: %s\n", ba_last_error());
+    return 1;
+  }
+  // the table ceres prints with minimizer_progress_to_stdout (src/main.cpp:4711)
+  printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius  ls_iter\n");
+  for (int i = 0; i < sm.num_iterations && i < (int)rows.size(); ++i)
+    printf("%4d  %.6e  %9.2e  %9.2e  %9.2e  %9.2e  %9.2e  %6d\n", rows[i].iteration, rows[i].cost, rows[i].cost_change,
+           rows[i].gradient_max_norm, rows[i].step_norm, rows[i].relative_decrease, rows[i].trust_region_radius,
+           rows[i].linear_iterations);
+  printf("Initial cost %.6e  Final cost %.6e  Termination %s\n", sm.initial_cost, sm.final_cost,
+         sm.termination == BA_CONVERGENCE ? "CONVERGENCE" : sm.termination == BA_NO_CONVERGENCE ? "NO_CONVERGENCE" : "FAILURE");
+  double red = 0;
+  const double s0 = ba_sigma0(&sm, d.n_pts, ba_net_num_ap_correction(net), &red);
+  printf("        *Ceres Quadratic Error: %g\n        *Ceres Redundancy: %g\n        *Ceres A Posteriori Variance: %g\n"
+         "        *Ceres A Posteriori Std Dev: %g\n", 2 * sm.final_cost, red, s0 * s0, s0);
+  std::vector<double> res(2 * (size_t)d.n_obs + 3 * (size_t)d.n_pts + 3 * (size_t)d.n_cam);
+  double cost = 0;
+  if (ba_evaluate(p, ba_net_eop(net), ba_net_xyz(net), ba_net_iop(net), ba_net_ap(net), 1, &cost, res.data())) {
+    fprintf(stderr, "error: %s\n", ba_last_error());
+    return 1;
+  }
+  if (ba_net_write_results(net, out.c_str(), res.data())) { fprintf(stderr, "error: %s\n", ba_host_last_error()); return 1; }
+  ba_destroy(p);
+  ba_net_free(net);
+  return 0;
+}

@@ -33,6 +33,13 @@ def lib():
         path = lib_path()
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: run `python -m bundleadjustment_amd.build` (there is no CPU path)")
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64/librccl, and a process
+        # that loads this library first and torch afterwards ends up with a device-less runtime.
+        # Loading torch first makes both share torch's copy (same SONAMEs).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(path)
         L.ba_last_error.restype = C.c_char_p
         L.ba_create.argtypes = [C.POINTER(BaDims), C.POINTER(BaInputs), C.POINTER(C.c_void_p)]
