@@ -99,6 +99,14 @@ struct ba_problem {
   double *d_g = nullptr, *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_p = nullptr, *d_q = nullptr;
   double *d_Minv = nullptr, *d_Ssc = nullptr, *d_Scc = nullptr, *d_Lcc = nullptr, *d_cgscal = nullptr, *h_cgscal = nullptr;
   double *d_Sdense = nullptr;
+  // explicit block-sparse reduced system (null / 0 when the network is too dense for it)
+  bool explicit_ok = false;
+  int n_ublk = 0, n_bsr = 0;
+  int64_t n_pairs = 0;
+  int *d_bsr_rowptr = nullptr, *d_bsr_col = nullptr, *d_ublk_cstart = nullptr;
+  int2 *d_ublk_dst = nullptr, *d_pairs = nullptr;
+  double *d_Y = nullptr, *d_bsr_val = nullptr, *d_Sdiag = nullptr, *d_Jt = nullptr, *d_corner = nullptr;
+  double *d_part_pq = nullptr, *d_part_qc = nullptr, *d_part_rz = nullptr, *d_cg2scal = nullptr;
   // state
   bool have_params = false;
   // multi-GPU
@@ -252,6 +260,96 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   // (chunks are laid out in station order and stations are contiguous in sta_list, so
   //  chunk_begin[ch+1] is also the end of chunk ch)
 
+  // Block structure of the reduced matrix: every unordered pair of observations of one point
+  // couples the two stations.  Pairs are grouped by (lo station, hi station); the groups become
+  // the upper-triangular blocks, mirrored into a full BSR pattern for the SpMV.
+  std::vector<int> bsr_rowptr, bsr_col, ublk_cstart;
+  std::vector<int2> ublk_dst, pairs;
+  {
+    int64_t npairs = 0;
+    for (int j = 0; j < P; ++j) npairs += (int64_t)deg[j] * (deg[j] - 1) / 2;
+    // pairs of one point that share a station are listed in both orders (diagonal block)
+    const int64_t pair_cap = 600000000LL;
+    if (npairs <= pair_cap && S > 0) {
+      std::vector<int64_t> rowcnt(S + 1, 0);
+      auto for_pairs = [&](auto &&fn) {
+        for (int jj = 0; jj < P; ++jj)
+          for (int a = pt_start[jj]; a < pt_start[jj + 1]; ++a)
+            for (int b = a + 1; b < pt_start[jj + 1]; ++b) {
+              const int ia = e_sta[a], ib = e_sta[b];
+              if (ia < ib) fn(ia, ib, a, b);
+              else if (ib < ia) fn(ib, ia, b, a);
+              else { fn(ia, ia, a, b); fn(ia, ia, b, a); }
+            }
+      };
+      for_pairs([&](int lo, int, int, int) { rowcnt[lo + 1]++; });
+      for (int i = 0; i < S; ++i) rowcnt[i + 1] += rowcnt[i];
+      const int64_t tot = rowcnt[S];
+      std::vector<int> hi_of(tot), ea_of(tot), eb_of(tot);
+      {
+        std::vector<int64_t> pos(rowcnt.begin(), rowcnt.end() - 1);
+        for_pairs([&](int lo, int hi, int a, int b) {
+          const int64_t q = pos[lo]++;
+          hi_of[q] = hi; ea_of[q] = a; eb_of[q] = b;
+        });
+      }
+      // inside a row: stable counting sort by hi (keeps point order inside a block)
+      pairs.resize(tot);
+      std::vector<int> cnt(S + 1), nb_lo(S, 0), nb_hi(S, 0);
+      std::vector<int> ub_lo, ub_hi;
+      ublk_cstart.push_back(0);
+      std::vector<int> touched;
+      for (int lo = 0; lo < S; ++lo) {
+        const int64_t r0 = rowcnt[lo], r1 = rowcnt[lo + 1];
+        if (r0 == r1) continue;
+        touched.clear();
+        for (int64_t q = r0; q < r1; ++q)
+          if (cnt[hi_of[q]]++ == 0) touched.push_back(hi_of[q]);
+        std::sort(touched.begin(), touched.end());
+        int64_t run = r0;
+        for (int h : touched) {
+          const int c = cnt[h];
+          cnt[h] = (int)(run - r0);  // start offset of this block inside the row
+          run += c;
+          ub_lo.push_back(lo);
+          ub_hi.push_back(h);
+          ublk_cstart.push_back((int)run);
+        }
+        for (int64_t q = r0; q < r1; ++q) {
+          const int64_t d = r0 + cnt[hi_of[q]]++;
+          pairs[d] = make_int2(ea_of[q], eb_of[q]);
+        }
+        for (int h : touched) cnt[h] = 0;
+      }
+      const int nu = (int)ub_lo.size();
+      // full BSR pattern: diagonal first, then neighbours in ascending column order
+      std::vector<int> nnb(S, 1);
+      for (int u = 0; u < nu; ++u)
+        if (ub_lo[u] != ub_hi[u]) { nnb[ub_lo[u]]++; nnb[ub_hi[u]]++; }
+      bsr_rowptr.assign(S + 1, 0);
+      for (int i = 0; i < S; ++i) bsr_rowptr[i + 1] = bsr_rowptr[i] + nnb[i];
+      const int64_t nb_total = bsr_rowptr[S];
+      if ((double)nb_total * 288.0 <= 48e9 && tot < 2000000000LL) {
+        bsr_col.assign(nb_total, 0);
+        std::vector<int> fillb(S);
+        for (int i = 0; i < S; ++i) { bsr_col[bsr_rowptr[i]] = i; fillb[i] = bsr_rowptr[i] + 1; }
+        ublk_dst.resize(nu);
+        for (int u = 0; u < nu; ++u) {
+          const int lo = ub_lo[u], hi = ub_hi[u];
+          if (lo == hi) { ublk_dst[u] = make_int2(bsr_rowptr[lo], -1); continue; }
+          const int dlo = fillb[lo]++, dhi = fillb[hi]++;
+          bsr_col[dlo] = hi;
+          bsr_col[dhi] = lo;
+          ublk_dst[u] = make_int2(dlo, dhi);
+        }
+        p->explicit_ok = true;
+        p->n_ublk = nu;
+        p->n_bsr = (int)nb_total;
+        p->n_pairs = tot;
+      }
+    }
+  }
+
   std::vector<double> prior(3 * (size_t)P), isig(3 * (size_t)P);
   for (int jj = 0; jj < P; ++jj)
     for (int k = 0; k < 3; ++k) {
@@ -304,7 +402,23 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   BA_TRY(p->dalloc(&p->d_diagfull, (size_t)p->nr));
   p->d_d2_sta = p->d_diagfull;
   BA_TRY(p->dalloc(&p->d_F, 39 * (size_t)S));
-  BA_TRY(p->dalloc(&p->d_part, 39 * (size_t)p->n_chunks));
+  BA_TRY(p->dalloc(&p->d_part, (size_t)std::max(39, border_nacc()) * p->n_chunks));
+  BA_TRY(p->dalloc(&p->d_Sdiag, 36 * (size_t)S));
+  BA_TRY(p->dalloc(&p->d_corner, 64));
+  if (p->explicit_ok) {
+    BA_TRY(p->upload(&p->d_bsr_rowptr, bsr_rowptr));
+    BA_TRY(p->upload(&p->d_bsr_col, bsr_col));
+    BA_TRY(p->upload(&p->d_ublk_cstart, ublk_cstart));
+    BA_TRY(p->upload(&p->d_ublk_dst, ublk_dst));
+    BA_TRY(p->upload(&p->d_pairs, pairs));
+    BA_TRY(p->dalloc(&p->d_Y, (size_t)BA_Y_STRIDE * N));
+    BA_TRY(p->dalloc(&p->d_bsr_val, 36 * (size_t)p->n_bsr));
+    BA_TRY(p->dalloc(&p->d_part_pq, (size_t)cg2_blocks_spmv(S) + 1));
+    BA_TRY(p->dalloc(&p->d_part_qc, ((size_t)cg2_blocks_spmv(S) + 1) * std::max(p->ncam, 1)));
+    BA_TRY(p->dalloc(&p->d_part_rz, (size_t)cg2_blocks_vec(S) + 1));
+    BA_TRY(p->dalloc(&p->d_cg2scal, 8));
+  }
+  if (C == 1 && p->ncmax > 0 && p->ncmax <= border_ncb()) BA_TRY(p->dalloc(&p->d_Jt, 2 * (size_t)border_ncb() * N));
   p->n_partial = 4 * std::max(std::max(linearize_blocks(P), cost_blocks(N)), cost_blocks(6 * (int64_t)S + 3 * (int64_t)P)) + 16;
   BA_TRY(p->dalloc(&p->d_partial, (size_t)p->n_partial));
   BA_TRY(p->dalloc(&p->d_scal, (size_t)SC_COUNT));
@@ -355,6 +469,8 @@ struct LmState {
   double radius, lm_min, lm_max;
   bool reuse_diag;
   bool need_norms;  // column norms of the camera block are only needed when they are not clamped away
+  int reduced = 0;  // what to build after the elimination: 0 nothing, 1 preconditioner + border (implicit operator),
+                    // 2 explicit block-sparse system + border
 };
 
 StationArgs station_args(ba_problem *p, int voff, int stride) {
@@ -384,6 +500,8 @@ int camera_rows(ba_problem *p, int voff, double *out_cam) {
   return p->allreduce(out_cam, p->ncam, 0);
 }
 
+int build_reduced(ba_problem *p, bool explicit_blocks);
+
 // Residuals, Jacobians, point elimination, station blocks, gradient, reduced right-hand side.
 // Leaves cost in h_scal[SC_COST] (+ SC_FIXED) and the max-norm of the gradient in h_scal[SC_GMAX].
 int linearize(ba_problem *p, const LmState &st) {
@@ -395,6 +513,7 @@ int linearize(ba_problem *p, const LmState &st) {
   la.rec = p->d_rec; la.Jp = p->d_Jp; la.Jc = p->d_Jc; la.Mo = p->d_Mo; la.Vinv = p->d_Vinv; la.g_pt = p->d_g_pt;
   la.colnorm_pt = p->d_colnorm_pt; la.diag_pt = p->d_diag_pt; la.cost_partial = p->d_partial; la.flags = p->d_flags;
   la.huber_a = p->huber_a; la.lm_min = st.lm_min; la.lm_max = st.lm_max; la.radius = st.radius; la.reuse_diag = st.reuse_diag;
+  la.Y = (st.reduced == 2) ? p->d_Y : nullptr;
   launch_linearize(s, la);
   launch_sum_partials(s, p->d_partial, linearize_blocks(p->P), p->d_scal, SC_COST);
   BA_TRY(p->allreduce(p->d_scal + SC_COST, 1, 0));
@@ -408,7 +527,7 @@ int linearize(ba_problem *p, const LmState &st) {
   fa.S = p->S; fa.reuse_diag = st.reuse_diag; fa.sta_used = p->d_sta_used; fa.F = p->d_F;
   fa.lm_min = st.lm_min; fa.lm_max = st.lm_max; fa.radius = st.radius;
   fa.colnorm_sta = p->d_colnorm_sta; fa.diag_sta = p->d_diag_sta; fa.d2_sta = p->d_d2_sta; fa.g_sta = p->d_g; fa.b_sta = p->d_b;
-  fa.Minv = p->d_Minv; fa.flags = p->d_flags;
+  fa.Sdiag = p->d_Sdiag;
   launch_station_finish(s, fa);
   // camera rows of the gradient and of the reduced right-hand side
   if (p->ncam > 0) {
@@ -441,6 +560,7 @@ int linearize(ba_problem *p, const LmState &st) {
   } else {
     HIP_OK(hipMemsetAsync(p->d_scal + SC_GMAX, 0, sizeof(double), s));
   }
+  if (st.reduced) BA_TRY(build_reduced(p, st.reduced == 2));
   BA_TRY(p->check_kernels());
   BA_TRY(p->read_scal());
   p->h_scal[SC_GMAX] = std::max(p->h_scal[SC_GMAX], std::max(p->h_scal[SC_GMAX_P], p->h_scal[SC_GMAX_SC]));
@@ -475,15 +595,37 @@ int probe_column(ba_problem *p, int64_t k, double *out) {
   return 0;
 }
 
-// explicit camera border of the reduced matrix and the Cholesky factor of its camera block
-int build_border(ba_problem *p) {
-  if (p->ncam == 0) return 0;
+// What the reduced solve needs beyond the right-hand side: the 6x6 station blocks (inverted
+// for the block-Jacobi preconditioner), the dense camera border with its Cholesky factor and,
+// when explicit_blocks, the off-diagonal station blocks in BSR form.
+int build_reduced(ba_problem *p, bool explicit_blocks) {
   hipStream_t s = p->stream;
   const size_t ns = 6 * (size_t)p->S;
-  for (int k = 0; k < p->ncam; ++k) {
-    BA_TRY(probe_column(p, (int64_t)ns + k, p->d_q));
-    launch_copy(s, ns, p->d_q, p->d_Ssc + (size_t)k * ns);
-    launch_copy(s, p->ncam, p->d_q + ns, p->d_Scc + (size_t)k * p->ncam);
+  if (explicit_blocks) {
+    HIP_OK(hipMemsetAsync(p->d_bsr_val, 0, 36 * (size_t)p->n_bsr * sizeof(double), s));
+    launch_schur_blocks(s, p->n_ublk, p->d_ublk_cstart, p->d_ublk_dst, p->d_pairs, p->d_Y, p->d_bsr_val);
+    BA_TRY(p->allreduce(p->d_bsr_val, 36 * (int64_t)p->n_bsr, 0));
+    launch_bsr_add_diag(s, p->S, p->d_bsr_rowptr, p->d_Sdiag, p->d_bsr_val);
+    launch_invert_blocks(s, p->S, p->d_bsr_val, p->d_bsr_rowptr, p->d_sta_used, p->d_Minv, p->d_flags);
+  } else {
+    launch_invert_blocks(s, p->S, p->d_Sdiag, nullptr, p->d_sta_used, p->d_Minv, p->d_flags);
+  }
+  if (p->ncam == 0) return 0;
+  if (p->d_Jt) {
+    // one camera, few free parameters: the border comes out of one point sweep and one station sweep
+    launch_border_point(s, p->P, p->ncmax, p->d_pt_start, p->d_Jp, p->d_Jc, p->d_Vinv, p->d_Jt);
+    StationArgs sa = station_args(p, 6, border_nacc());
+    launch_border_station(s, sa, p->d_Jt);
+    launch_border_fold(s, p->S, p->ncam, p->n_chunks, p->d_sta_chunk0, p->d_part, border_nacc(), p->d_Ssc, p->d_corner);
+    BA_TRY(p->allreduce(p->d_Ssc, (int64_t)ns * p->ncam, 0));
+    BA_TRY(p->allreduce(p->d_corner, border_ncb() * (border_ncb() + 1) / 2, 0));
+    launch_border_corner(s, p->ncam, p->d_corner, p->d_diagfull + ns, p->d_Scc);
+  } else {
+    // general case: one pass of the implicit operator per camera column
+    for (int k = 0; k < p->ncam; ++k) {
+      BA_TRY(probe_column(p, (int64_t)ns + k, p->d_q));
+      launch_store_border_col(s, p->S, p->ncam, k, p->d_q, p->d_Ssc, p->d_Scc);
+    }
   }
   launch_copy(s, (int64_t)p->ncam * p->ncam, p->d_Scc, p->d_Lcc);
   launch_cholesky(s, p->d_Lcc, p->ncam, p->d_info);
@@ -494,10 +636,35 @@ int build_border(ba_problem *p) {
   return 0;
 }
 
+// PCG on the explicit block-sparse system: the whole iteration stays on the device, the host
+// only looks at the stopping flag once per batch.
+int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
+  hipStream_t s = p->stream;
+  BsrCgArgs a{};
+  a.S = p->S; a.ncam = p->ncam; a.rowptr = p->d_bsr_rowptr; a.col = p->d_bsr_col; a.val = p->d_bsr_val; a.Ssc = p->d_Ssc;
+  a.Scc = p->d_Scc; a.Lcc = p->d_Lcc; a.Minv = p->d_Minv; a.b = p->d_b; a.x = p->d_x; a.r = p->d_r; a.z = p->d_z; a.p = p->d_p;
+  a.q = p->d_q; a.scal = p->d_cg2scal; a.part_pq = p->d_part_pq; a.part_qc = p->d_part_qc; a.part_rz = p->d_part_rz;
+  launch_cg2_init(s, a, opt->pcg_rtol);
+  const int batch = 32;
+  int it = 0;
+  for (;;) {
+    HIP_OK(hipMemcpyAsync(p->h_cgscal, p->d_cg2scal, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    it = (int)p->h_cgscal[3];
+    if (p->h_cgscal[5] != 0.0 || it >= opt->pcg_max_iters) break;
+    const int n = std::min(batch, opt->pcg_max_iters - it);
+    for (int k = 0; k < n; ++k) launch_cg2_iteration(s, a, (it + k) & 1);
+  }
+  *iters = it;
+  BA_TRY(p->check_kernels());
+  if (p->h_cgscal[5] == 2.0) return fail(BA_ERR_NUMERIC, "PCG breakdown at iteration %d (p.Sp = %g)", it, p->h_cgscal[4]);
+  if (!std::isfinite(p->h_cgscal[2])) return fail(BA_ERR_NUMERIC, "PCG: non-finite right-hand side");
+  return 0;
+}
+
 // block-Jacobi preconditioned conjugate gradients on the reduced system; solution in d_x
 int solve_pcg(ba_problem *p, const ba_options *opt, int *iters) {
   hipStream_t s = p->stream;
-  BA_TRY(build_border(p));
   CgArgs ca{};
   ca.n = p->nr; ca.S = p->S; ca.ncam = p->ncam; ca.b = p->d_b; ca.Minv = p->d_Minv; ca.Lcc = p->d_Lcc; ca.Ssc = p->d_Ssc;
   ca.Scc = p->d_Scc; ca.d2_sta = p->d_d2_sta; ca.x = p->d_x; ca.r = p->d_r; ca.z = p->d_z; ca.p = p->d_p; ca.q = p->d_q;
@@ -534,15 +701,21 @@ int solve_pcg(ba_problem *p, const ba_options *opt, int *iters) {
   return p->check_kernels();
 }
 
-// dense reduced matrix (one implicit-operator probe per column), Cholesky on the matrix cores
-int solve_dense(ba_problem *p) {
+// dense reduced matrix (scattered from the block-sparse form, or one implicit-operator probe per
+// column when that form is not available), Cholesky on the matrix cores
+int solve_dense(ba_problem *p, bool explicit_blocks) {
   hipStream_t s = p->stream;
   const size_t nr = (size_t)p->nr;
   if (!p->d_Sdense) {
     if ((double)nr * nr * 8.0 > 64e9) return fail(BA_ERR_INVALID, "dense reduced system of order %zu does not fit; use the PCG solver", nr);
     BA_TRY(p->dalloc(&p->d_Sdense, nr * nr));
   }
-  for (size_t k = 0; k < nr; ++k) BA_TRY(probe_column(p, (int64_t)k, p->d_Sdense + k * nr));
+  if (explicit_blocks) {
+    HIP_OK(hipMemsetAsync(p->d_Sdense, 0, nr * nr * sizeof(double), s));
+    launch_bsr_to_dense(s, p->S, p->ncam, p->d_bsr_rowptr, p->d_bsr_col, p->d_bsr_val, p->d_Ssc, p->d_Scc, p->d_Sdense);
+  } else {
+    for (size_t k = 0; k < nr; ++k) BA_TRY(probe_column(p, (int64_t)k, p->d_Sdense + k * nr));
+  }
   launch_cholesky(s, p->d_Sdense, p->nr, p->d_info);
   launch_copy(s, p->nr, p->d_b, p->d_x);
   launch_chol_solve(s, p->d_Sdense, p->nr, p->d_x);
@@ -621,7 +794,7 @@ int init_scaling(ba_problem *p, const ba_options *opt) {
   if (p->C) HIP_OK(hipMemcpyAsync(p->d_cam, p->cam_h.data(), p->cam_h.size() * sizeof(CamRec), hipMemcpyHostToDevice, s));
   HIP_OK(hipStreamSynchronize(s));
   if (!opt->jacobi_scaling) return 0;
-  LmState st{opt->initial_trust_region_radius, opt->min_lm_diagonal, opt->max_lm_diagonal, false, true};
+  LmState st{opt->initial_trust_region_radius, opt->min_lm_diagonal, opt->max_lm_diagonal, false, true, 0};
   BA_TRY(linearize(p, st));
   launch_make_scale(s, 3 * (int64_t)p->P, p->d_colnorm_pt, p->d_scale_pt);
   launch_make_scale(s, 6 * (int64_t)p->S, p->d_colnorm_sta, p->d_scale_sta);
@@ -744,8 +917,10 @@ int ba_get_parameters(ba_problem *p, double *eop, double *xyz, double *iop, doub
 int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary, ba_iter_row *rows, int32_t rows_cap) {
   if (!p || !opt) return fail(BA_ERR_INVALID, "ba_solve_resident: null argument");
   if (!p->have_params) return fail(BA_ERR_INVALID, "ba_solve_resident: call ba_set_parameters first");
-  if (opt->linear_solver != BA_SOLVER_DENSE_SCHUR && opt->linear_solver != BA_SOLVER_PCG_SCHUR)
+  if (opt->linear_solver != BA_SOLVER_DENSE_SCHUR && opt->linear_solver != BA_SOLVER_PCG_SCHUR &&
+      opt->linear_solver != BA_SOLVER_PCG_IMPLICIT)
     return fail(BA_ERR_UNSUPPORTED, "linear_solver %d", opt->linear_solver);
+  const bool use_explicit = p->explicit_ok && opt->linear_solver != BA_SOLVER_PCG_IMPLICIT;
   if (!(opt->initial_trust_region_radius > 0.0)) return fail(BA_ERR_INVALID, "initial_trust_region_radius must be positive");
   const double t_begin = now_s();
   ba_summary sm;
@@ -753,7 +928,7 @@ int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary,
   fill_sizes(p, &sm);
   int n_rows = 0;
   LmState st{opt->initial_trust_region_radius, opt->min_lm_diagonal, opt->max_lm_diagonal, false,
-             opt->min_lm_diagonal != opt->max_lm_diagonal};
+             opt->min_lm_diagonal != opt->max_lm_diagonal, use_explicit ? 2 : 1};
   double decrease_factor = 2.0;
   int num_invalid = 0;
 
@@ -806,7 +981,10 @@ int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary,
       linearized_for_radius = true;
     }
     int lin_iters = 0;
-    int lrc = (opt->linear_solver == BA_SOLVER_PCG_SCHUR) ? solve_pcg(p, opt, &lin_iters) : solve_dense(p);
+    int lrc;
+    if (opt->linear_solver == BA_SOLVER_DENSE_SCHUR) lrc = solve_dense(p, use_explicit);
+    else if (use_explicit) lrc = solve_pcg_explicit(p, opt, &lin_iters);
+    else lrc = solve_pcg(p, opt, &lin_iters);
     it.linear_iterations = lin_iters;
     sm.total_linear_iterations += lin_iters;
     if (lrc != 0 && lrc != BA_ERR_NUMERIC) return lrc;
@@ -963,7 +1141,7 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
   ba_default_options(&opt);
   // a valid linearisation (scales, station records, Jacobians) for the kernels to run on
   BA_TRY(init_scaling(p, &opt));
-  LmState st{opt.initial_trust_region_radius, opt.min_lm_diagonal, opt.max_lm_diagonal, false, false};
+  LmState st{opt.initial_trust_region_radius, opt.min_lm_diagonal, opt.max_lm_diagonal, false, false, p->explicit_ok ? 2 : 1};
   BA_TRY(linearize(p, st));
   launch_copy(s, p->nr, p->d_b, p->d_p);
   LinArgs la{};
@@ -972,6 +1150,13 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
   la.rec = p->d_rec; la.Jp = p->d_Jp; la.Jc = p->d_Jc; la.Mo = p->d_Mo; la.Vinv = p->d_Vinv; la.g_pt = p->d_g_pt;
   la.colnorm_pt = p->d_colnorm_pt; la.diag_pt = p->d_diag_pt; la.cost_partial = p->d_partial; la.flags = p->d_flags;
   la.huber_a = p->huber_a; la.lm_min = st.lm_min; la.lm_max = st.lm_max; la.radius = st.radius; la.reuse_diag = 0;
+  la.Y = p->explicit_ok ? p->d_Y : nullptr;
+  BsrCgArgs ba{};
+  ba.S = p->S; ba.ncam = p->ncam; ba.rowptr = p->d_bsr_rowptr; ba.col = p->d_bsr_col; ba.val = p->d_bsr_val; ba.Ssc = p->d_Ssc;
+  ba.Scc = p->d_Scc; ba.Lcc = p->d_Lcc; ba.Minv = p->d_Minv; ba.b = p->d_b; ba.x = p->d_x; ba.r = p->d_r; ba.z = p->d_z; ba.p = p->d_p;
+  ba.q = p->d_q; ba.scal = p->d_cg2scal; ba.part_pq = p->d_part_pq; ba.part_qc = p->d_part_qc; ba.part_rz = p->d_part_rz;
+  if ((which == 4 || which == 5) && !p->explicit_ok) return fail(BA_ERR_INVALID, "ba_time_kernel: the block-sparse system was not built for this network");
+  if (which == 5) launch_cg2_init(s, ba, 0.0);
   PointArgs pa = point_args(p, p->d_p);
   StationArgs sa = station_args(p, 7, 6);
   CostArgs ca{};
@@ -986,10 +1171,12 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
       case 1: launch_point_pass(s, pa, MODE_APPLY, false); break;
       case 2: launch_station_pass(s, sa, SMODE_GATHER); break;
       case 3: launch_cost_obs(s, ca, cost_blocks(p->N)); break;
+      case 4: launch_schur_blocks(s, p->n_ublk, p->d_ublk_cstart, p->d_ublk_dst, p->d_pairs, p->d_Y, p->d_bsr_val); break;
+      case 5: launch_cg2_iteration(s, ba, 0); break;
       default: break;
     }
   };
-  if (which < 0 || which > 3) return fail(BA_ERR_INVALID, "ba_time_kernel: unknown kernel %d", which);
+  if (which < 0 || which > 5) return fail(BA_ERR_INVALID, "ba_time_kernel: unknown kernel %d", which);
   run();  // warm-up
   HIP_OK(hipEventRecord(e0, s));
   for (int k = 0; k < repeats; ++k) run();

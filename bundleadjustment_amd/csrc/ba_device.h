@@ -10,6 +10,7 @@
 //   Jp      [e]  6 doubles: row0(3), row1(3)
 //   Jc      [e]  2*ncmax doubles: row0(ncmax), row1(ncmax)  (free camera parameters only)
 //   Mo      [e]  3 doubles: I - Jp Vinv Jp^T (symmetric 2x2)
+//   Y       [e]  24 doubles: Js^T Jp L with Vinv = L L^T, 6 rows padded to 4 (block-sparse path only)
 // Jacobians in rec/Jp/Jc carry the robust-loss correction sqrt(rho') and the Jacobi column
 // scaling, i.e. they are rows of the matrix the trust-region step is computed from.
 #pragma once
@@ -20,6 +21,7 @@
 #define BA_OBS_STRIDE 8
 #define BA_STA_STRIDE 24
 #define BA_REC_STRIDE 16
+#define BA_Y_STRIDE 24  // 6 rows x (3 + 1 pad) doubles = 192 B = three 64-B sectors
 #define BA_NCAMPAR 19
 #define BA_APSCALE 1000.0  // src/main.cpp:55
 

@@ -19,6 +19,7 @@ struct LinArgs {
   const double *obs, *sta, *xyz, *scale_pt, *pt_prior, *pt_isig;
   const CamRec *cam;
   double *rec, *Jp, *Jc, *Mo, *Vinv, *g_pt, *colnorm_pt, *diag_pt, *cost_partial;
+  double *Y;  // may be null
   unsigned *flags;
   double huber_a, lm_min, lm_max, radius;
   int reuse_diag;
@@ -48,8 +49,7 @@ struct StationFinishArgs {
   const int *sta_used;
   const double *F;  // folded SMODE_SETUP sums, 39 per station
   double lm_min, lm_max, radius;
-  double *colnorm_sta, *diag_sta, *d2_sta, *g_sta, *b_sta, *Minv;
-  unsigned *flags;
+  double *colnorm_sta, *diag_sta, *d2_sta, *g_sta, *b_sta, *Sdiag;
 };
 
 struct CamFinishArgs {
@@ -98,6 +98,7 @@ void launch_camera_fold(hipStream_t s, int C, int n_chunks, const int *chunk_sta
 void launch_add_diag_entry(hipStream_t s, double *v, const double *diag, int64_t k);
 void launch_camera_prior_cost(hipStream_t s, int C, const CamRec *cam, double *out, int slot, int fixed_slot, double *res_out);
 void launch_station_finish(hipStream_t s, const StationFinishArgs &a);
+void launch_invert_blocks(hipStream_t s, int S, const double *src, const int *idx, const int *sta_used, double *Minv, unsigned *flags);
 int cost_blocks(int64_t n);
 void launch_cost_obs(hipStream_t s, const CostArgs &a, int blocks);
 void launch_cost_prior(hipStream_t s, int P, const double *xyz, const double *prior, const double *isig, const int *pt_file,
@@ -116,6 +117,31 @@ void launch_cg_step(hipStream_t s, const CgArgs &a);
 void launch_copy(hipStream_t s, int64_t n, const double *src, double *dst);
 void launch_unit(hipStream_t s, int64_t n, double *v, int64_t k);
 void launch_resjac_dense(hipStream_t s, const CostArgs &a, double *r_out, double *J_out);
+
+// ba_schur.hip: explicit block-sparse reduced system and PCG on it
+struct BsrCgArgs {
+  int S, ncam;
+  const int *rowptr, *col;
+  const double *val, *Ssc, *Scc, *Lcc, *Minv, *b;
+  double *x, *r, *z, *p, *q, *scal, *part_pq, *part_qc, *part_rz;
+};
+void launch_schur_blocks(hipStream_t s, int nu, const int *cstart, const int2 *dst, const int2 *pairs, const double *Y, double *val);
+void launch_bsr_add_diag(hipStream_t s, int S, const int *rowptr, const double *Sdiag, double *val);
+void launch_bsr_to_dense(hipStream_t s, int S, int ncam, const int *rowptr, const int *col, const double *val, const double *Ssc,
+                         const double *Scc, double *A);
+void launch_store_border_col(hipStream_t s, int S, int ncam, int k, const double *v, double *Ssc, double *Scc);
+int border_ncb();   // largest number of free camera parameters the explicit border kernels handle
+int border_nacc();  // partial sums per chunk of the border station sweep
+void launch_border_point(hipStream_t s, int P, int ncmax, const int *pt_start, const double *Jp, const double *Jc,
+                         const double *Vinv, double *Jt);
+void launch_border_station(hipStream_t s, const StationArgs &sa, const double *Jt);
+void launch_border_fold(hipStream_t s, int S, int ncam, int n_chunks, const int *sta_chunk0, const double *part, int stride,
+                        double *Ssc, double *corner);
+void launch_border_corner(hipStream_t s, int ncam, const double *corner, const double *camdiag, double *Scc);
+int cg2_blocks_spmv(int S);
+int cg2_blocks_vec(int S);
+void launch_cg2_init(hipStream_t s, const BsrCgArgs &a, double rtol);
+void launch_cg2_iteration(hipStream_t s, const BsrCgArgs &a, int parity);
 
 // ba_chol.hip: in-place lower Cholesky of a dense row-major n x n matrix (ld = n) and the
 // solve L L^T x = b (b overwritten).  info[0] != 0 after the factorisation when a pivot was

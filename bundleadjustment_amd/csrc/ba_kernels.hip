@@ -138,7 +138,11 @@ k_linearize(LinArgs a) {
     go[0] = g[0]; go[1] = g[1]; go[2] = g[2];
     double u0, u1, u2;
     sym3_mul(Vi, g[0], g[1], g[2], u0, u1, u2);
-    // second walk: M = I - Jp Vinv Jp^T and the reduced residual r - Jp Vinv g
+    // Vinv = L L^T (lower Cholesky), for the whitened coupling blocks Y = Js^T Jp L
+    const double l00 = sqrt(Vi[0]), l10 = Vi[1] / l00, l20 = Vi[2] / l00;
+    const double l11 = sqrt(Vi[3] - l10 * l10), l21 = (Vi[4] - l20 * l10) / l11;
+    const double l22 = sqrt(Vi[5] - l20 * l20 - l21 * l21);
+    // second walk: M = I - Jp Vinv Jp^T, the reduced residual r - Jp Vinv g, and Y
     for (int e = e0; e < e1; ++e) {
       const double2 *jp = reinterpret_cast<const double2 *>(a.Jp + 6 * (int64_t)e);
       const double2 q0 = jp[0], q1 = jp[1], q2 = jp[2];
@@ -153,6 +157,20 @@ k_linearize(LinArgs a) {
       double2 *rec = reinterpret_cast<double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
       const double2 r = rec[6];
       rec[7] = make_double2(r.x - (p0 * u0 + p1 * u1 + p2 * u2), r.y - (p3 * u0 + p4 * u1 + p5 * u2));
+      if (a.Y) {
+        // G = Jp L (2x3);  Y[r][m] = Js0[r] G0[m] + Js1[r] G1[m], rows padded to 4 doubles
+        const double g00 = p0 * l00 + p1 * l10 + p2 * l20, g01 = p1 * l11 + p2 * l21, g02 = p2 * l22;
+        const double g10 = p3 * l00 + p4 * l10 + p5 * l20, g11 = p4 * l11 + p5 * l21, g12 = p5 * l22;
+        double2 *yo = reinterpret_cast<double2 *>(a.Y + (int64_t)BA_Y_STRIDE * e);
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+          const double2 ja = rec[h], jb = rec[3 + h];  // Js row 0 and row 1, columns 2h, 2h+1
+          yo[4 * h] = make_double2(ja.x * g00 + jb.x * g10, ja.x * g01 + jb.x * g11);
+          yo[4 * h + 1] = make_double2(ja.x * g02 + jb.x * g12, 0.0);
+          yo[4 * h + 2] = make_double2(ja.y * g00 + jb.y * g10, ja.y * g01 + jb.y * g11);
+          yo[4 * h + 3] = make_double2(ja.y * g02 + jb.y * g12, 0.0);
+        }
+      }
     }
   }
   const double t = block_sum(cost, lds);
@@ -360,8 +378,8 @@ __global__ void k_add_diag_entry(double *__restrict__ v, const double *__restric
   if (blockIdx.x == 0 && threadIdx.x == 0) v[k] += diag[k];
 }
 
-// After SMODE_SETUP and the fold: per station, add the LM diagonal, invert the 6x6
-// preconditioner block, and emit gradient / rhs / column norms.
+// After SMODE_SETUP and the fold: per station, add the LM diagonal, emit the diagonal block of
+// the reduced matrix, gradient, rhs and column norms.
 __global__ void k_station_finish(StationFinishArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.S) return;
@@ -386,21 +404,35 @@ __global__ void k_station_finish(StationFinishArgs a) {
     a.g_sta[6 * (int64_t)i + k] = acc[27 + k];
     a.b_sta[6 * (int64_t)i + k] = used ? acc[33 + k] : 0.0;
   }
-  // symmetric 6x6 from its upper triangle, Cholesky, inverse
-  double A[6][6];
+  // symmetric 6x6 diagonal block of the reduced matrix: sum Js^T M Js + LM diagonal
+  double *sd = a.Sdiag + 36 * (int64_t)i;
   {
     int idx = 0;
 #pragma unroll
     for (int p = 0; p < 6; ++p)
 #pragma unroll
       for (int q = p; q < 6; ++q) {
-        A[p][q] = acc[idx];
-        A[q][p] = acc[idx];
+        const double v = acc[idx] + (p == q ? d2[p] : 0.0);
+        sd[6 * p + q] = v;
+        sd[6 * q + p] = v;
         ++idx;
       }
   }
+}
+
+// Inverse of the 6x6 diagonal blocks (block-Jacobi preconditioner).  Block i is read at
+// src + 36 * (idx ? idx[i] : i).  Stations without observations get a zero block.
+__global__ void k_invert_blocks(int S, const double *__restrict__ src, const int *__restrict__ idx,
+                                const int *__restrict__ sta_used, double *__restrict__ Minv, unsigned *flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S) return;
+  const double *sp = src + 36 * (int64_t)(idx ? idx[i] : i);
+  double A[6][6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) A[k][k] += d2[k];
+  for (int p = 0; p < 6; ++p)
+#pragma unroll
+    for (int q = 0; q < 6; ++q) A[p][q] = sp[6 * p + q];
+  const bool used = sta_used[i] != 0;
   double L[6][6];
   bool ok = used;
 #pragma unroll
@@ -423,11 +455,11 @@ __global__ void k_station_finish(StationFinishArgs a) {
         L[r][j] = s * il;
       }
   }
-  double *mi = a.Minv + 36 * (int64_t)i;
+  double *mi = Minv + 36 * (int64_t)i;
   if (!ok) {
 #pragma unroll
     for (int k = 0; k < 36; ++k) mi[k] = 0.0;
-    if (used) atomicOr(a.flags, 2);
+    if (used) atomicOr(flags, 2);
     return;
   }
   // inverse column by column: solve L L^T x = e_c
@@ -776,13 +808,12 @@ k_cg_step(CgArgs a) {
   // LM diagonal of the station columns (the implicit operator carries only Js^T M Js)
   for (int t = threadIdx.x; t < ns; t += blockDim.x) a.q[t] += a.d2_sta[t] * a.p[t];
   __syncthreads();
-  // border:  q_s += Ssc p_c ;  q_c = Ssc^T p_s + Scc p_c      (Ssc column-major [ns x nc])
+  // border:  q_s += Ssc p_c ;  q_c = Ssc^T p_s + Scc p_c      (Ssc row-major [ns x nc])
   if (nc > 0) {
     const double *pc = a.p + ns;
     for (int k = 0; k < nc; ++k) {
-      const double *col = a.Ssc + (int64_t)k * ns;
       double s = 0.0;
-      for (int t = threadIdx.x; t < ns; t += blockDim.x) s += col[t] * a.p[t];
+      for (int t = threadIdx.x; t < ns; t += blockDim.x) s += a.Ssc[(int64_t)t * nc + k] * a.p[t];
       const double d = block_sum(s, lds);
       if (threadIdx.x == 0) {
         double v = d;
@@ -792,7 +823,7 @@ k_cg_step(CgArgs a) {
     }
     for (int t = threadIdx.x; t < ns; t += blockDim.x) {
       double s = a.q[t];
-      for (int k = 0; k < nc; ++k) s += a.Ssc[(int64_t)k * ns + t] * pc[k];
+      for (int k = 0; k < nc; ++k) s += a.Ssc[(int64_t)t * nc + k] * pc[k];
       a.q[t] = s;
     }
     __syncthreads();
@@ -902,6 +933,9 @@ void launch_camera_prior_cost(hipStream_t s, int C, const CamRec *cam, double *o
 }
 void launch_station_finish(hipStream_t s, const StationFinishArgs &a) {
   if (a.S > 0) hipLaunchKernelGGL(k_station_finish, dim3(nblk(a.S, 64)), dim3(64), 0, s, a);
+}
+void launch_invert_blocks(hipStream_t s, int S, const double *src, const int *idx, const int *sta_used, double *Minv, unsigned *flags) {
+  if (S > 0) hipLaunchKernelGGL(k_invert_blocks, dim3(nblk(S, 64)), dim3(64), 0, s, S, src, idx, sta_used, Minv, flags);
 }
 int cost_blocks(int64_t n) {
   const int b = nblk(n, 256);

@@ -1,0 +1,504 @@
+// ba_schur.hip -- the reduced camera system in explicit block-sparse form, and PCG on it.
+//
+// After the point blocks are eliminated, the station part of the reduced matrix is
+//   S_ii'  =  [i == i'] (sum_a Js_a^T M_a Js_a + D^2)  -  sum_{points seen by i and i'} Y_a Y_b^T ,
+// with Y = Js^T Jp L (6x3 per observation, V^-1 = L L^T) written by the linearisation kernel.
+// The 6x6 blocks are stored in BSR form (row = station, diagonal block first, neighbours by
+// ascending column).  Which observation pairs feed which block is fixed by the network and is
+// prepared once on the host: the pair list is sorted by block, so every block is summed by ONE
+// wave in a fixed order -- no atomics, bitwise reproducible.
+// The camera (IOP/AP) columns are a dense border [S x 6 x ncam] plus an ncam x ncam corner.
+// PCG then runs entirely on this explicit system: one SpMV kernel and two vector kernels per
+// iteration, all multi-workgroup; the scalars (alpha, beta, stopping test) never leave the device.
+#include "ba_kernels.h"
+
+#include "ba_device.h"
+
+namespace ba {
+
+// ------------------------------------------------------------------------------------------
+// assembly
+// ------------------------------------------------------------------------------------------
+// One wave per upper-triangular block u (lo <= hi).  Lane (r,c), r = lane/6, c = lane%6 (36 of 64
+// lanes) owns one entry and walks the block's pair list.
+__global__ void __launch_bounds__(256)
+k_schur_blocks(int nu, const int *__restrict__ cstart, const int2 *__restrict__ dst, const int2 *__restrict__ pairs,
+               const double *__restrict__ Y, double *__restrict__ val) {
+  const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (u >= nu || lane >= 36) return;
+  const int r = lane / 6, c = lane - 6 * r;
+  const int q0 = cstart[u], q1 = cstart[u + 1];
+  double acc0 = 0.0, acc1 = 0.0;
+  int q = q0;
+  for (; q + 1 < q1; q += 2) {
+    const int2 pa = pairs[q], pb = pairs[q + 1];
+    const double2 *ya = reinterpret_cast<const double2 *>(Y + (int64_t)BA_Y_STRIDE * pa.x + 4 * r);
+    const double2 *yb = reinterpret_cast<const double2 *>(Y + (int64_t)BA_Y_STRIDE * pa.y + 4 * c);
+    const double2 *yc = reinterpret_cast<const double2 *>(Y + (int64_t)BA_Y_STRIDE * pb.x + 4 * r);
+    const double2 *yd = reinterpret_cast<const double2 *>(Y + (int64_t)BA_Y_STRIDE * pb.y + 4 * c);
+    const double2 a0 = ya[0], a1 = ya[1], b0 = yb[0], b1 = yb[1];
+    const double2 c0 = yc[0], c1 = yc[1], d0 = yd[0], d1 = yd[1];
+    acc0 += a0.x * b0.x + a0.y * b0.y + a1.x * b1.x;
+    acc1 += c0.x * d0.x + c0.y * d0.y + c1.x * d1.x;
+  }
+  if (q < q1) {
+    const int2 pa = pairs[q];
+    const double2 *ya = reinterpret_cast<const double2 *>(Y + (int64_t)BA_Y_STRIDE * pa.x + 4 * r);
+    const double2 *yb = reinterpret_cast<const double2 *>(Y + (int64_t)BA_Y_STRIDE * pa.y + 4 * c);
+    const double2 a0 = ya[0], a1 = ya[1], b0 = yb[0], b1 = yb[1];
+    acc0 += a0.x * b0.x + a0.y * b0.y + a1.x * b1.x;
+  }
+  const double v = -(acc0 + acc1);
+  const int2 d = dst[u];
+  val[36 * (int64_t)d.x + 6 * r + c] = v;
+  if (d.y >= 0) val[36 * (int64_t)d.y + 6 * c + r] = v;  // the mirrored block (hi, lo)
+}
+
+// diagonal blocks: val[row i, first block] += Sdiag[i]
+__global__ void k_bsr_add_diag(int S, const int *__restrict__ rowptr, const double *__restrict__ Sdiag, double *__restrict__ val) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= 36 * (int64_t)S) return;
+  const int i = (int)(t / 36), k = (int)(t - 36 * (int64_t)i);
+  val[36 * (int64_t)rowptr[i] + k] += Sdiag[t];
+}
+
+// dense copy of the explicit system for the Cholesky path: A is nr x nr, row-major
+__global__ void k_bsr_to_dense(int S, int ncam, const int *__restrict__ rowptr, const int *__restrict__ col,
+                               const double *__restrict__ val, const double *__restrict__ Ssc, const double *__restrict__ Scc,
+                               double *__restrict__ A) {
+  const int i = blockIdx.x;
+  const int64_t nr = 6 * (int64_t)S + ncam;
+  if (i < S) {
+    for (int b = rowptr[i]; b < rowptr[i + 1]; ++b) {
+      const int j = col[b];
+      for (int t = threadIdx.x; t < 36; t += blockDim.x) A[(6 * (int64_t)i + t / 6) * nr + 6 * j + t % 6] = val[36 * (int64_t)b + t];
+    }
+    for (int t = threadIdx.x; t < 6 * ncam; t += blockDim.x) {
+      const int r = t / ncam, k = t - r * ncam;
+      const double v = Ssc[(6 * (int64_t)i + r) * ncam + k];
+      A[(6 * (int64_t)i + r) * nr + 6 * S + k] = v;
+      A[(6 * (int64_t)S + k) * nr + 6 * i + r] = v;
+    }
+  } else {
+    for (int t = threadIdx.x; t < ncam * ncam; t += blockDim.x)
+      A[(6 * (int64_t)S + t / ncam) * nr + 6 * S + t % ncam] = Scc[t];
+  }
+}
+
+// border column k from a probe result v (6S + ncam): Ssc[., k] and Scc[k, .]
+__global__ void k_store_border_col(int S, int ncam, int k, const double *__restrict__ v, double *__restrict__ Ssc,
+                                   double *__restrict__ Scc) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t ns = 6 * (int64_t)S;
+  if (t < ns) Ssc[t * ncam + k] = v[t];
+  else if (t < ns + ncam) Scc[(int64_t)k * ncam + (t - ns)] = v[t];
+}
+
+// ------------------------------------------------------------------------------------------
+// explicit border for one camera with at most 8 free parameters
+// ------------------------------------------------------------------------------------------
+// Point sweep: B = sum_a Jc_a^T Jp_a (nc x 3), Z = V^-1 B^T, then per observation the projected
+// camera Jacobian  Jt_a = Jc_a - Jp_a Z  (2 x nc).
+#define NCB 8
+__global__ void __launch_bounds__(256)
+k_border_point(int P, int ncmax, const int *__restrict__ pt_start, const double *__restrict__ Jp, const double *__restrict__ Jc,
+               const double *__restrict__ Vinv, double *__restrict__ Jt) {
+  const int jj = blockIdx.x * blockDim.x + threadIdx.x;
+  if (jj >= P) return;
+  const int e0 = pt_start[jj], e1 = pt_start[jj + 1];
+  double B[NCB][3];
+#pragma unroll
+  for (int k = 0; k < NCB; ++k) B[k][0] = B[k][1] = B[k][2] = 0.0;
+  for (int e = e0; e < e1; ++e) {
+    const double *jp = Jp + 6 * (int64_t)e, *jc = Jc + 2 * (int64_t)ncmax * e;
+    const double p0 = jp[0], p1 = jp[1], p2 = jp[2], p3 = jp[3], p4 = jp[4], p5 = jp[5];
+#pragma unroll
+    for (int k = 0; k < NCB; ++k)
+      if (k < ncmax) {
+        const double c0 = jc[k], c1 = jc[ncmax + k];
+        B[k][0] += c0 * p0 + c1 * p3;
+        B[k][1] += c0 * p1 + c1 * p4;
+        B[k][2] += c0 * p2 + c1 * p5;
+      }
+  }
+  const double *vi = Vinv + 6 * (int64_t)jj;
+  const double Vi[6] = {vi[0], vi[1], vi[2], vi[3], vi[4], vi[5]};
+  double Z[NCB][3];
+#pragma unroll
+  for (int k = 0; k < NCB; ++k) sym3_mul(Vi, B[k][0], B[k][1], B[k][2], Z[k][0], Z[k][1], Z[k][2]);
+  for (int e = e0; e < e1; ++e) {
+    const double *jp = Jp + 6 * (int64_t)e, *jc = Jc + 2 * (int64_t)ncmax * e;
+    double *jt = Jt + 2 * (int64_t)NCB * e;
+    const double p0 = jp[0], p1 = jp[1], p2 = jp[2], p3 = jp[3], p4 = jp[4], p5 = jp[5];
+#pragma unroll
+    for (int k = 0; k < NCB; ++k) {
+      double t0 = 0.0, t1 = 0.0;
+      if (k < ncmax) {
+        t0 = jc[k] - (p0 * Z[k][0] + p1 * Z[k][1] + p2 * Z[k][2]);
+        t1 = jc[ncmax + k] - (p3 * Z[k][0] + p4 * Z[k][1] + p5 * Z[k][2]);
+      }
+      jt[k] = t0;
+      jt[NCB + k] = t1;
+    }
+  }
+}
+
+// Station sweep over the chunks: out[chunk][0..6*NCB) = sum Js^T Jt (6 x nc), then the upper
+// triangle of sum Jc^T Jt (nc x nc, symmetric) in out[chunk][6*NCB .. 6*NCB + NCB*(NCB+1)/2).
+#define NBORDER (6 * NCB + NCB * (NCB + 1) / 2)
+__global__ void __launch_bounds__(256)
+k_border_station(StationArgs a, const double *__restrict__ Jt) {
+  __shared__ double lds[4 * NBORDER];
+  const int ch = blockIdx.x;
+  const int b0 = a.chunk_begin[ch], b1 = a.chunk_begin[ch + 1];
+  double acc[NBORDER];
+#pragma unroll
+  for (int k = 0; k < NBORDER; ++k) acc[k] = 0.0;
+  for (int q = b0 + threadIdx.x; q < b1; q += blockDim.x) {
+    const int e = a.sta_list[q];
+    const double2 *rec = reinterpret_cast<const double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
+    double r0[6], r1[6];
+    {
+      const double2 j0 = rec[0], j1 = rec[1], j2 = rec[2], j3 = rec[3], j4 = rec[4], j5 = rec[5];
+      r0[0] = j0.x; r0[1] = j0.y; r0[2] = j1.x; r0[3] = j1.y; r0[4] = j2.x; r0[5] = j2.y;
+      r1[0] = j3.x; r1[1] = j3.y; r1[2] = j4.x; r1[3] = j4.y; r1[4] = j5.x; r1[5] = j5.y;
+    }
+    const double *jt = Jt + 2 * (int64_t)NCB * e, *jc = a.Jc + 2 * (int64_t)a.ncmax * e;
+    double t0[NCB], t1[NCB], c0[NCB], c1[NCB];
+#pragma unroll
+    for (int k = 0; k < NCB; ++k) {
+      t0[k] = jt[k];
+      t1[k] = jt[NCB + k];
+      c0[k] = (k < a.ncmax) ? jc[k] : 0.0;
+      c1[k] = (k < a.ncmax) ? jc[a.ncmax + k] : 0.0;
+    }
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+      for (int k = 0; k < NCB; ++k) acc[p * NCB + k] += r0[p] * t0[k] + r1[p] * t1[k];
+    int idx = 6 * NCB;
+#pragma unroll
+    for (int k = 0; k < NCB; ++k)
+#pragma unroll
+      for (int m = k; m < NCB; ++m) acc[idx++] += c0[k] * t0[m] + c1[k] * t1[m];
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NBORDER; ++k) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) lds[w * NBORDER + k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NBORDER) {
+    const int k = threadIdx.x;
+    a.out[(int64_t)a.out_stride * ch + k] = lds[k] + lds[NBORDER + k] + lds[2 * NBORDER + k] + lds[3 * NBORDER + k];
+  }
+}
+
+// fold the border chunks: Ssc[i][r][k] (row-major, ncam columns) and the raw corner sums
+__global__ void __launch_bounds__(256)
+k_border_fold(int S, int ncam, int n_chunks, const int *__restrict__ sta_chunk0, const double *__restrict__ part, int stride,
+              double *__restrict__ Ssc, double *__restrict__ corner /* NCB*(NCB+1)/2 */) {
+  __shared__ double lds[8];
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t < 6 * (int64_t)S * ncam) {
+    const int i = (int)(t / (6 * ncam));
+    const int rem = (int)(t - (int64_t)i * 6 * ncam), r = rem / ncam, k = rem - r * ncam;
+    double s = 0.0;
+    for (int ch = sta_chunk0[i]; ch < sta_chunk0[i + 1]; ++ch) s += part[(int64_t)stride * ch + r * NCB + k];
+    Ssc[t] = s;
+  }
+  if (blockIdx.x == 0) {
+    for (int m = 0; m < NCB * (NCB + 1) / 2; ++m) {
+      double s = 0.0;
+      for (int ch = threadIdx.x; ch < n_chunks; ch += blockDim.x) s += part[(int64_t)stride * ch + 6 * NCB + m];
+      const double v = block_sum(s, lds);
+      if (threadIdx.x == 0) corner[m] = v;
+    }
+  }
+}
+
+// Scc (ncam x ncam, symmetric, row-major) from the folded upper triangle plus prior + LM diagonal
+__global__ void k_border_corner(int ncam, const double *__restrict__ corner, const double *__restrict__ camdiag,
+                                double *__restrict__ Scc) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int idx = 0;
+  for (int k = 0; k < NCB; ++k)
+    for (int m = k; m < NCB; ++m) {
+      if (k < ncam && m < ncam) {
+        const double v = corner[idx] + (k == m ? camdiag[k] : 0.0);
+        Scc[k * ncam + m] = v;
+        Scc[m * ncam + k] = v;
+      }
+      ++idx;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// PCG on the explicit system
+// ------------------------------------------------------------------------------------------
+// scal: [0],[1] r.z (double-buffered by iteration parity), [2] initial r.z, [3] iterations done,
+//       [4] last p.Sp, [5] done flag (1 converged, 2 breakdown), [6] target sqrt(r.z)
+// q = S p for station rows (one wave per row) with per-workgroup partials of p.q and of the
+// camera rows Ssc^T p.
+__global__ void __launch_bounds__(256)
+k_bsr_spmv(BsrCgArgs a) {
+  __shared__ double lds_pq[4];
+  __shared__ double lds_qc[4][80];
+  if (a.scal[5] != 0.0) return;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + w;
+  const int g = lane >> 3, r = lane & 7;
+  double s = 0.0;
+  if (i < a.S && r < 6) {
+    for (int b = a.rowptr[i] + g; b < a.rowptr[i + 1]; b += 8) {
+      const double2 *B = reinterpret_cast<const double2 *>(a.val + 36 * (int64_t)b + 6 * r);
+      const double2 *pc = reinterpret_cast<const double2 *>(a.p + 6 * (int64_t)a.col[b]);
+      const double2 b0 = B[0], b1 = B[1], b2 = B[2], p0 = pc[0], p1 = pc[1], p2 = pc[2];
+      s += b0.x * p0.x + b0.y * p0.y + b1.x * p1.x + b1.y * p1.y + b2.x * p2.x + b2.y * p2.y;
+    }
+  }
+  s += __shfl_xor(s, 8, 64);
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  double pq = 0.0;
+  if (i < a.S && lane < 6) {
+    const double *pcam = a.p + 6 * (int64_t)a.S;
+    const double *row = a.Ssc + (6 * (int64_t)i + lane) * a.ncam;
+    for (int k = 0; k < a.ncam; ++k) s += row[k] * pcam[k];
+    a.q[6 * (int64_t)i + lane] = s;
+    pq = s * a.p[6 * (int64_t)i + lane];
+  }
+  pq = wave_sum(pq);
+  if (lane == 0) lds_pq[w] = pq;
+  // camera rows: t_k = sum_r Ssc[i][r][k] p_i[r]
+  for (int k = lane; k < a.ncam; k += 64) {
+    double t = 0.0;
+    if (i < a.S) {
+      const double *pi = a.p + 6 * (int64_t)i;
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) t += a.Ssc[(6 * (int64_t)i + rr) * a.ncam + k] * pi[rr];
+    }
+    lds_qc[w][k] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) a.part_pq[blockIdx.x] = lds_pq[0] + lds_pq[1] + lds_pq[2] + lds_pq[3];
+  for (int k = threadIdx.x; k < a.ncam; k += blockDim.x)
+    a.part_qc[(int64_t)blockIdx.x * a.ncam + k] = lds_qc[0][k] + lds_qc[1][k] + lds_qc[2][k] + lds_qc[3][k];
+}
+
+// camera part of z = M^-1 r with the dense Cholesky factor of the corner (one thread)
+__device__ void cam_precond(int n, const double *__restrict__ L, const double *__restrict__ rc, double *__restrict__ zc) {
+  for (int i = 0; i < n; ++i) {
+    double s = rc[i];
+    for (int k = 0; k < i; ++k) s -= L[i * n + k] * zc[k];
+    zc[i] = s / L[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = zc[i];
+    for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * zc[k];
+    zc[i] = s / L[i * n + i];
+  }
+}
+
+// thread per station: z_i = Minv_i r_i; returns r_i . z_i
+__device__ __forceinline__ double station_precond(const double *__restrict__ Minv, const double *__restrict__ r,
+                                                  double *__restrict__ z, int i) {
+  const double *m = Minv + 36 * (int64_t)i, *ri = r + 6 * (int64_t)i;
+  const double r0 = ri[0], r1 = ri[1], r2 = ri[2], r3 = ri[3], r4 = ri[4], r5 = ri[5];
+  double dot = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double v = m[6 * k] * r0 + m[6 * k + 1] * r1 + m[6 * k + 2] * r2 + m[6 * k + 3] * r3 + m[6 * k + 4] * r4 + m[6 * k + 5] * r5;
+    z[6 * (int64_t)i + k] = v;
+    dot += v * ri[k];
+  }
+  return dot;
+}
+
+// x = 0, r = b, z = M^-1 r, p = z; per-workgroup partials of r.z
+__global__ void __launch_bounds__(256)
+k_cg2_init(BsrCgArgs a) {
+  __shared__ double lds[8];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double dot = 0.0;
+  if (i < a.S) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      a.x[6 * (int64_t)i + k] = 0.0;
+      a.r[6 * (int64_t)i + k] = a.b[6 * (int64_t)i + k];
+    }
+    dot = station_precond(a.Minv, a.r, a.z, i);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a.p[6 * (int64_t)i + k] = a.z[6 * (int64_t)i + k];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.ncam > 0) {
+    const int64_t o = 6 * (int64_t)a.S;
+    for (int k = 0; k < a.ncam; ++k) {
+      a.x[o + k] = 0.0;
+      a.r[o + k] = a.b[o + k];
+    }
+    cam_precond(a.ncam, a.Lcc, a.r + o, a.z + o);
+    for (int k = 0; k < a.ncam; ++k) {
+      a.p[o + k] = a.z[o + k];
+      dot += a.r[o + k] * a.z[o + k];
+    }
+  }
+  const double t = block_sum(dot, lds);
+  if (threadIdx.x == 0) a.part_rz[blockIdx.x] = t;
+}
+
+// sums the initial r.z partials; sets the stopping target
+__global__ void __launch_bounds__(256)
+k_cg2_init_finish(BsrCgArgs a, int nblk, double rtol) {
+  __shared__ double lds[8];
+  double s = 0.0;
+  for (int k = threadIdx.x; k < nblk; k += blockDim.x) s += a.part_rz[k];
+  const double t = block_sum(s, lds);
+  if (threadIdx.x == 0) {
+    a.scal[0] = t;
+    a.scal[1] = t;
+    a.scal[2] = t;
+    a.scal[3] = 0.0;
+    a.scal[4] = 0.0;
+    a.scal[5] = (t > 0.0) ? 0.0 : 1.0;
+    a.scal[6] = rtol * sqrt(fmax(t, 0.0));
+  }
+}
+
+// alpha = r.z / p.Sp; x += alpha p; r -= alpha q; z = M^-1 r; partials of the new r.z
+__global__ void __launch_bounds__(256)
+k_cg2_update1(BsrCgArgs a, int parity, int nblk_spmv) {
+  __shared__ double lds[8];
+  __shared__ double qc_s[80];
+  __shared__ double pq_s;
+  if (a.scal[5] != 0.0) return;
+  // every workgroup folds the SpMV partials in the same order -> identical alpha everywhere
+  double s = 0.0;
+  for (int k = threadIdx.x; k < nblk_spmv; k += blockDim.x) s += a.part_pq[k];
+  double pq = block_sum(s, lds);
+  const int64_t o = 6 * (int64_t)a.S;
+  for (int k = 0; k < a.ncam; ++k) {
+    double t = 0.0;
+    for (int m = threadIdx.x; m < nblk_spmv; m += blockDim.x) t += a.part_qc[(int64_t)m * a.ncam + k];
+    const double v = block_sum(t, lds);
+    if (threadIdx.x == 0) {
+      double qk = v;
+      for (int m = 0; m < a.ncam; ++m) qk += a.Scc[k * a.ncam + m] * a.p[o + m];
+      qc_s[k] = qk;
+      pq += qk * a.p[o + k];
+    }
+  }
+  if (threadIdx.x == 0) pq_s = pq;
+  __syncthreads();
+  pq = pq_s;
+  const double rz = a.scal[parity];
+  const double alpha = rz / pq;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double dot = 0.0;
+  if (i < a.S) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      a.x[6 * (int64_t)i + k] += alpha * a.p[6 * (int64_t)i + k];
+      a.r[6 * (int64_t)i + k] -= alpha * a.q[6 * (int64_t)i + k];
+    }
+    dot = station_precond(a.Minv, a.r, a.z, i);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int k = 0; k < a.ncam; ++k) {
+      a.x[o + k] += alpha * a.p[o + k];
+      a.r[o + k] -= alpha * qc_s[k];
+    }
+    if (a.ncam > 0) cam_precond(a.ncam, a.Lcc, a.r + o, a.z + o);
+    for (int k = 0; k < a.ncam; ++k) dot += a.r[o + k] * a.z[o + k];
+    a.scal[4] = pq;
+  }
+  const double t = block_sum(dot, lds);
+  if (threadIdx.x == 0) a.part_rz[blockIdx.x] = t;
+}
+
+// beta = r.z(new) / r.z(old); p = z + beta p; stopping test
+__global__ void __launch_bounds__(256)
+k_cg2_update2(BsrCgArgs a, int parity, int nblk) {
+  __shared__ double lds[8];
+  __shared__ double rzn_s;
+  if (a.scal[5] != 0.0) return;
+  double s = 0.0;
+  for (int k = threadIdx.x; k < nblk; k += blockDim.x) s += a.part_rz[k];
+  const double t = block_sum(s, lds);
+  if (threadIdx.x == 0) rzn_s = t;
+  __syncthreads();
+  const double rzn = rzn_s, rz = a.scal[parity];
+  const double beta = rzn / rz;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < a.S) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a.p[6 * (int64_t)i + k] = a.z[6 * (int64_t)i + k] + beta * a.p[6 * (int64_t)i + k];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t o = 6 * (int64_t)a.S;
+    for (int k = 0; k < a.ncam; ++k) a.p[o + k] = a.z[o + k] + beta * a.p[o + k];
+    a.scal[parity ^ 1] = rzn;
+    a.scal[3] += 1.0;
+  }
+}
+
+// runs after update2 of the same iteration: reads what update2 published, sets the done flag.
+// (a separate tiny kernel so that no workgroup of update2 can see the flag change under it)
+__global__ void k_cg2_test(BsrCgArgs a, int parity) {
+  if (blockIdx.x != 0 || threadIdx.x != 0 || a.scal[5] != 0.0) return;
+  const double rzn = a.scal[parity ^ 1], pq = a.scal[4];
+  if (!(pq > 0.0) || !(rzn == rzn)) a.scal[5] = 2.0;
+  else if (sqrt(fmax(rzn, 0.0)) <= a.scal[6]) a.scal[5] = 1.0;
+}
+
+// ------------------------------------------------------------------------------------------
+static inline int nblk(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
+
+void launch_schur_blocks(hipStream_t s, int nu, const int *cstart, const int2 *dst, const int2 *pairs, const double *Y, double *val) {
+  if (nu > 0) hipLaunchKernelGGL(k_schur_blocks, dim3(nblk(nu, 4)), dim3(256), 0, s, nu, cstart, dst, pairs, Y, val);
+}
+void launch_bsr_add_diag(hipStream_t s, int S, const int *rowptr, const double *Sdiag, double *val) {
+  if (S > 0) hipLaunchKernelGGL(k_bsr_add_diag, dim3(nblk(36 * (int64_t)S, 256)), dim3(256), 0, s, S, rowptr, Sdiag, val);
+}
+void launch_bsr_to_dense(hipStream_t s, int S, int ncam, const int *rowptr, const int *col, const double *val, const double *Ssc,
+                         const double *Scc, double *A) {
+  hipLaunchKernelGGL(k_bsr_to_dense, dim3(S + 1), dim3(64), 0, s, S, ncam, rowptr, col, val, Ssc, Scc, A);
+}
+void launch_store_border_col(hipStream_t s, int S, int ncam, int k, const double *v, double *Ssc, double *Scc) {
+  hipLaunchKernelGGL(k_store_border_col, dim3(nblk(6 * (int64_t)S + ncam, 256)), dim3(256), 0, s, S, ncam, k, v, Ssc, Scc);
+}
+int border_ncb() { return NCB; }
+int border_nacc() { return NBORDER; }
+void launch_border_point(hipStream_t s, int P, int ncmax, const int *pt_start, const double *Jp, const double *Jc,
+                         const double *Vinv, double *Jt) {
+  if (P > 0) hipLaunchKernelGGL(k_border_point, dim3(nblk(P, 256)), dim3(256), 0, s, P, ncmax, pt_start, Jp, Jc, Vinv, Jt);
+}
+void launch_border_station(hipStream_t s, const StationArgs &sa, const double *Jt) {
+  if (sa.n_chunks > 0) hipLaunchKernelGGL(k_border_station, dim3(sa.n_chunks), dim3(256), 0, s, sa, Jt);
+}
+void launch_border_fold(hipStream_t s, int S, int ncam, int n_chunks, const int *sta_chunk0, const double *part, int stride,
+                        double *Ssc, double *corner) {
+  const int nb = nblk(6 * (int64_t)S * ncam, 256);
+  hipLaunchKernelGGL(k_border_fold, dim3(nb > 0 ? nb : 1), dim3(256), 0, s, S, ncam, n_chunks, sta_chunk0, part, stride, Ssc, corner);
+}
+void launch_border_corner(hipStream_t s, int ncam, const double *corner, const double *camdiag, double *Scc) {
+  hipLaunchKernelGGL(k_border_corner, dim3(1), dim3(1), 0, s, ncam, corner, camdiag, Scc);
+}
+int cg2_blocks_spmv(int S) { return nblk(S, 4); }
+int cg2_blocks_vec(int S) { return nblk(S, 256) > 0 ? nblk(S, 256) : 1; }
+void launch_cg2_init(hipStream_t s, const BsrCgArgs &a, double rtol) {
+  const int nb = cg2_blocks_vec(a.S);
+  hipLaunchKernelGGL(k_cg2_init, dim3(nb), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_cg2_init_finish, dim3(1), dim3(256), 0, s, a, nb, rtol);
+}
+void launch_cg2_iteration(hipStream_t s, const BsrCgArgs &a, int parity) {
+  const int nbs = cg2_blocks_spmv(a.S), nbv = cg2_blocks_vec(a.S);
+  if (nbs > 0) hipLaunchKernelGGL(k_bsr_spmv, dim3(nbs), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_cg2_update1, dim3(nbv), dim3(256), 0, s, a, parity, nbs);
+  hipLaunchKernelGGL(k_cg2_update2, dim3(nbv), dim3(256), 0, s, a, parity, nbv);
+  hipLaunchKernelGGL(k_cg2_test, dim3(1), dim3(1), 0, s, a, parity);
+}
+
+}  // namespace ba

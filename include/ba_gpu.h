@@ -56,7 +56,9 @@ enum ba_stop_reason {
 
 enum ba_linear_solver {
   BA_SOLVER_DENSE_SCHUR = 0, /* point elimination + dense fp64 Cholesky of the reduced system */
-  BA_SOLVER_PCG_SCHUR = 1    /* point elimination + block-Jacobi PCG on the implicit reduced system */
+  BA_SOLVER_PCG_SCHUR = 1,   /* point elimination + block-Jacobi PCG on the reduced system, held as 6x6
+                                blocks in block-sparse form (matrix-free when it is too dense for that) */
+  BA_SOLVER_PCG_IMPLICIT = 2 /* same PCG, always matrix-free: S p = Jc^T (I - Jp V^-1 Jp^T) Jc p */
 };
 
 typedef struct {
@@ -224,9 +226,11 @@ int ba_residual_jacobian(ba_problem *p, double *r, double *J);
  * solver's stream and returns the mean seconds per launch.  Used for the Jacobian obs/s figure
  * and the roofline line of the benchmark.  which:
  *   0  fused residual + Jacobian + point elimination (one lane per point)
- *   1  point half of the reduced operator  S p   (PCG inner loop)
+ *   1  point half of the reduced operator  S p   (matrix-free PCG inner loop)
  *   2  station half of the reduced operator      (PCG inner loop)
  *   3  residual-only cost evaluation at a candidate point
+ *   4  assembly of the off-diagonal 6x6 blocks of the reduced matrix
+ *   5  one PCG iteration on the block-sparse reduced system (SpMV + two vector kernels)
  * No counterpart in the reference (its timers are wall-clock prints, src/main.cpp:3027, 4703).
  */
 int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *seconds_per_launch);

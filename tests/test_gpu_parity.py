@@ -97,7 +97,10 @@ def test_sparsity_bit_exact(masks):
 # ------------------------------------------------------------------------------------------------
 # full solves
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("ls", [capi.SOLVER_DENSE_SCHUR, capi.SOLVER_PCG_SCHUR])
+ALL_SOLVERS = [capi.SOLVER_DENSE_SCHUR, capi.SOLVER_PCG_SCHUR, capi.SOLVER_PCG_IMPLICIT]
+
+
+@pytest.mark.parametrize("ls", ALL_SOLVERS)
 def test_cfg1_solve_parity_and_sigma0(ls):
     # configs[0]: the reference's CPU-runnable case, full size; oracle in its most literal mode
     hn = host.synth_config("cfg1")
@@ -120,7 +123,7 @@ def test_cfg1_solve_parity_and_sigma0(ls):
 
 
 @pytest.mark.parametrize("name,scale", [("cfg2", 0.05), ("cfg3", 0.01), ("cfg4", 0.005)])
-@pytest.mark.parametrize("ls", [capi.SOLVER_DENSE_SCHUR, capi.SOLVER_PCG_SCHUR])
+@pytest.mark.parametrize("ls", ALL_SOLVERS)
 def test_scaled_configs_solve_parity(name, scale, ls):
     net = host.synth_config(name, scale=scale).net
     opt = options(ls)
@@ -130,7 +133,7 @@ def test_scaled_configs_solve_parity(name, scale, ls):
     assert_solve_parity(g, o)
 
 
-@pytest.mark.parametrize("ls", [capi.SOLVER_DENSE_SCHUR, capi.SOLVER_PCG_SCHUR])
+@pytest.mark.parametrize("ls", ALL_SOLVERS)
 @pytest.mark.parametrize("clamp", [True, False])
 def test_rejected_steps(ls, clamp):
     toy = host.synth(n_cam=1, n_sta=3, n_pts=8, rays_per_point=3, ap_free_mask=host.ap_mask("k1"), control_every=1,
@@ -164,7 +167,7 @@ def test_edge_cases_unused_blocks():
         ap=np.vstack([base.ap, np.zeros((1, 16))]),
         ap_free_mask=np.array([host.AP_BROWN7, host.AP_BROWN7]), iop_free_mask=np.array([7, 7]))
     assert net.n_sta == S + 1 and net.n_pts == P + 1 and net.n_cam == 2
-    for ls in (capi.SOLVER_DENSE_SCHUR, capi.SOLVER_PCG_SCHUR):
+    for ls in ALL_SOLVERS:
         opt = options(ls)
         g = gpu_solve(net, opt)
         o = po.solve(net, opt, po.FULL_DENSE)
@@ -176,11 +179,28 @@ def test_edge_cases_unused_blocks():
         assert g[4]["num_parameters_reduced"] == 6 * S + 3 * (P + 1) + 19 + 3
 
 
+def test_duplicate_observations_of_a_point_from_one_station():
+    # the same target measured twice in one image: both rows couple into the station's own diagonal block
+    base = host.synth(n_cam=1, n_sta=6, n_pts=40, rays_per_point=4, seed=14, control_every=4,
+                      ap_free_mask=host.AP_K1K2P1P2).net
+    dup = np.arange(0, base.n_obs, 7)
+    cat = lambda a, b: np.concatenate([a, b])
+    net = modified(base, obs_pt=cat(base.obs_pt, base.obs_pt[dup]), obs_sta=cat(base.obs_sta, base.obs_sta[dup]),
+                   obs_x=cat(base.obs_x, base.obs_x[dup] + 0.3), obs_y=cat(base.obs_y, base.obs_y[dup] - 0.2),
+                   obs_sx=cat(base.obs_sx, base.obs_sx[dup]), obs_sy=cat(base.obs_sy, base.obs_sy[dup]),
+                   obs_cx=cat(base.obs_cx, base.obs_cx[dup]), obs_cy=cat(base.obs_cy, base.obs_cy[dup]))
+    for ls in ALL_SOLVERS:
+        opt = options(ls)
+        g = gpu_solve(net, opt)
+        o = po.solve(net, opt, po.FULL_DENSE)
+        assert_solve_parity(g, o)
+
+
 def test_constant_blocks_and_partial_masks():
     net = host.synth(n_cam=2, n_sta=8, n_pts=60, rays_per_point=6, seed=6, control_every=4,
                      ap_free_mask=host.ap_mask("k1", "p1"), iop_free_mask=4).net  # only c free
     net = modified(net, ap_free_mask=np.array([host.ap_mask("k1", "p1"), 0]), iop_free_mask=np.array([4, 0]))
-    for ls in (capi.SOLVER_DENSE_SCHUR, capi.SOLVER_PCG_SCHUR):
+    for ls in ALL_SOLVERS:
         opt = options(ls)
         g = gpu_solve(net, opt)
         o = po.solve(net, opt, po.FULL_DENSE)
