@@ -107,6 +107,8 @@ struct ba_problem {
   int2 *d_ublk_dst = nullptr, *d_pairs = nullptr;
   double *d_Y = nullptr, *d_bsr_val = nullptr, *d_Sdiag = nullptr, *d_Jt = nullptr, *d_corner = nullptr;
   double *d_part_pq = nullptr, *d_part_qc = nullptr, *d_part_rz = nullptr, *d_cg2scal = nullptr;
+  hipGraphExec_t cg_graph = nullptr;  // one batch of PCG iterations, captured once
+  bool cg_graph_failed = false;
   // state
   bool have_params = false;
   // multi-GPU
@@ -416,7 +418,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
     BA_TRY(p->dalloc(&p->d_part_pq, (size_t)cg2_blocks_spmv(S) + 1));
     BA_TRY(p->dalloc(&p->d_part_qc, ((size_t)cg2_blocks_spmv(S) + 1) * std::max(p->ncam, 1)));
     BA_TRY(p->dalloc(&p->d_part_rz, (size_t)cg2_blocks_vec(S) + 1));
-    BA_TRY(p->dalloc(&p->d_cg2scal, 8));
+    BA_TRY(p->dalloc(&p->d_cg2scal, 16));
   }
   if (C == 1 && p->ncmax > 0 && p->ncmax <= border_ncb()) BA_TRY(p->dalloc(&p->d_Jt, 2 * (size_t)border_ncb() * N));
   p->n_partial = 4 * std::max(std::max(linearize_blocks(P), cost_blocks(N)), cost_blocks(6 * (int64_t)S + 3 * (int64_t)P)) + 16;
@@ -424,7 +426,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   BA_TRY(p->dalloc(&p->d_scal, (size_t)SC_COUNT));
   BA_TRY(p->dalloc(&p->d_cgscal, 8));
   HIP_OK(hipHostMalloc((void **)&p->h_scal, SC_COUNT * sizeof(double)));
-  HIP_OK(hipHostMalloc((void **)&p->h_cgscal, 8 * sizeof(double)));
+  HIP_OK(hipHostMalloc((void **)&p->h_cgscal, 16 * sizeof(double)));
   const size_t nr = (size_t)p->nr;
   BA_TRY(p->dalloc(&p->d_g, nr)); BA_TRY(p->dalloc(&p->d_b, nr)); BA_TRY(p->dalloc(&p->d_x, nr));
   BA_TRY(p->dalloc(&p->d_r, nr)); BA_TRY(p->dalloc(&p->d_z, nr)); BA_TRY(p->dalloc(&p->d_p, nr));
@@ -645,19 +647,41 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
   a.Scc = p->d_Scc; a.Lcc = p->d_Lcc; a.Minv = p->d_Minv; a.b = p->d_b; a.x = p->d_x; a.r = p->d_r; a.z = p->d_z; a.p = p->d_p;
   a.q = p->d_q; a.scal = p->d_cg2scal; a.part_pq = p->d_part_pq; a.part_qc = p->d_part_qc; a.part_rz = p->d_part_rz;
   launch_cg2_init(s, a, opt->pcg_rtol);
-  const int batch = 32;
+  const int batch = 32;  // even, so that the parity pattern of a batch repeats
+  if (!p->cg_graph && !p->cg_graph_failed) {
+    // the launch sequence of a batch never changes for this problem: capture it into a graph once
+    hipGraph_t graph = nullptr;
+    bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+      for (int k = 0; k < batch; ++k) launch_cg2_iteration(s, a, k & 1);
+      ok = hipStreamEndCapture(s, &graph) == hipSuccess && graph != nullptr;
+    }
+    if (ok) ok = hipGraphInstantiate(&p->cg_graph, graph, nullptr, nullptr, 0) == hipSuccess;
+    if (graph) hipGraphDestroy(graph);
+    if (!ok) {
+      p->cg_graph = nullptr;
+      p->cg_graph_failed = true;
+      (void)hipGetLastError();
+    }
+  }
   int it = 0;
+  double done = 0.0;
   for (;;) {
-    HIP_OK(hipMemcpyAsync(p->h_cgscal, p->d_cg2scal, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(p->h_cgscal, p->d_cg2scal, 10 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     it = (int)p->h_cgscal[3];
-    if (p->h_cgscal[5] != 0.0 || it >= opt->pcg_max_iters) break;
+    done = std::max(p->h_cgscal[8], p->h_cgscal[9]);
+    if (done != 0.0 || it >= opt->pcg_max_iters) break;
     const int n = std::min(batch, opt->pcg_max_iters - it);
-    for (int k = 0; k < n; ++k) launch_cg2_iteration(s, a, (it + k) & 1);
+    if (p->cg_graph && n == batch && (it & 1) == 0) {
+      HIP_OK(hipGraphLaunch(p->cg_graph, s));
+    } else {
+      for (int k = 0; k < n; ++k) launch_cg2_iteration(s, a, (it + k) & 1);
+    }
   }
   *iters = it;
   BA_TRY(p->check_kernels());
-  if (p->h_cgscal[5] == 2.0) return fail(BA_ERR_NUMERIC, "PCG breakdown at iteration %d (p.Sp = %g)", it, p->h_cgscal[4]);
+  if (done == 2.0) return fail(BA_ERR_NUMERIC, "PCG breakdown at iteration %d (p.Sp = %g)", it, p->h_cgscal[4]);
   if (!std::isfinite(p->h_cgscal[2])) return fail(BA_ERR_NUMERIC, "PCG: non-finite right-hand side");
   return 0;
 }
@@ -878,6 +902,7 @@ void ba_destroy(ba_problem *p) {
   if (!p) return;
   if (p->stream) hipStreamSynchronize(p->stream);
   if (p->comm) ncclCommDestroy(p->comm);
+  if (p->cg_graph) hipGraphExecDestroy(p->cg_graph);
   for (void *q : p->allocs) hipFree(q);
   if (p->h_scal) hipHostFree(p->h_scal);
   if (p->h_cgscal) hipHostFree(p->h_cgscal);

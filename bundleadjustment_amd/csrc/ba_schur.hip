@@ -19,40 +19,60 @@ namespace ba {
 // ------------------------------------------------------------------------------------------
 // assembly
 // ------------------------------------------------------------------------------------------
-// One wave per upper-triangular block u (lo <= hi).  Lane (r,c), r = lane/6, c = lane%6 (36 of 64
-// lanes) owns one entry and walks the block's pair list.
+// One wave per upper-triangular block u (lo <= hi).  Four lanes share one observation pair (each
+// owns a 3x3 quadrant of Y_a Y_b^T), so sixteen pairs are in flight per wave and their row gathers
+// overlap; the sixteen partial blocks are folded with wave shuffles in a fixed order.
 __global__ void __launch_bounds__(256)
 k_schur_blocks(int nu, const int *__restrict__ cstart, const int2 *__restrict__ dst, const int2 *__restrict__ pairs,
                const double *__restrict__ Y, double *__restrict__ val) {
   const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= nu) return;
   const int lane = threadIdx.x & 63;
-  if (u >= nu || lane >= 36) return;
-  const int r = lane / 6, c = lane - 6 * r;
+  const int g = lane >> 2, qa = (lane >> 1) & 1, qb = lane & 1;
   const int q0 = cstart[u], q1 = cstart[u + 1];
-  double acc0 = 0.0, acc1 = 0.0;
-  int q = q0;
-  for (; q + 1 < q1; q += 2) {
-    const int2 pa = pairs[q], pb = pairs[q + 1];
-    const double2 *ya = reinterpret_cast<const double2 *>(Y + (int64_t)BA_Y_STRIDE * pa.x + 4 * r);
-    const double2 *yb = reinterpret_cast<const double2 *>(Y + (int64_t)BA_Y_STRIDE * pa.y + 4 * c);
-    const double2 *yc = reinterpret_cast<const double2 *>(Y + (int64_t)BA_Y_STRIDE * pb.x + 4 * r);
-    const double2 *yd = reinterpret_cast<const double2 *>(Y + (int64_t)BA_Y_STRIDE * pb.y + 4 * c);
-    const double2 a0 = ya[0], a1 = ya[1], b0 = yb[0], b1 = yb[1];
-    const double2 c0 = yc[0], c1 = yc[1], d0 = yd[0], d1 = yd[1];
-    acc0 += a0.x * b0.x + a0.y * b0.y + a1.x * b1.x;
-    acc1 += c0.x * d0.x + c0.y * d0.y + c1.x * d1.x;
+  double acc[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = 0.0;
+  for (int q = q0 + g; q < q1; q += 16) {
+    const int2 pr = pairs[q];
+    const double2 *ya = reinterpret_cast<const double2 *>(Y + (int64_t)BA_Y_STRIDE * pr.x + 12 * qa);
+    const double2 *yb = reinterpret_cast<const double2 *>(Y + (int64_t)BA_Y_STRIDE * pr.y + 12 * qb);
+    double av[3][3], bv[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double2 a0 = ya[2 * i], a1 = ya[2 * i + 1], b0 = yb[2 * i], b1 = yb[2 * i + 1];
+      av[i][0] = a0.x; av[i][1] = a0.y; av[i][2] = a1.x;
+      bv[i][0] = b0.x; bv[i][1] = b0.y; bv[i][2] = b1.x;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[i][j] += av[i][0] * bv[j][0] + av[i][1] * bv[j][1] + av[i][2] * bv[j][2];
   }
-  if (q < q1) {
-    const int2 pa = pairs[q];
-    const double2 *ya = reinterpret_cast<const double2 *>(Y + (int64_t)BA_Y_STRIDE * pa.x + 4 * r);
-    const double2 *yb = reinterpret_cast<const double2 *>(Y + (int64_t)BA_Y_STRIDE * pa.y + 4 * c);
-    const double2 a0 = ya[0], a1 = ya[1], b0 = yb[0], b1 = yb[1];
-    acc0 += a0.x * b0.x + a0.y * b0.y + a1.x * b1.x;
-  }
-  const double v = -(acc0 + acc1);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double v = acc[i][j];
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      acc[i][j] = v;
+    }
+  if (g != 0) return;
   const int2 d = dst[u];
-  val[36 * (int64_t)d.x + 6 * r + c] = v;
-  if (d.y >= 0) val[36 * (int64_t)d.y + 6 * c + r] = v;  // the mirrored block (hi, lo)
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int r = 3 * qa + i, c = 3 * qb + j;
+      const double v = -acc[i][j];
+      val[36 * (int64_t)d.x + 6 * r + c] = v;
+      if (d.y >= 0) val[36 * (int64_t)d.y + 6 * c + r] = v;  // the mirrored block (hi, lo)
+    }
 }
 
 // diagonal blocks: val[row i, first block] += Sdiag[i]
@@ -239,53 +259,70 @@ __global__ void k_border_corner(int ncam, const double *__restrict__ corner, con
 // PCG on the explicit system
 // ------------------------------------------------------------------------------------------
 // scal: [0],[1] r.z (double-buffered by iteration parity), [2] initial r.z, [3] iterations done,
-//       [4] last p.Sp, [5] done flag (1 converged, 2 breakdown), [6] target sqrt(r.z)
+//       [4] last p.Sp, [6] target sqrt(r.z), [8],[9] done flag (1 converged, 2 breakdown), double-buffered
+//       the same way: iteration `it` reads slot it&1 and publishes the next state in the other slot,
+//       so no workgroup ever sees a scalar change under it.
 // q = S p for station rows (one wave per row) with per-workgroup partials of p.q and of the
 // camera rows Ssc^T p.
-__global__ void __launch_bounds__(256)
-k_bsr_spmv(BsrCgArgs a) {
-  __shared__ double lds_pq[4];
-  __shared__ double lds_qc[4][80];
-  if (a.scal[5] != 0.0) return;
+#define SPMV_WAVES 16
+__global__ void __launch_bounds__(64 * SPMV_WAVES)
+k_bsr_spmv(BsrCgArgs a, int parity) {
+  __shared__ double lds_pq[SPMV_WAVES];
+  __shared__ double lds_qc[SPMV_WAVES][80];
+  if (a.scal[8 + parity] != 0.0) return;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + w;
   const int g = lane >> 3, r = lane & 7;
-  double s = 0.0;
-  if (i < a.S && r < 6) {
-    for (int b = a.rowptr[i] + g; b < a.rowptr[i + 1]; b += 8) {
-      const double2 *B = reinterpret_cast<const double2 *>(a.val + 36 * (int64_t)b + 6 * r);
-      const double2 *pc = reinterpret_cast<const double2 *>(a.p + 6 * (int64_t)a.col[b]);
-      const double2 b0 = B[0], b1 = B[1], b2 = B[2], p0 = pc[0], p1 = pc[1], p2 = pc[2];
-      s += b0.x * p0.x + b0.y * p0.y + b1.x * p1.x + b1.y * p1.y + b2.x * p2.x + b2.y * p2.y;
-    }
-  }
-  s += __shfl_xor(s, 8, 64);
-  s += __shfl_xor(s, 16, 64);
-  s += __shfl_xor(s, 32, 64);
   double pq = 0.0;
-  if (i < a.S && lane < 6) {
-    const double *pcam = a.p + 6 * (int64_t)a.S;
-    const double *row = a.Ssc + (6 * (int64_t)i + lane) * a.ncam;
-    for (int k = 0; k < a.ncam; ++k) s += row[k] * pcam[k];
-    a.q[6 * (int64_t)i + lane] = s;
-    pq = s * a.p[6 * (int64_t)i + lane];
+  double tcam0 = 0.0, tcam1 = 0.0;  // camera-row partials of this lane: columns lane and lane + 64
+  const double *pcam = a.p + 6 * (int64_t)a.S;
+  for (int i = blockIdx.x * SPMV_WAVES + w; i < a.S; i += gridDim.x * SPMV_WAVES) {
+    double s = 0.0;
+    if (r < 6) {
+      for (int b = a.rowptr[i] + g; b < a.rowptr[i + 1]; b += 8) {
+        const double2 *B = reinterpret_cast<const double2 *>(a.val + 36 * (int64_t)b + 6 * r);
+        const double2 *pc = reinterpret_cast<const double2 *>(a.p + 6 * (int64_t)a.col[b]);
+        const double2 b0 = B[0], b1 = B[1], b2 = B[2], p0 = pc[0], p1 = pc[1], p2 = pc[2];
+        s += b0.x * p0.x + b0.y * p0.y + b1.x * p1.x + b1.y * p1.y + b2.x * p2.x + b2.y * p2.y;
+      }
+    }
+    s += __shfl_xor(s, 8, 64);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (lane < 6) {
+      const double *row = a.Ssc + (6 * (int64_t)i + lane) * a.ncam;
+      for (int k = 0; k < a.ncam; ++k) s += row[k] * pcam[k];
+      a.q[6 * (int64_t)i + lane] = s;
+      pq += s * a.p[6 * (int64_t)i + lane];
+    }
+    // camera rows: t_k += sum_r Ssc[i][r][k] p_i[r]
+    if (lane < a.ncam) {
+      const double *pi = a.p + 6 * (int64_t)i;
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) tcam0 += a.Ssc[(6 * (int64_t)i + rr) * a.ncam + lane] * pi[rr];
+    }
+    if (lane + 64 < a.ncam) {
+      const double *pi = a.p + 6 * (int64_t)i;
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) tcam1 += a.Ssc[(6 * (int64_t)i + rr) * a.ncam + lane + 64] * pi[rr];
+    }
   }
   pq = wave_sum(pq);
   if (lane == 0) lds_pq[w] = pq;
-  // camera rows: t_k = sum_r Ssc[i][r][k] p_i[r]
-  for (int k = lane; k < a.ncam; k += 64) {
-    double t = 0.0;
-    if (i < a.S) {
-      const double *pi = a.p + 6 * (int64_t)i;
-#pragma unroll
-      for (int rr = 0; rr < 6; ++rr) t += a.Ssc[(6 * (int64_t)i + rr) * a.ncam + k] * pi[rr];
-    }
-    lds_qc[w][k] = t;
-  }
+  if (lane < a.ncam) lds_qc[w][lane] = tcam0;
+  if (lane + 64 < a.ncam) lds_qc[w][lane + 64] = tcam1;
   __syncthreads();
-  if (threadIdx.x == 0) a.part_pq[blockIdx.x] = lds_pq[0] + lds_pq[1] + lds_pq[2] + lds_pq[3];
-  for (int k = threadIdx.x; k < a.ncam; k += blockDim.x)
-    a.part_qc[(int64_t)blockIdx.x * a.ncam + k] = lds_qc[0][k] + lds_qc[1][k] + lds_qc[2][k] + lds_qc[3][k];
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int m = 0; m < SPMV_WAVES; ++m) t += lds_pq[m];
+    a.part_pq[blockIdx.x] = t;
+  }
+  for (int k = threadIdx.x; k < a.ncam; k += blockDim.x) {
+    double t = 0.0;
+#pragma unroll
+    for (int m = 0; m < SPMV_WAVES; ++m) t += lds_qc[m][k];
+    a.part_qc[(int64_t)blockIdx.x * a.ncam + k] = t;
+  }
 }
 
 // camera part of z = M^-1 r with the dense Cholesky factor of the corner (one thread)
@@ -362,8 +399,9 @@ k_cg2_init_finish(BsrCgArgs a, int nblk, double rtol) {
     a.scal[2] = t;
     a.scal[3] = 0.0;
     a.scal[4] = 0.0;
-    a.scal[5] = (t > 0.0) ? 0.0 : 1.0;
+    a.scal[5] = 0.0;
     a.scal[6] = rtol * sqrt(fmax(t, 0.0));
+    a.scal[8] = a.scal[9] = (t > 0.0) ? 0.0 : 1.0;
   }
 }
 
@@ -371,28 +409,48 @@ k_cg2_init_finish(BsrCgArgs a, int nblk, double rtol) {
 __global__ void __launch_bounds__(256)
 k_cg2_update1(BsrCgArgs a, int parity, int nblk_spmv) {
   __shared__ double lds[8];
-  __shared__ double qc_s[80];
+  __shared__ double red[80];   // [0] p.q over the station rows, [1 + k] camera row k of S p
+  __shared__ double pcs[80];   // camera part of p
   __shared__ double pq_s;
-  if (a.scal[5] != 0.0) return;
-  // every workgroup folds the SpMV partials in the same order -> identical alpha everywhere
-  double s = 0.0;
-  for (int k = threadIdx.x; k < nblk_spmv; k += blockDim.x) s += a.part_pq[k];
-  double pq = block_sum(s, lds);
+  if (a.scal[8 + parity] != 0.0) return;
+  // Every workgroup folds the SpMV partials in the same order -> identical alpha everywhere.
+  // The 1 + ncam sums are dealt to the four waves; each is one strided walk and a wave reduction.
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t o = 6 * (int64_t)a.S;
-  for (int k = 0; k < a.ncam; ++k) {
-    double t = 0.0;
-    for (int m = threadIdx.x; m < nblk_spmv; m += blockDim.x) t += a.part_qc[(int64_t)m * a.ncam + k];
-    const double v = block_sum(t, lds);
-    if (threadIdx.x == 0) {
-      double qk = v;
-      for (int m = 0; m < a.ncam; ++m) qk += a.Scc[k * a.ncam + m] * a.p[o + m];
-      qc_s[k] = qk;
-      pq += qk * a.p[o + k];
+  for (int k = threadIdx.x; k < a.ncam; k += blockDim.x) pcs[k] = a.p[o + k];
+  for (int qn = w; qn < 1 + a.ncam; qn += 4) {
+    // four independent accumulators keep four loads in flight per lane (fixed order: deterministic)
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const double *src = (qn == 0) ? a.part_pq : a.part_qc + (qn - 1);
+    const int64_t st = (qn == 0) ? 1 : a.ncam;
+    int m = lane;
+    for (; m + 192 < nblk_spmv; m += 256) {
+      s0 += src[st * m];
+      s1 += src[st * (m + 64)];
+      s2 += src[st * (m + 128)];
+      s3 += src[st * (m + 192)];
     }
+    for (; m < nblk_spmv; m += 64) s0 += src[st * m];
+    double s = wave_sum((s0 + s1) + (s2 + s3));
+    if (lane == 0) red[qn] = s;
   }
-  if (threadIdx.x == 0) pq_s = pq;
   __syncthreads();
-  pq = pq_s;
+  // camera rows: add the corner, S_cc p_c
+  double qk = 0.0;
+  if (threadIdx.x < a.ncam) {
+    qk = red[1 + threadIdx.x];
+    for (int m = 0; m < a.ncam; ++m) qk += a.Scc[threadIdx.x * a.ncam + m] * pcs[m];
+  }
+  __syncthreads();
+  if (threadIdx.x < a.ncam) red[1 + threadIdx.x] = qk;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double pq = red[0];
+    for (int k = 0; k < a.ncam; ++k) pq += red[1 + k] * pcs[k];
+    pq_s = pq;
+  }
+  __syncthreads();
+  const double pq = pq_s;
   const double rz = a.scal[parity];
   const double alpha = rz / pq;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -405,10 +463,11 @@ k_cg2_update1(BsrCgArgs a, int parity, int nblk_spmv) {
     }
     dot = station_precond(a.Minv, a.r, a.z, i);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    // the last workgroup is the least loaded one: it also carries the camera entries
     for (int k = 0; k < a.ncam; ++k) {
-      a.x[o + k] += alpha * a.p[o + k];
-      a.r[o + k] -= alpha * qc_s[k];
+      a.x[o + k] += alpha * pcs[k];
+      a.r[o + k] -= alpha * red[1 + k];
     }
     if (a.ncam > 0) cam_precond(a.ncam, a.Lcc, a.r + o, a.z + o);
     for (int k = 0; k < a.ncam; ++k) dot += a.r[o + k] * a.z[o + k];
@@ -418,12 +477,16 @@ k_cg2_update1(BsrCgArgs a, int parity, int nblk_spmv) {
   if (threadIdx.x == 0) a.part_rz[blockIdx.x] = t;
 }
 
-// beta = r.z(new) / r.z(old); p = z + beta p; stopping test
+// beta = r.z(new) / r.z(old); p = z + beta p; stopping test for the next iteration
 __global__ void __launch_bounds__(256)
 k_cg2_update2(BsrCgArgs a, int parity, int nblk) {
   __shared__ double lds[8];
   __shared__ double rzn_s;
-  if (a.scal[5] != 0.0) return;
+  const double done = a.scal[8 + parity];
+  if (done != 0.0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.scal[8 + (parity ^ 1)] = done;  // keep both slots set
+    return;
+  }
   double s = 0.0;
   for (int k = threadIdx.x; k < nblk; k += blockDim.x) s += a.part_rz[k];
   const double t = block_sum(s, lds);
@@ -441,16 +504,12 @@ k_cg2_update2(BsrCgArgs a, int parity, int nblk) {
     for (int k = 0; k < a.ncam; ++k) a.p[o + k] = a.z[o + k] + beta * a.p[o + k];
     a.scal[parity ^ 1] = rzn;
     a.scal[3] += 1.0;
+    const double pq = a.scal[4];
+    double nd = 0.0;
+    if (!(pq > 0.0) || !(rzn == rzn)) nd = 2.0;
+    else if (sqrt(fmax(rzn, 0.0)) <= a.scal[6]) nd = 1.0;
+    a.scal[8 + (parity ^ 1)] = nd;
   }
-}
-
-// runs after update2 of the same iteration: reads what update2 published, sets the done flag.
-// (a separate tiny kernel so that no workgroup of update2 can see the flag change under it)
-__global__ void k_cg2_test(BsrCgArgs a, int parity) {
-  if (blockIdx.x != 0 || threadIdx.x != 0 || a.scal[5] != 0.0) return;
-  const double rzn = a.scal[parity ^ 1], pq = a.scal[4];
-  if (!(pq > 0.0) || !(rzn == rzn)) a.scal[5] = 2.0;
-  else if (sqrt(fmax(rzn, 0.0)) <= a.scal[6]) a.scal[5] = 1.0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -486,7 +545,10 @@ void launch_border_fold(hipStream_t s, int S, int ncam, int n_chunks, const int 
 void launch_border_corner(hipStream_t s, int ncam, const double *corner, const double *camdiag, double *Scc) {
   hipLaunchKernelGGL(k_border_corner, dim3(1), dim3(1), 0, s, ncam, corner, camdiag, Scc);
 }
-int cg2_blocks_spmv(int S) { return nblk(S, 4); }
+int cg2_blocks_spmv(int S) {
+  const int nb = nblk(S, SPMV_WAVES);
+  return nb > 2048 ? 2048 : nb;
+}
 int cg2_blocks_vec(int S) { return nblk(S, 256) > 0 ? nblk(S, 256) : 1; }
 void launch_cg2_init(hipStream_t s, const BsrCgArgs &a, double rtol) {
   const int nb = cg2_blocks_vec(a.S);
@@ -495,10 +557,9 @@ void launch_cg2_init(hipStream_t s, const BsrCgArgs &a, double rtol) {
 }
 void launch_cg2_iteration(hipStream_t s, const BsrCgArgs &a, int parity) {
   const int nbs = cg2_blocks_spmv(a.S), nbv = cg2_blocks_vec(a.S);
-  if (nbs > 0) hipLaunchKernelGGL(k_bsr_spmv, dim3(nbs), dim3(256), 0, s, a);
+  if (nbs > 0) hipLaunchKernelGGL(k_bsr_spmv, dim3(nbs), dim3(64 * SPMV_WAVES), 0, s, a, parity);
   hipLaunchKernelGGL(k_cg2_update1, dim3(nbv), dim3(256), 0, s, a, parity, nbs);
   hipLaunchKernelGGL(k_cg2_update2, dim3(nbv), dim3(256), 0, s, a, parity, nbv);
-  hipLaunchKernelGGL(k_cg2_test, dim3(1), dim3(1), 0, s, a, parity);
 }
 
 }  // namespace ba
