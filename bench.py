@@ -23,22 +23,62 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
 
-def kernel_bytes(which, net_obs, net_pts, net_sta):
-    """Algorithmic bytes one launch must move (per-observation figures x observations).
-    0 linearize     : obs record 56 + station 48 + point 24 + residual 16 + W-equivalent 144 per observation,
-                      72 per point (V, g), 216 per station (U, g)
-    1 point_apply   : Js 96 + Jp 48 + station index 4 + p_i 48 + b 16 per observation, Vinv 48 per point
-    2 station_gather: Js 96 + b 16 + index 4 per observation, q 48 per station"""
+def kernel_bytes(which, n_obs, n_pts, n_sta, n_blocks=0, n_pairs=0, ncam=0):
+    """Algorithmic bytes one launch must move (per-unit figures x units; written out in DESIGN.md).
+    0 linearize      : per observation 56 (record) + 48 (station) + 24 (point) + 16 (residual) + 144 (coupling block W),
+                       per point 72 (V, g), per station 216 (U, g)
+    1 point_apply    : per observation Js 96 + Jp 48 + station index 4 + p_i 48 + b 16, per point Vinv 48
+    2 station_gather : per observation Js 96 + b 16 + index 4, per station q 48
+    3 cost           : per observation record 56 + point 24
+    4 schur_blocks   : per observation pair two 144-B coupling blocks + the 8-B pair record, per 6x6 block 288 written twice
+    5 pcg_iteration  : the block-sparse matrix once (288 B per block + 4-B column index), the border once,
+                       and the six vectors of the iteration (x r z p q read, x r z p q written: 10 x 48 B per station)"""
     if which == 0:
-        return 288.0 * net_obs + 72.0 * net_pts + 216.0 * net_sta
+        return 288.0 * n_obs + 72.0 * n_pts + 216.0 * n_sta
     if which == 1:
-        return 212.0 * net_obs + 48.0 * net_pts
+        return 212.0 * n_obs + 48.0 * n_pts
     if which == 2:
-        return 116.0 * net_obs + 48.0 * net_sta
-    return 80.0 * net_obs  # cost: obs record 56 + point 24 (station table stays in L2)
+        return 116.0 * n_obs + 48.0 * n_sta
+    if which == 3:
+        return 80.0 * n_obs
+    if which == 4:
+        return 296.0 * n_pairs + 2 * 288.0 * n_blocks
+    if which == 5:
+        return 292.0 * n_blocks + 48.0 * ncam * n_sta + 480.0 * n_sta
+    return 292.0 * n_blocks + 48.0 * ncam * n_sta + 96.0 * n_sta  # 6 spmv: matrix, border, p read, q written
 
 
-KERNEL_NAMES = {0: "k_linearize", 1: "k_point_pass<APPLY>", 2: "k_station_pass<GATHER>", 3: "k_cost_obs"}
+KERNEL_NAMES = {0: "k_linearize", 1: "k_point_pass<APPLY>", 2: "k_station_pass<GATHER>", 3: "k_cost_obs",
+                4: "k_schur_blocks", 5: "pcg iteration (k_bsr_spmv + k_cg2_update1 + k_cg2_update2)", 6: "k_bsr_spmv"}
+
+
+def structure_counts(net):
+    """Observation pairs and distinct station pairs (6x6 blocks incl. the diagonal ones) of a network."""
+    order = np.argsort(net.obs_pt, kind="stable")
+    deg = np.bincount(net.obs_pt, minlength=net.n_pts).astype(np.int64)
+    n_pairs = int(np.sum(deg * (deg - 1) // 2))
+    sta = net.obs_sta[order].astype(np.int64)
+    start = np.concatenate([[0], np.cumsum(deg)])
+    keys = []
+    dmax = int(deg.max()) if len(deg) else 0
+    if len(deg) and np.all(deg == dmax):  # uniform degree: vectorised
+        m = sta.reshape(-1, dmax)
+        for a in range(dmax):
+            for b in range(a + 1, dmax):
+                lo, hi = np.minimum(m[:, a], m[:, b]), np.maximum(m[:, a], m[:, b])
+                keys.append(np.unique(lo * net.n_sta + hi))
+        uniq = np.unique(np.concatenate(keys)) if keys else np.zeros(0, np.int64)
+        off = int(np.sum(uniq // net.n_sta != uniq % net.n_sta))
+    else:
+        seen = set()
+        for j in range(net.n_pts):
+            ss = sta[start[j]:start[j + 1]]
+            for a in range(len(ss)):
+                for b in range(a + 1, len(ss)):
+                    if ss[a] != ss[b]:
+                        seen.add((min(ss[a], ss[b]), max(ss[a], ss[b])))
+        off = len(seen)
+    return n_pairs, 2 * off + net.n_sta
 
 
 def cpu_baseline(config, cpu_scale, pcg_rtol):
@@ -138,23 +178,35 @@ def main():
         sys.exit(f"solver ran {steps_done} iterations instead of {args.steps}: {sm}")
 
     # per-kernel timing with HIP events on the solver's stream (live, same process)
-    ktime = {w: P.time_kernel(w, 10) for w in (0, 1, 2, 3)}
+    which_all = (0, 4, 6, 5, 3)
+    ktime = {w: P.time_kernel(w, 10) for w in which_all}
     if world > 1:
-        t = torch.tensor([ktime[w] for w in (0, 1, 2, 3)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([ktime[w] for w in which_all], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ktime = {w: float(t[i].item()) for i, w in enumerate((0, 1, 2, 3))}
+        ktime = {w: float(t[i].item()) for i, w in enumerate(which_all)}
     lin_iters = sm["total_linear_iterations"]
     n_lin = sum(1 for r in rows if r["step_is_successful"]) + 1
-    share = {0: ktime[0] * n_lin, 1: ktime[1] * lin_iters, 2: ktime[2] * lin_iters, 3: ktime[3] * args.steps}
+    calls = {0: n_lin, 4: n_lin, 5: lin_iters, 6: lin_iters, 3: args.steps}
+    share = {w: ktime[w] * calls[w] for w in which_all}
+    share[5] = 0.0  # the whole iteration is listed for information; its kernels are ranked one by one
+    n_pairs, n_blocks = structure_counts(net)
+    ncam = int(sum(bin(int(a)).count("1") + bin(int(b) & 7).count("1") for a, b in zip(net.ap_free_mask, net.iop_free_mask)))
+    full_pairs, full_blocks = (n_pairs, n_blocks) if world == 1 else structure_counts(full)
+
+    def kb(w):
+        # the PCG iteration runs on the whole reduced system on every rank; the other kernels on the shard
+        if w in (5, 6):
+            return kernel_bytes(w, full.n_obs, full.n_pts, full.n_sta, full_blocks, full_pairs, ncam)
+        return kernel_bytes(w, net.n_obs, net.n_pts, net.n_sta, n_blocks, n_pairs, ncam)
+
     dom = max(share, key=share.get)
-    nbytes = kernel_bytes(dom, net.n_obs, net.n_pts, net.n_sta)
-    achieved = nbytes / ktime[dom] / 1e9
+    achieved = kb(dom) / ktime[dom] / 1e9
     kernels = []
-    for w in (0, 1, 2, 3):
-        b = kernel_bytes(w, net.n_obs, net.n_pts, net.n_sta)
-        kernels.append({"kernel": KERNEL_NAMES[w], "ms": ktime[w] * 1e3, "algorithmic_GB": b / 1e9,
-                        "GBps": b / ktime[w] / 1e9, "frac": b / ktime[w] / 1e9 / HBM_PEAK_GBS,
-                        "share_of_step_time": share[w] / max(sum(share.values()), 1e-30)})
+    for w in which_all:
+        b = kb(w)
+        kernels.append({"kernel": KERNEL_NAMES[w], "ms": ktime[w] * 1e3, "launches_in_timed_region": calls[w],
+                        "algorithmic_GB": b / 1e9, "GBps": b / ktime[w] / 1e9, "frac": b / ktime[w] / 1e9 / HBM_PEAK_GBS,
+                        "share_of_kernel_time": ktime[w] * calls[w] / max(sum(share.values()), 1e-30)})
 
     out = {
         "metric": "LM iter/s (10M-obs synthetic network)",
@@ -170,7 +222,8 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"{args.config}: {full.n_cam} camera(s), {full.n_sta} stations, {full.n_pts} points, "
-                               f"{full.n_obs} observations, self-calibrating (IOP + k1 k2 p1 p2), Schur + block-Jacobi PCG",
+                               f"{full.n_obs} observations, self-calibrating (IOP + k1 k2 p1 p2), point elimination + block-Jacobi PCG "
+                               f"on the block-sparse reduced system",
                    "scale": args.scale, "pcg_rtol": args.pcg_rtol, "sharding": f"points/{world}"},
         "jacobian_obs_per_s": full.n_obs / ktime[0],
         "pcg_iterations_per_step": lin_iters / args.steps,

@@ -142,6 +142,7 @@ int cg2_blocks_spmv(int S);
 int cg2_blocks_vec(int S);
 void launch_cg2_init(hipStream_t s, const BsrCgArgs &a, double rtol);
 void launch_cg2_iteration(hipStream_t s, const BsrCgArgs &a, int parity);
+void launch_bsr_spmv(hipStream_t s, const BsrCgArgs &a, int parity);
 
 // ba_chol.hip: in-place lower Cholesky of a dense row-major n x n matrix (ld = n) and the
 // solve L L^T x = b (b overwritten).  info[0] != 0 after the factorisation when a pivot was

@@ -555,6 +555,10 @@ void launch_cg2_init(hipStream_t s, const BsrCgArgs &a, double rtol) {
   hipLaunchKernelGGL(k_cg2_init, dim3(nb), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_cg2_init_finish, dim3(1), dim3(256), 0, s, a, nb, rtol);
 }
+void launch_bsr_spmv(hipStream_t s, const BsrCgArgs &a, int parity) {
+  const int nbs = cg2_blocks_spmv(a.S);
+  if (nbs > 0) hipLaunchKernelGGL(k_bsr_spmv, dim3(nbs), dim3(64 * SPMV_WAVES), 0, s, a, parity);
+}
 void launch_cg2_iteration(hipStream_t s, const BsrCgArgs &a, int parity) {
   const int nbs = cg2_blocks_spmv(a.S), nbv = cg2_blocks_vec(a.S);
   if (nbs > 0) hipLaunchKernelGGL(k_bsr_spmv, dim3(nbs), dim3(64 * SPMV_WAVES), 0, s, a, parity);

@@ -231,6 +231,7 @@ int ba_residual_jacobian(ba_problem *p, double *r, double *J);
  *   3  residual-only cost evaluation at a candidate point
  *   4  assembly of the off-diagonal 6x6 blocks of the reduced matrix
  *   5  one PCG iteration on the block-sparse reduced system (SpMV + two vector kernels)
+ *   6  the block-sparse matrix-vector product of that iteration alone
  * No counterpart in the reference (its timers are wall-clock prints, src/main.cpp:3027, 4703).
  */
 int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *seconds_per_launch);
