@@ -107,6 +107,8 @@ struct ba_problem {
   int2 *d_ublk_dst = nullptr, *d_pairs = nullptr;
   double *d_Y = nullptr, *d_bsr_val = nullptr, *d_Sdiag = nullptr, *d_Jt = nullptr, *d_corner = nullptr;
   double *d_part_pq = nullptr, *d_part_qc = nullptr, *d_part_rz = nullptr, *d_cg2scal = nullptr;
+  std::vector<int> ub_lo_h, ub_hi_h, bsr_rowptr_h, bsr_col_h;  // host copies of the block structure
+  std::vector<int> cam_used_h;
   hipGraphExec_t cg_graph = nullptr;  // one batch of PCG iterations, captured once
   bool cg_graph_failed = false;
   // state
@@ -183,7 +185,8 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   p->ap_mask_h.assign(in->ap_free_mask, in->ap_free_mask + C);
   p->iop_mask_h.assign(in->iop_free_mask, in->iop_free_mask + C);
   p->sta_used_h.assign(S, 0);
-  std::vector<int> cam_used(C, 0);
+  std::vector<int> &cam_used = p->cam_used_h;
+  cam_used.assign(C, 0);
   std::vector<int> deg(P, 0), sdeg(S, 0);
   for (int n = 0; n < N; ++n) {
     p->sta_used_h[in->obs_sta[n]] = 1;
@@ -348,6 +351,10 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
         p->n_ublk = nu;
         p->n_bsr = (int)nb_total;
         p->n_pairs = tot;
+        p->ub_lo_h = ub_lo;
+        p->ub_hi_h = ub_hi;
+        p->bsr_rowptr_h = bsr_rowptr;
+        p->bsr_col_h = bsr_col;
       }
     }
   }
@@ -1276,17 +1283,98 @@ int ba_sparsity(ba_problem *p, int32_t *num_rows, int32_t *num_cols, int64_t *nn
 }
 
 // ---- multi-GPU ------------------------------------------------------------------------------
-static int sync_station_usage(ba_problem *p) {
-  // a station may be observed only from points of another shard
-  if (!p->ar || p->S == 0) return 0;
-  std::vector<double> u(p->S);
-  for (int i = 0; i < p->S; ++i) u[i] = p->sta_used_h[i];
-  HIP_OK(hipMemcpy(p->d_F, u.data(), u.size() * sizeof(double), hipMemcpyHostToDevice));
-  BA_TRY(p->allreduce(p->d_F, p->S, 1));
+// Reduces a small host vector over the ranks through the device-side callback (op 0 sum, 1 max).
+static int host_allreduce(ba_problem *p, std::vector<double> &v, int op) {
+  if (v.empty()) return 0;
+  if (v.size() > 39 * (size_t)std::max(p->S, 1)) return fail(BA_ERR_INVALID, "host_allreduce: vector too long");
+  HIP_OK(hipMemcpy(p->d_F, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+  BA_TRY(p->allreduce(p->d_F, (int64_t)v.size(), op));
   HIP_OK(hipStreamSynchronize(p->stream));
-  HIP_OK(hipMemcpy(u.data(), p->d_F, u.size() * sizeof(double), hipMemcpyDeviceToHost));
-  for (int i = 0; i < p->S; ++i) p->sta_used_h[i] = u[i] > 0.0;
-  HIP_OK(hipMemcpy(p->d_sta_used, p->sta_used_h.data(), p->sta_used_h.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(v.data(), p->d_F, v.size() * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// What every rank must agree on before a sharded solve: which stations are observed at all,
+// whether the block-sparse form is used, and the block pattern itself (the union over the shards,
+// so that the value arrays of all ranks have the same layout and can be summed element-wise).
+static int sync_shards(ba_problem *p) {
+  if (!p->ar) return 0;
+  const int S = p->S;
+  if (S > 0) {
+    std::vector<double> u(S);
+    for (int i = 0; i < S; ++i) u[i] = p->sta_used_h[i];
+    BA_TRY(host_allreduce(p, u, 1));
+    for (int i = 0; i < S; ++i) p->sta_used_h[i] = u[i] > 0.0;
+    HIP_OK(hipMemcpy(p->d_sta_used, p->sta_used_h.data(), p->sta_used_h.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  if (p->C > 0 && S > 0) {
+    std::vector<double> c(std::min(p->C, 39 * S));
+    for (size_t k = 0; k < c.size(); ++k) c[k] = p->cam_used_h[k];
+    BA_TRY(host_allreduce(p, c, 1));
+    for (size_t k = 0; k < c.size(); ++k)
+      if ((c[k] > 0.0) != (p->cam_used_h[k] != 0))
+        return fail(BA_ERR_UNSUPPORTED, "camera %zu is observed on another shard but not on this one: every rank must hold "
+                    "observations of every camera that is used", k);
+  }
+  if (S == 0) return 0;
+  std::vector<double> flag(1, p->explicit_ok ? 0.0 : 1.0);
+  BA_TRY(host_allreduce(p, flag, 1));
+  if (flag[0] > 0.0) {
+    p->explicit_ok = false;
+    return 0;
+  }
+  // union of the neighbour lists, one allreduce(min) round per list position
+  std::vector<int> cur(S, -1), pos(S);
+  for (int i = 0; i < S; ++i) pos[i] = p->bsr_rowptr_h[i] + 1;  // skip the diagonal block
+  std::vector<std::vector<int>> nb(S);
+  std::vector<double> cand(S);
+  for (;;) {
+    for (int i = 0; i < S; ++i) {
+      while (pos[i] < p->bsr_rowptr_h[i + 1] && p->bsr_col_h[pos[i]] <= cur[i]) ++pos[i];
+      const int c = pos[i] < p->bsr_rowptr_h[i + 1] ? p->bsr_col_h[pos[i]] : S;
+      cand[i] = -(double)c;
+    }
+    BA_TRY(host_allreduce(p, cand, 1));
+    bool any = false;
+    for (int i = 0; i < S; ++i) {
+      const int c = (int)(-cand[i]);
+      if (c < S) {
+        nb[i].push_back(c);
+        cur[i] = c;
+        any = true;
+      } else {
+        cur[i] = S;
+      }
+    }
+    if (!any) break;
+  }
+  std::vector<int> rowptr(S + 1, 0), col;
+  for (int i = 0; i < S; ++i) rowptr[i + 1] = rowptr[i] + 1 + (int)nb[i].size();
+  col.resize(rowptr[S]);
+  for (int i = 0; i < S; ++i) {
+    col[rowptr[i]] = i;
+    std::copy(nb[i].begin(), nb[i].end(), col.begin() + rowptr[i] + 1);
+  }
+  std::vector<int2> dst(p->n_ublk);
+  auto find = [&](int row, int c) {
+    const int *b = col.data() + rowptr[row] + 1, *e = col.data() + rowptr[row + 1];
+    return (int)(std::lower_bound(b, e, c) - col.data());
+  };
+  for (int u = 0; u < p->n_ublk; ++u) {
+    const int lo = p->ub_lo_h[u], hi = p->ub_hi_h[u];
+    dst[u] = (lo == hi) ? make_int2(rowptr[lo], -1) : make_int2(find(lo, hi), find(hi, lo));
+  }
+  p->bsr_rowptr_h = rowptr;
+  p->bsr_col_h = col;
+  p->n_bsr = rowptr[S];
+  BA_TRY(p->upload(&p->d_bsr_rowptr, rowptr));
+  BA_TRY(p->upload(&p->d_bsr_col, col));
+  BA_TRY(p->upload(&p->d_ublk_dst, dst));
+  BA_TRY(p->dalloc(&p->d_bsr_val, 36 * (size_t)p->n_bsr));
+  if (p->cg_graph) {
+    hipGraphExecDestroy(p->cg_graph);
+    p->cg_graph = nullptr;
+  }
   return 0;
 }
 
@@ -1294,7 +1382,21 @@ int ba_set_allreduce(ba_problem *p, ba_allreduce_fn fn, void *user) {
   if (!p) return fail(BA_ERR_INVALID, "ba_set_allreduce: null problem");
   p->ar = fn;
   p->ar_user = user;
-  return sync_station_usage(p);
+  return sync_shards(p);
+}
+
+int ba_copy_to_host(void *host_dst, const double *device_src, int64_t count, void *hip_stream) {
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  HIP_OK(hipMemcpyAsync(host_dst, device_src, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  return 0;
+}
+
+int ba_copy_to_device(double *device_dst, const void *host_src, int64_t count, void *hip_stream) {
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  HIP_OK(hipMemcpyAsync(device_dst, host_src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_OK(hipStreamSynchronize(s));
+  return 0;
 }
 
 static int rccl_allreduce(void *user, double *buf, int64_t count, int32_t op, void *stream) {

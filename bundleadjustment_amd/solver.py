@@ -20,7 +20,7 @@ KERNEL_LINEARIZE, KERNEL_POINT_APPLY, KERNEL_STATION_GATHER, KERNEL_COST = 0, 1,
 # every entry point include/ba_gpu.h declares
 EXPORTS = ("ba_default_options", "ba_create", "ba_destroy", "ba_set_parameters", "ba_get_parameters",
            "ba_solve_resident", "ba_solve", "ba_evaluate", "ba_sparsity", "ba_residual_jacobian", "ba_time_kernel",
-           "ba_set_allreduce", "ba_rccl_unique_id", "ba_use_rccl", "ba_last_error")
+           "ba_set_allreduce", "ba_copy_to_host", "ba_copy_to_device", "ba_rccl_unique_id", "ba_use_rccl", "ba_last_error")
 
 
 def lib_path():
@@ -57,6 +57,8 @@ def lib():
         L.ba_residual_jacobian.argtypes = [C.c_void_p, c_double_p, c_double_p]
         L.ba_time_kernel.argtypes = [C.c_void_p, C.c_int32, C.c_int32, c_double_p]
         L.ba_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+        L.ba_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.ba_copy_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.ba_rccl_unique_id.argtypes = [C.c_void_p]
         L.ba_use_rccl.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         _lib = L
@@ -181,6 +183,18 @@ class Problem:
                 return -1
         self._cb = ALLREDUCE_FN(tramp)
         _check(lib().ba_set_allreduce(self._h, self._cb, None))
+
+    def set_allreduce_host_staged(self, reduce_fn):
+        """reduce_fn(numpy array, op) -> reduces the array in place over all ranks (op 0 sum, 1 max).
+        The device buffer is copied to the host, reduced there, and copied back: for tests and for
+        back ends without device-side collectives."""
+        def cb(ptr, count, op, stream):
+            buf = np.empty(count, dtype=np.float64)
+            _check(lib().ba_copy_to_host(buf.ctypes.data, ptr, count, stream))
+            reduce_fn(buf, op)
+            _check(lib().ba_copy_to_device(ptr, buf.ctypes.data, count, stream))
+            return 0
+        self.set_allreduce(cb)
 
     def use_rccl(self, n_ranks, rank, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, 128)

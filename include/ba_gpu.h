@@ -252,6 +252,11 @@ typedef int (*ba_allreduce_fn)(void *user, double *device_buf, int64_t count, in
                                void *hip_stream);
 int ba_set_allreduce(ba_problem *p, ba_allreduce_fn fn, void *user);
 
+/* Helpers for callbacks that stage through host memory (e.g. a gloo or MPI reduction in tests):
+ * synchronous copies ordered after the work already queued on hip_stream. */
+int ba_copy_to_host(void *host_dst, const double *device_src, int64_t count, void *hip_stream);
+int ba_copy_to_device(double *device_dst, const void *host_src, int64_t count, void *hip_stream);
+
 /* RCCL implementation of the callback above.  unique_id is the 128-byte ncclUniqueId made
  * by ba_rccl_unique_id on rank 0 and distributed by the host. */
 int ba_rccl_unique_id(void *unique_id_128);
