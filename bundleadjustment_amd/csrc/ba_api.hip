@@ -109,6 +109,9 @@ struct ba_problem {
   double *d_part_pq = nullptr, *d_part_qc = nullptr, *d_part_rz = nullptr, *d_cg2scal = nullptr;
   std::vector<int> ub_lo_h, ub_hi_h, bsr_rowptr_h, bsr_col_h;  // host copies of the block structure
   std::vector<int> cam_used_h;
+  unsigned *d_sync = nullptr;  // grid-barrier words of the persistent PCG kernel
+  int n_cu = 0;
+  bool persistent_failed = false;
   hipGraphExec_t cg_graph = nullptr;  // one batch of PCG iterations, captured once
   bool cg_graph_failed = false;
   // state
@@ -422,10 +425,17 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
     BA_TRY(p->upload(&p->d_pairs, pairs));
     BA_TRY(p->dalloc(&p->d_Y, (size_t)BA_Y_STRIDE * N));
     BA_TRY(p->dalloc(&p->d_bsr_val, 36 * (size_t)p->n_bsr));
-    BA_TRY(p->dalloc(&p->d_part_pq, (size_t)cg2_blocks_spmv(S) + 1));
-    BA_TRY(p->dalloc(&p->d_part_qc, ((size_t)cg2_blocks_spmv(S) + 1) * std::max(p->ncam, 1)));
-    BA_TRY(p->dalloc(&p->d_part_rz, (size_t)cg2_blocks_vec(S) + 1));
+    const size_t npart = (size_t)std::max(std::max(cg2_blocks_spmv(S), cg2_blocks_vec(S)), 1024) + 1;
+    BA_TRY(p->dalloc(&p->d_part_pq, npart));
+    BA_TRY(p->dalloc(&p->d_part_qc, npart * std::max(p->ncam, 1)));
+    BA_TRY(p->dalloc(&p->d_part_rz, npart));
     BA_TRY(p->dalloc(&p->d_cg2scal, 16));
+    BA_TRY(p->dalloc(&p->d_sync, 4));
+    {
+      int dev = 0;
+      HIP_OK(hipGetDevice(&dev));
+      HIP_OK(hipDeviceGetAttribute(&p->n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
   }
   if (C == 1 && p->ncmax > 0 && p->ncmax <= border_ncb()) BA_TRY(p->dalloc(&p->d_Jt, 2 * (size_t)border_ncb() * N));
   p->n_partial = 4 * std::max(std::max(linearize_blocks(P), cost_blocks(N)), cost_blocks(6 * (int64_t)S + 3 * (int64_t)P)) + 16;
@@ -653,6 +663,22 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
   a.S = p->S; a.ncam = p->ncam; a.rowptr = p->d_bsr_rowptr; a.col = p->d_bsr_col; a.val = p->d_bsr_val; a.Ssc = p->d_Ssc;
   a.Scc = p->d_Scc; a.Lcc = p->d_Lcc; a.Minv = p->d_Minv; a.b = p->d_b; a.x = p->d_x; a.r = p->d_r; a.z = p->d_z; a.p = p->d_p;
   a.q = p->d_q; a.scal = p->d_cg2scal; a.part_pq = p->d_part_pq; a.part_qc = p->d_part_qc; a.part_rz = p->d_part_rz;
+  if (!p->persistent_failed && opt->reserved == 0 && p->n_cu > 0) {
+    // the whole PCG loop in one launch (grid barriers instead of kernel boundaries)
+    launch_pcg_persistent(s, a, p->d_sync, opt->pcg_rtol, opt->pcg_max_iters, p->n_cu);
+    unsigned words[4] = {0, 0, 0, 0};
+    HIP_OK(hipMemcpyAsync(p->h_cgscal, p->d_cg2scal, 10 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(words, p->d_sync, sizeof words, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    BA_TRY(p->check_kernels());
+    if (words[1] == 0) {
+      *iters = (int)p->h_cgscal[3];
+      if (p->h_cgscal[8] == 2.0) return fail(BA_ERR_NUMERIC, "PCG breakdown at iteration %d (p.Sp = %g)", *iters, p->h_cgscal[4]);
+      if (!std::isfinite(p->h_cgscal[2])) return fail(BA_ERR_NUMERIC, "PCG: non-finite right-hand side");
+      return 0;
+    }
+    p->persistent_failed = true;  // a grid barrier timed out: use kernel boundaries from now on
+  }
   launch_cg2_init(s, a, opt->pcg_rtol);
   const int batch = 32;  // even, so that the parity pattern of a batch repeats
   if (!p->cg_graph && !p->cg_graph_failed) {

@@ -143,6 +143,7 @@ int cg2_blocks_vec(int S);
 void launch_cg2_init(hipStream_t s, const BsrCgArgs &a, double rtol);
 void launch_cg2_iteration(hipStream_t s, const BsrCgArgs &a, int parity);
 void launch_bsr_spmv(hipStream_t s, const BsrCgArgs &a, int parity);
+int launch_pcg_persistent(hipStream_t s, const BsrCgArgs &a, unsigned *sync_words, double rtol, int max_iters, int n_cu);
 
 // ba_chol.hip: in-place lower Cholesky of a dense row-major n x n matrix (ld = n) and the
 // solve L L^T x = b (b overwritten).  info[0] != 0 after the factorisation when a pivot was
