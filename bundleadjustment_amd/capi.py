@@ -38,7 +38,7 @@ class BaOptions(C.Structure):
         ("parameter_tolerance", C.c_double),
         ("max_num_iterations", C.c_int32), ("max_num_consecutive_invalid_steps", C.c_int32),
         ("jacobi_scaling", C.c_int32), ("linear_solver", C.c_int32),
-        ("pcg_rtol", C.c_double), ("pcg_max_iters", C.c_int32), ("reserved", C.c_int32),
+        ("pcg_rtol", C.c_double), ("pcg_max_iters", C.c_int32), ("preconditioner", C.c_int32),
     ]
 
 

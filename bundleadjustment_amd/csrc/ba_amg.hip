@@ -1,0 +1,643 @@
+// ba_amg.hip -- multilevel preconditioner for the PCG on the block-sparse reduced camera system.
+//
+// The reference hands the normal equations to a sparse direct factorisation inside Ceres
+// (src/main.cpp:4679-4721, SPARSE_NORMAL_CHOLESKY); here the reduced system is solved by PCG, and
+// block-Jacobi alone needs on the order of a thousand iterations on large strip/block networks.
+// This file builds a smoothed-aggregation hierarchy over the station graph and applies it
+// additively:
+//
+//     z = D0^-1 r + P0 ( D1^-1 P0^T r + P1 ( D2^-1 P1^T P0^T r + ... ) )
+//
+// with D_l the 6x6 diagonal blocks of the Galerkin matrices A_{l+1} = P_l^T A_l P_l and
+// P_l = (I - w_l D_l^-1 A_l) T_l the damped-Jacobi smoothed piecewise-constant prolongator of the
+// aggregates.  Every term is symmetric positive semidefinite and the first is definite, so z is a
+// valid CG preconditioner.  All sums run in a fixed order (host-built gather lists, no atomics).
+//
+// Structure (aggregates, sparsity patterns, gather lists) is built once per problem on the host
+// from the block pattern and the block norms of the first linearisation; the numeric part
+// (P_l, A_l P_l, A_{l+1}, D_{l+1}^-1) is recomputed on the device after every linearisation.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "ba_device.h"
+#include "ba_kernels.h"
+
+namespace ba {
+
+// ------------------------------------------------------------------------------------------
+// device kernels: numeric set-up
+// ------------------------------------------------------------------------------------------
+__global__ void k_amg_block_norms(int n, const double *__restrict__ val, double *__restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n) return;
+  const double *v = val + 36 * (int64_t)b;
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 36; ++k) s += v[k] * v[k];
+  out[b] = sqrt(s);
+}
+
+// P[i,c] = [agg(i) == c] I - omega Dinv_i sum_{j in row i, agg(j) == c} A_ij ; one wave per block of P
+__global__ void __launch_bounds__(256)
+k_amg_build_P(int nP, const int *__restrict__ P_row, const int *__restrict__ P_own, const int *__restrict__ Pa_ptr,
+              const int *__restrict__ Pa_idx, const double *__restrict__ A_val, const double *__restrict__ Dinv, double omega,
+              double *__restrict__ P_val) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (t >= nP) return;
+  const int e = lane < 36 ? lane : 0, r = e / 6, c = e % 6;
+  double sum = 0.0;
+  for (int k = Pa_ptr[t]; k < Pa_ptr[t + 1]; ++k) sum += A_val[36 * (int64_t)Pa_idx[k] + e];
+  const double *D = Dinv + 36 * (int64_t)P_row[t];
+  double acc = 0.0;
+#pragma unroll
+  for (int m = 0; m < 6; ++m) acc += D[6 * r + m] * __shfl(sum, 6 * m + c, 64);
+  const double own = (P_own[t] && r == c) ? 1.0 : 0.0;
+  if (lane < 36) P_val[36 * (int64_t)t + lane] = own - omega * acc;
+}
+
+// out[o] = sum_k op(X[la[k]]) Y[lb[k]], k in [ptr[o], ptr[o+1]) ; op = transpose when TRANS ; one wave per block
+template <int TRANS>
+__global__ void __launch_bounds__(256)
+k_amg_products(int n_out, const int *__restrict__ ptr, const int *__restrict__ la, const int *__restrict__ lb,
+               const double *__restrict__ X, const double *__restrict__ Y, double *__restrict__ out) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= n_out) return;
+  const int e = lane < 36 ? lane : 0, r = e / 6, c = e % 6;
+  double acc = 0.0;
+  const int beg = ptr[o], end = ptr[o + 1];
+  double xv = 0.0, yv = 0.0;
+  if (beg < end) {
+    xv = X[36 * (int64_t)la[beg] + e];
+    yv = Y[36 * (int64_t)lb[beg] + e];
+  }
+  for (int k = beg; k < end; ++k) {
+    double xn = 0.0, yn = 0.0;
+    if (k + 1 < end) {  // next pair in flight while this one is multiplied
+      xn = X[36 * (int64_t)la[k + 1] + e];
+      yn = Y[36 * (int64_t)lb[k + 1] + e];
+    }
+#pragma unroll
+    for (int m = 0; m < 6; ++m) acc += __shfl(xv, TRANS ? (6 * m + r) : (6 * r + m), 64) * __shfl(yv, 6 * m + c, 64);
+    xv = xn;
+    yv = yn;
+  }
+  if (lane < 36) out[36 * (int64_t)o + lane] = acc;
+}
+
+// x_out = Dinv A x_in ; one wave per block row (power iteration for the damping factor)
+__global__ void __launch_bounds__(256)
+k_amg_power_step(int nb, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
+                 const double *__restrict__ Dinv, const double *__restrict__ xin, double *__restrict__ xout) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= nb) return;
+  const int g = lane >> 3, r = lane & 7;
+  double s = 0.0;
+  if (r < 6)
+    for (int b = rowptr[i] + g; b < rowptr[i + 1]; b += 8) {
+      const double *B = val + 36 * (int64_t)b + 6 * r, *x = xin + 6 * (int64_t)col[b];
+#pragma unroll
+      for (int m = 0; m < 6; ++m) s += B[m] * x[m];
+    }
+  s += __shfl_xor(s, 8, 64);
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  double y = 0.0;
+  const double *D = Dinv + 36 * (int64_t)i;
+#pragma unroll
+  for (int m = 0; m < 6; ++m) y += D[6 * (lane < 6 ? lane : 0) + m] * __shfl(s, m, 64);
+  if (lane < 6) xout[6 * (int64_t)i + lane] = y;
+}
+
+__global__ void k_amg_seed(int n, double *__restrict__ x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = 0.5 + (double)((unsigned)i * 2654435761u >> 8) * (1.0 / 16777216.0);
+}
+
+__global__ void __launch_bounds__(1024)
+k_amg_norm2(int n, const double *__restrict__ x, double *__restrict__ out) {
+  __shared__ double lds[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += x[i] * x[i];
+  const double t = block_sum(s, lds);
+  if (threadIdx.x == 0) out[0] = sqrt(t);
+}
+
+// ------------------------------------------------------------------------------------------
+// device kernels: application inside the PCG iteration
+// ------------------------------------------------------------------------------------------
+struct AmgTransfer {  // between a fine level and the next coarser one
+  int nb, nc;
+  const int *P_rowptr, *P_col;
+  const double *P_val;
+  const int *Pt_ptr, *Pt_blk, *Pt_row;  // blocks of P by column
+  const double *Dinv_c;                 // inverse diagonal blocks of the coarse matrix
+  double *rc, *y;                       // coarse vectors: restricted residual, correction
+};
+// at most AMG_MAX_LEVELS levels; a level needs AMG_MIN_BLOCKS blocks, one beyond the third AMG_DEEP_BLOCKS
+// (more additive levels than that cost iterations instead of saving them)
+enum { AMG_MAX_LEVELS = 4, AMG_MIN_BLOCKS = 4, AMG_DEEP_BLOCKS = 48 };
+struct AmgApplyArgs {
+  int n_transfers;
+  AmgTransfer t[AMG_MAX_LEVELS - 1];
+  double *part;  // per-workgroup partials of rc . y from the restrictions that run as kernels of their own
+  int n_part;
+};
+
+// lanes 0..5 of a group of 8 get y = Dinv rc (rc[k] sits in lane base + k of the same group);
+// returns rc[r] * y[r] of this lane (0 for r >= 6)
+__device__ __forceinline__ double coarse_jacobi(const double *__restrict__ D, double s, int lane, int r, double *y_out) {
+  const int base = lane & ~7;
+  double y = 0.0;
+#pragma unroll
+  for (int m = 0; m < 6; ++m) y += D[6 * (r < 6 ? r : 0) + m] * __shfl(s, base + m, 64);
+  *y_out = y;
+  return r < 6 ? s * y : 0.0;
+}
+
+// restriction between two large levels: rc = P^T v, y = Dc^-1 rc ; one wave per coarse block;
+// per-workgroup partials of rc . y
+__global__ void __launch_bounds__(256)
+k_amg_restrict(AmgTransfer t, const double *__restrict__ v, double *__restrict__ part) {
+  __shared__ double lds[4];
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int g = lane >> 3, r = lane & 7;
+  double dot = 0.0;
+  if (c < t.nc) {
+    double s = 0.0;
+    if (r < 6)
+      for (int k = t.Pt_ptr[c] + g; k < t.Pt_ptr[c + 1]; k += 8) {
+        const double *P = t.P_val + 36 * (int64_t)t.Pt_blk[k] + r, *vi = v + 6 * (int64_t)t.Pt_row[k];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) s += P[6 * m] * vi[m];
+      }
+    s += __shfl_xor(s, 8, 64);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    double y;
+    const double d = coarse_jacobi(t.Dinv_c + 36 * (int64_t)c, s, lane, r, &y);
+    if (lane < 6) {
+      t.rc[6 * (int64_t)c + lane] = s;
+      t.y[6 * (int64_t)c + lane] = y;
+      dot = d;
+    }
+  }
+  const double tot = block_sum(dot, lds);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// prolongation between two large levels: yf += P yc ; 8 lanes per fine block row
+__global__ void __launch_bounds__(256)
+k_amg_prolong(AmgTransfer t, double *__restrict__ yf) {
+  const int i = blockIdx.x * 32 + (threadIdx.x >> 3), r = threadIdx.x & 7;
+  if (i >= t.nb || r >= 6) return;
+  double s = 0.0;
+  for (int k = t.P_rowptr[i]; k < t.P_rowptr[i + 1]; ++k) {
+    const double *P = t.P_val + 36 * (int64_t)k + 6 * r, *yc = t.y + 6 * (int64_t)t.P_col[k];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) s += P[m] * yc[m];
+  }
+  yf[6 * (int64_t)i + r] += s;
+}
+
+// Last kernel of an iteration.  Every workgroup folds the partials of r.z = r.D0^-1 r + sum_l rc_l.y_l
+// in the same order (identical beta everywhere); z = D0^-1 r (already in cg.z) + P0 y1;
+// p = z + beta p (mode 1) or p = z (mode 0, start of the solve); 8 lanes per station.
+// Workgroup 0 publishes the scalars for the next iteration in the other parity slot.
+__global__ void __launch_bounds__(256)
+k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restrict__ part, int n_part, int n_part_rz,
+              int parity, int mode, double rtol) {
+  __shared__ double lds[4];
+  __shared__ double rzn_s;
+  if (mode == 1) {
+    const double done = cg.scal[8 + parity];
+    if (done != 0.0) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) cg.scal[8 + (parity ^ 1)] = done;
+      return;
+    }
+  }
+  double s = 0.0;
+  for (int k = threadIdx.x; k < n_part_rz; k += blockDim.x) s += cg.part_rz[k];
+  for (int k = threadIdx.x; k < n_part; k += blockDim.x) s += part[k];
+  const double tot = block_sum(s, lds);
+  if (threadIdx.x == 0) rzn_s = tot;
+  __syncthreads();
+  const double rzn = rzn_s;
+  const double beta = (mode == 1) ? rzn / cg.scal[parity] : 0.0;
+  const int i = blockIdx.x * 32 + (threadIdx.x >> 3), r = threadIdx.x & 7;
+  if (i < cg.S && r < 6) {
+    double z = cg.z[6 * (int64_t)i + r];
+    if (has_coarse) {
+      const int k0 = t.P_rowptr[i], k1 = t.P_rowptr[i + 1];
+      for (int k = k0; k < k1; ++k) {
+        const double *P = t.P_val + 36 * (int64_t)k + 6 * r, *yc = t.y + 6 * (int64_t)t.P_col[k];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) z += P[m] * yc[m];
+      }
+    }
+    cg.p[6 * (int64_t)i + r] = (mode == 1) ? z + beta * cg.p[6 * (int64_t)i + r] : z;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t o = 6 * (int64_t)cg.S;
+    for (int k = 0; k < cg.ncam; ++k) cg.p[o + k] = (mode == 1) ? cg.z[o + k] + beta * cg.p[o + k] : cg.z[o + k];
+    if (mode == 0) {
+      cg.scal[0] = cg.scal[1] = cg.scal[2] = rzn;
+      cg.scal[3] = cg.scal[4] = cg.scal[5] = 0.0;
+      cg.scal[6] = rtol * sqrt(fmax(rzn, 0.0));
+      cg.scal[8] = cg.scal[9] = (rzn > 0.0) ? 0.0 : 1.0;
+    } else {
+      cg.scal[parity ^ 1] = rzn;
+      cg.scal[3] += 1.0;
+      const double pq = cg.scal[4];
+      double nd = 0.0;
+      if (!(pq > 0.0) || !(rzn == rzn)) nd = 2.0;
+      else if (sqrt(fmax(rzn, 0.0)) <= cg.scal[6]) nd = 1.0;
+      cg.scal[8 + (parity ^ 1)] = nd;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host: hierarchy
+// ------------------------------------------------------------------------------------------
+namespace {
+
+static inline int nblk(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
+
+struct Pattern {
+  int nb = 0;
+  std::vector<int> rowptr, col;
+};
+
+struct Level {  // transfer from level l to level l + 1 and everything the numeric set-up of it needs
+  int nb = 0, nc = 0, nA = 0, nP = 0, nAP = 0, nAc = 0;
+  double omega = 0.0;
+  // fine matrix (level 0: borrowed from the solver)
+  const int *A_rowptr = nullptr, *A_col = nullptr;
+  const double *A_val = nullptr, *Dinv = nullptr;
+  // owned device arrays
+  int *P_rowptr = nullptr, *P_col = nullptr, *P_row = nullptr, *P_own = nullptr, *Pa_ptr = nullptr, *Pa_idx = nullptr;
+  int *AP_ptr = nullptr, *AP_la = nullptr, *AP_lb = nullptr, *Ac_ptr = nullptr, *Ac_la = nullptr, *Ac_lb = nullptr;
+  int *Pt_ptr = nullptr, *Pt_blk = nullptr, *Pt_row = nullptr;
+  int *Ac_rowptr = nullptr, *Ac_col = nullptr, *Ac_diag = nullptr, *used_c = nullptr;
+  double *P_val = nullptr, *AP_val = nullptr, *Ac_val = nullptr, *Dinv_c = nullptr, *rc = nullptr, *y = nullptr;
+};
+
+}  // namespace
+
+struct Amg {
+  std::vector<Level> levels;
+  std::vector<void *> allocs;
+  double *d_tmp = nullptr, *d_tmp2 = nullptr, *d_part = nullptr, *d_norm = nullptr;
+  unsigned *d_flags = nullptr;
+  int n_part = 0;  // per-workgroup partials of all restrictions
+  char err[256] = {0};
+
+  template <class T>
+  bool dalloc(T **p, size_t n) {
+    void *q = nullptr;
+    if (hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) {
+      snprintf(err, sizeof err, "multilevel preconditioner: hipMalloc of %zu bytes failed", n * sizeof(T));
+      return false;
+    }
+    allocs.push_back(q);
+    *p = static_cast<T *>(q);
+    return true;
+  }
+  template <class T>
+  bool upload(T **p, const std::vector<T> &v) {
+    if (!dalloc(p, v.size())) return false;
+    if (!v.empty() && hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
+      snprintf(err, sizeof err, "multilevel preconditioner: upload failed");
+      return false;
+    }
+    return true;
+  }
+  void release() {
+    for (void *q : allocs) (void)hipFree(q);
+    allocs.clear();
+    levels.clear();
+  }
+};
+
+namespace {
+
+// Greedy aggregation (Vanek et al.): a neighbour j of i is strong when
+// |A_ij| / sqrt(|A_ii| |A_jj|) >= theta * (largest such ratio in row i), |.| = Frobenius norm.
+void aggregate(const Pattern &A, const std::vector<double> &fro, double theta, std::vector<int> &agg, int &nc) {
+  const int nb = A.nb;
+  std::vector<double> dg(nb, 0.0);
+  for (int i = 0; i < nb; ++i)
+    for (int b = A.rowptr[i]; b < A.rowptr[i + 1]; ++b)
+      if (A.col[b] == i) dg[i] = fro[b];
+  std::vector<double> sij(A.col.size(), 0.0);
+  std::vector<char> strong(A.col.size(), 0);
+  for (int i = 0; i < nb; ++i) {
+    double rmax = 0.0;
+    for (int b = A.rowptr[i]; b < A.rowptr[i + 1]; ++b) {
+      const int j = A.col[b];
+      if (j == i) continue;
+      const double d = dg[i] * dg[j];
+      sij[b] = d > 0.0 ? fro[b] / std::sqrt(d) : 0.0;
+      rmax = std::max(rmax, sij[b]);
+    }
+    for (int b = A.rowptr[i]; b < A.rowptr[i + 1]; ++b)
+      strong[b] = (A.col[b] != i && sij[b] > 0.0 && sij[b] >= theta * rmax) ? 1 : 0;
+  }
+  agg.assign(nb, -1);
+  nc = 0;
+  for (int i = 0; i < nb; ++i) {  // roots whose strong neighbourhood is untouched
+    if (agg[i] >= 0) continue;
+    bool free_nb = true;
+    for (int b = A.rowptr[i]; b < A.rowptr[i + 1] && free_nb; ++b)
+      if (strong[b] && agg[A.col[b]] >= 0) free_nb = false;
+    if (!free_nb) continue;
+    agg[i] = nc;
+    for (int b = A.rowptr[i]; b < A.rowptr[i + 1]; ++b)
+      if (strong[b]) agg[A.col[b]] = nc;
+    ++nc;
+  }
+  const std::vector<int> first = agg;
+  for (int i = 0; i < nb; ++i) {  // leftovers join the aggregate of their strongest aggregated neighbour
+    if (agg[i] >= 0) continue;
+    double best = 0.0;
+    int to = -1;
+    for (int b = A.rowptr[i]; b < A.rowptr[i + 1]; ++b)
+      if (strong[b] && first[A.col[b]] >= 0 && sij[b] > best) {
+        best = sij[b];
+        to = first[A.col[b]];
+      }
+    if (to >= 0) agg[i] = to;
+  }
+  for (int i = 0; i < nb; ++i) {  // whatever is still free forms aggregates of its own
+    if (agg[i] >= 0) continue;
+    agg[i] = nc;
+    for (int b = A.rowptr[i]; b < A.rowptr[i + 1]; ++b)
+      if (strong[b] && agg[A.col[b]] < 0) agg[A.col[b]] = nc;
+    ++nc;
+  }
+}
+
+struct Symbolic {
+  std::vector<int> P_rowptr, P_col, P_row, P_own, Pa_ptr, Pa_idx;
+  std::vector<int> AP_rowptr, AP_col, AP_ptr, AP_la, AP_lb;
+  std::vector<int> Ac_ptr, Ac_la, Ac_lb, Ac_diag;
+  std::vector<int> Pt_ptr, Pt_blk, Pt_row, used_c;
+  Pattern Ac;
+};
+
+void symbolic(const Pattern &A, const std::vector<int> &agg, int nc, const std::vector<int> &used, Symbolic &sy) {
+  const int nb = A.nb;
+  // ---- P: one block per (row, aggregate seen in the row)
+  sy.P_rowptr.assign(nb + 1, 0);
+  sy.Pa_ptr.assign(1, 0);
+  std::vector<std::pair<int, int>> tmp;
+  for (int i = 0; i < nb; ++i) {
+    tmp.clear();
+    for (int b = A.rowptr[i]; b < A.rowptr[i + 1]; ++b) tmp.emplace_back(agg[A.col[b]], b);
+    std::sort(tmp.begin(), tmp.end());
+    for (size_t k = 0; k < tmp.size(); ++k) {
+      if (k == 0 || tmp[k].first != tmp[k - 1].first) {
+        if (k) sy.Pa_ptr.push_back((int)sy.Pa_idx.size());
+        sy.P_col.push_back(tmp[k].first);
+        sy.P_row.push_back(i);
+        sy.P_own.push_back(tmp[k].first == agg[i] ? 1 : 0);
+      }
+      sy.Pa_idx.push_back(tmp[k].second);
+    }
+    if (!tmp.empty()) sy.Pa_ptr.push_back((int)sy.Pa_idx.size());
+    sy.P_rowptr[i + 1] = (int)sy.P_col.size();
+  }
+  const int nP = (int)sy.P_col.size();
+  // ---- A P: row i = union of the rows of P over the neighbours of i
+  sy.AP_rowptr.assign(nb + 1, 0);
+  sy.AP_ptr.assign(1, 0);
+  std::vector<std::pair<int, std::pair<int, int>>> tri;
+  for (int i = 0; i < nb; ++i) {
+    tri.clear();
+    for (int b = A.rowptr[i]; b < A.rowptr[i + 1]; ++b) {
+      const int j = A.col[b];
+      for (int t = sy.P_rowptr[j]; t < sy.P_rowptr[j + 1]; ++t) tri.push_back({sy.P_col[t], {b, t}});
+    }
+    std::sort(tri.begin(), tri.end());
+    for (size_t k = 0; k < tri.size(); ++k) {
+      if (k == 0 || tri[k].first != tri[k - 1].first) {
+        if (k) sy.AP_ptr.push_back((int)sy.AP_la.size());
+        sy.AP_col.push_back(tri[k].first);
+      }
+      sy.AP_la.push_back(tri[k].second.first);
+      sy.AP_lb.push_back(tri[k].second.second);
+    }
+    if (!tri.empty()) sy.AP_ptr.push_back((int)sy.AP_la.size());
+    sy.AP_rowptr[i + 1] = (int)sy.AP_col.size();
+  }
+  // ---- A_c = P^T (A P)
+  struct Ent {
+    int64_t key;
+    int t, u;
+  };
+  std::vector<Ent> ent;
+  for (int i = 0; i < nb; ++i)
+    for (int t = sy.P_rowptr[i]; t < sy.P_rowptr[i + 1]; ++t)
+      for (int u = sy.AP_rowptr[i]; u < sy.AP_rowptr[i + 1]; ++u)
+        ent.push_back({(int64_t)sy.P_col[t] * nc + sy.AP_col[u], t, u});
+  std::stable_sort(ent.begin(), ent.end(), [](const Ent &a, const Ent &b) { return a.key < b.key; });
+  sy.Ac.nb = nc;
+  sy.Ac.rowptr.assign(nc + 1, 0);
+  sy.Ac_ptr.assign(1, 0);
+  sy.Ac_diag.assign(nc, 0);
+  for (size_t k = 0; k < ent.size(); ++k) {
+    if (k == 0 || ent[k].key != ent[k - 1].key) {
+      if (k) sy.Ac_ptr.push_back((int)sy.Ac_la.size());
+      const int c = (int)(ent[k].key / nc), d = (int)(ent[k].key % nc);
+      if (c == d) sy.Ac_diag[c] = (int)sy.Ac.col.size();
+      sy.Ac.col.push_back(d);
+      sy.Ac.rowptr[c + 1] += 1;
+    }
+    sy.Ac_la.push_back(ent[k].t);
+    sy.Ac_lb.push_back(ent[k].u);
+  }
+  if (!ent.empty()) sy.Ac_ptr.push_back((int)sy.Ac_la.size());
+  for (int c = 0; c < nc; ++c) sy.Ac.rowptr[c + 1] += sy.Ac.rowptr[c];
+  // ---- P by column (restriction), coarse "has observations" flags
+  sy.Pt_ptr.assign(nc + 1, 0);
+  for (int t = 0; t < nP; ++t) sy.Pt_ptr[sy.P_col[t] + 1] += 1;
+  for (int c = 0; c < nc; ++c) sy.Pt_ptr[c + 1] += sy.Pt_ptr[c];
+  sy.Pt_blk.resize(nP);
+  sy.Pt_row.resize(nP);
+  std::vector<int> fill(sy.Pt_ptr.begin(), sy.Pt_ptr.end() - 1);
+  for (int t = 0; t < nP; ++t) {
+    const int k = fill[sy.P_col[t]]++;
+    sy.Pt_blk[k] = t;
+    sy.Pt_row[k] = sy.P_row[t];
+  }
+  sy.used_c.assign(nc, 0);
+  for (int i = 0; i < nb; ++i)
+    if (used[i]) sy.used_c[agg[i]] = 1;
+}
+
+void numeric_level(hipStream_t s, const Level &L, unsigned *flags) {
+  hipLaunchKernelGGL(k_amg_build_P, dim3(nblk(L.nP, 4)), dim3(256), 0, s, L.nP, L.P_row, L.P_own, L.Pa_ptr, L.Pa_idx, L.A_val,
+                     L.Dinv, L.omega, L.P_val);
+  hipLaunchKernelGGL(k_amg_products<0>, dim3(nblk(L.nAP, 4)), dim3(256), 0, s, L.nAP, L.AP_ptr, L.AP_la, L.AP_lb, L.A_val,
+                     L.P_val, L.AP_val);
+  hipLaunchKernelGGL(k_amg_products<1>, dim3(nblk(L.nAc, 4)), dim3(256), 0, s, L.nAc, L.Ac_ptr, L.Ac_la, L.Ac_lb, L.P_val,
+                     L.AP_val, L.Ac_val);
+  launch_invert_blocks(s, L.nc, L.Ac_val, L.Ac_diag, L.used_c, L.Dinv_c, flags);
+}
+
+}  // namespace
+
+Amg *amg_create() { return new Amg(); }
+void amg_destroy(Amg *a) {
+  if (!a) return;
+  a->release();
+  delete a;
+}
+const char *amg_error(const Amg *a) { return a->err; }
+int amg_levels(const Amg *a) { return (int)a->levels.size() + 1; }
+int amg_level_blocks(const Amg *a, int level) {
+  if (level == 0) return a->levels.empty() ? 0 : a->levels[0].nb;
+  return a->levels[level - 1].nc;
+}
+
+// Builds the hierarchy for the matrix (rowptr, col) whose current values are d_val (device) with
+// inverse diagonal blocks d_Dinv; also runs the first numeric set-up.  Returns 0, or -1 with
+// amg_error() set.  A hierarchy with no coarse level (amg_levels() == 1) is a valid outcome.
+int amg_build(Amg *a, hipStream_t s, int nb0, const std::vector<int> &rowptr, const std::vector<int> &col,
+              const std::vector<int> &used0, const int *d_rowptr, const int *d_col, const double *d_val, const double *d_Dinv,
+              double theta) {
+  a->release();
+  Pattern A;
+  A.nb = nb0;
+  A.rowptr = rowptr;
+  A.col = col;
+  std::vector<int> used = used0;
+  const int *dA_rowptr = d_rowptr, *dA_col = d_col;
+  const double *dA_val = d_val, *dDinv = d_Dinv;
+  const size_t n0 = 6 * (size_t)std::max(nb0, 1);
+  size_t tmp_cap = std::max(n0, col.size());
+  if (!a->dalloc(&a->d_tmp, tmp_cap) || !a->dalloc(&a->d_tmp2, n0) || !a->dalloc(&a->d_norm, 2) || !a->dalloc(&a->d_flags, 1))
+    return -1;
+  (void)hipMemsetAsync(a->d_flags, 0, sizeof(unsigned), s);
+  for (int l = 0; l < AMG_MAX_LEVELS - 1 && A.nb >= 2 * AMG_MIN_BLOCKS; ++l) {
+    const int nA = (int)A.col.size();
+    std::vector<double> fro(nA);
+    if ((size_t)nA > tmp_cap) {
+      tmp_cap = (size_t)nA;
+      if (!a->dalloc(&a->d_tmp, tmp_cap)) return -1;
+    }
+    hipLaunchKernelGGL(k_amg_block_norms, dim3(nblk(nA, 256)), dim3(256), 0, s, nA, dA_val, a->d_tmp);
+    if (hipMemcpyAsync(fro.data(), a->d_tmp, nA * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+      snprintf(a->err, sizeof a->err, "multilevel preconditioner: reading the block norms failed");
+      return -1;
+    }
+    std::vector<int> agg;
+    int nc = 0;
+    aggregate(A, fro, theta, agg, nc);
+    if (nc < AMG_MIN_BLOCKS || (l >= 2 && nc < AMG_DEEP_BLOCKS) || (int64_t)nc * 10 > (int64_t)A.nb * 9) break;  // no useful coarsening left
+    Symbolic sy;
+    symbolic(A, agg, nc, used, sy);
+    Level L;
+    L.nb = A.nb; L.nc = nc; L.nA = nA; L.nP = (int)sy.P_col.size(); L.nAP = (int)sy.AP_col.size(); L.nAc = (int)sy.Ac.col.size();
+    L.A_rowptr = dA_rowptr; L.A_col = dA_col; L.A_val = dA_val; L.Dinv = dDinv;
+    bool ok = a->upload(&L.P_rowptr, sy.P_rowptr) && a->upload(&L.P_col, sy.P_col) && a->upload(&L.P_row, sy.P_row) &&
+              a->upload(&L.P_own, sy.P_own) && a->upload(&L.Pa_ptr, sy.Pa_ptr) && a->upload(&L.Pa_idx, sy.Pa_idx) &&
+              a->upload(&L.AP_ptr, sy.AP_ptr) && a->upload(&L.AP_la, sy.AP_la) && a->upload(&L.AP_lb, sy.AP_lb) &&
+              a->upload(&L.Ac_ptr, sy.Ac_ptr) && a->upload(&L.Ac_la, sy.Ac_la) && a->upload(&L.Ac_lb, sy.Ac_lb) &&
+              a->upload(&L.Pt_ptr, sy.Pt_ptr) && a->upload(&L.Pt_blk, sy.Pt_blk) && a->upload(&L.Pt_row, sy.Pt_row) &&
+              a->upload(&L.Ac_rowptr, sy.Ac.rowptr) && a->upload(&L.Ac_col, sy.Ac.col) && a->upload(&L.Ac_diag, sy.Ac_diag) &&
+              a->upload(&L.used_c, sy.used_c) && a->dalloc(&L.P_val, 36 * (size_t)L.nP) &&
+              a->dalloc(&L.AP_val, 36 * (size_t)L.nAP) && a->dalloc(&L.Ac_val, 36 * (size_t)L.nAc) &&
+              a->dalloc(&L.Dinv_c, 36 * (size_t)nc) && a->dalloc(&L.rc, 6 * (size_t)nc) && a->dalloc(&L.y, 6 * (size_t)nc);
+    if (!ok) return -1;
+    // damping factor from the spectral radius of Dinv A (power iteration, fixed start vector)
+    {
+      const int n = 6 * A.nb, steps = 20;
+      double *x0 = a->d_tmp, *x1 = a->d_tmp2;
+      hipLaunchKernelGGL(k_amg_seed, dim3(nblk(n, 256)), dim3(256), 0, s, n, x0);
+      for (int k = 0; k < steps; ++k) {
+        if (k == steps - 1) hipLaunchKernelGGL(k_amg_norm2, dim3(1), dim3(1024), 0, s, n, x0, a->d_norm);
+        hipLaunchKernelGGL(k_amg_power_step, dim3(nblk(A.nb, 4)), dim3(256), 0, s, A.nb, dA_rowptr, dA_col, dA_val, dDinv, x0, x1);
+        std::swap(x0, x1);
+      }
+      hipLaunchKernelGGL(k_amg_norm2, dim3(1), dim3(1024), 0, s, n, x0, a->d_norm + 1);
+      double nrm[2] = {0.0, 0.0};
+      if (hipMemcpyAsync(nrm, a->d_norm, sizeof nrm, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        snprintf(a->err, sizeof a->err, "multilevel preconditioner: power iteration failed");
+        return -1;
+      }
+      double rho = (nrm[0] > 0.0 && std::isfinite(nrm[1])) ? nrm[1] / nrm[0] : 0.0;
+      if (!(rho > 1.0)) rho = 1.0;  // the diagonal blocks alone give 1
+      L.omega = 4.0 / (3.0 * rho);
+    }
+    numeric_level(s, L, a->d_flags);
+    a->levels.push_back(L);
+    A = sy.Ac;
+    used = sy.used_c;
+    dA_rowptr = L.Ac_rowptr; dA_col = L.Ac_col; dA_val = L.Ac_val; dDinv = L.Dinv_c;
+  }
+  a->n_part = 0;
+  for (const Level &L : a->levels) a->n_part += nblk(L.nc, 4);
+  if (!a->dalloc(&a->d_part, (size_t)a->n_part)) return -1;
+  if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) {
+    snprintf(a->err, sizeof a->err, "multilevel preconditioner: set-up kernels failed");
+    return -1;
+  }
+  return 0;
+}
+
+// numeric set-up for new matrix values (same pattern); level 0 pointers may have moved
+void amg_numeric(Amg *a, hipStream_t s, const double *d_val, const double *d_Dinv) {
+  if (a->levels.empty()) return;
+  a->levels[0].A_val = d_val;
+  a->levels[0].Dinv = d_Dinv;
+  for (const Level &L : a->levels) numeric_level(s, L, a->d_flags);
+}
+
+static AmgApplyArgs apply_args(const Amg *a) {
+  AmgApplyArgs aa{};
+  aa.n_transfers = (int)a->levels.size();
+  for (int l = 0; l < aa.n_transfers; ++l) {
+    const Level &L = a->levels[l];
+    AmgTransfer &t = aa.t[l];
+    t.nb = L.nb; t.nc = L.nc; t.P_rowptr = L.P_rowptr; t.P_col = L.P_col; t.P_val = L.P_val; t.Pt_ptr = L.Pt_ptr;
+    t.Pt_blk = L.Pt_blk; t.Pt_row = L.Pt_row; t.Dinv_c = L.Dinv_c; t.rc = L.rc; t.y = L.y;
+  }
+  aa.part = a->d_part;
+  aa.n_part = a->n_part;
+  return aa;
+}
+
+// preconditioner part of one PCG iteration: after the vector kernel has left r, z = D0^-1 r and
+// the partials of r.z, finish z, the scalars and p.  mode 0 right after the start-up kernel.
+static void amg_finish_iteration(hipStream_t s, const BsrCgArgs &cg, const Amg *a, int parity, int mode, double rtol) {
+  const AmgApplyArgs aa = apply_args(a);
+  int off = 0;
+  for (int l = 0; l < aa.n_transfers; ++l) {
+    const int nb = nblk(aa.t[l].nc, 4);
+    hipLaunchKernelGGL(k_amg_restrict, dim3(nb), dim3(256), 0, s, aa.t[l], l == 0 ? cg.r : aa.t[l - 1].rc, aa.part + off);
+    off += nb;
+  }
+  for (int l = aa.n_transfers - 1; l >= 1; --l)
+    hipLaunchKernelGGL(k_amg_prolong, dim3(nblk(aa.t[l].nb, 32)), dim3(256), 0, s, aa.t[l], aa.t[l - 1].y);
+  hipLaunchKernelGGL(k_amg_update2, dim3(nblk(cg.S, 32) > 0 ? nblk(cg.S, 32) : 1), dim3(256), 0, s, cg, aa.t[0],
+                     aa.n_transfers > 0 ? 1 : 0, aa.part, aa.n_part, cg2_blocks_vec(cg.S), parity, mode, rtol);
+}
+
+void launch_amg_cg_init(hipStream_t s, const BsrCgArgs &cg, const Amg *a, double rtol) {
+  launch_cg2_start(s, cg);
+  amg_finish_iteration(s, cg, a, 0, 0, rtol);
+}
+
+void launch_amg_cg_iteration(hipStream_t s, const BsrCgArgs &cg, const Amg *a, int parity) {
+  launch_cg2_spmv_update1(s, cg, parity);
+  amg_finish_iteration(s, cg, a, parity, 1, 0.0);
+}
+
+}  // namespace ba

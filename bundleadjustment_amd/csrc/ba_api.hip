@@ -109,11 +109,10 @@ struct ba_problem {
   double *d_part_pq = nullptr, *d_part_qc = nullptr, *d_part_rz = nullptr, *d_cg2scal = nullptr;
   std::vector<int> ub_lo_h, ub_hi_h, bsr_rowptr_h, bsr_col_h;  // host copies of the block structure
   std::vector<int> cam_used_h;
-  unsigned *d_sync = nullptr;  // grid-barrier words of the persistent PCG kernel
-  int n_cu = 0;
-  bool persistent_failed = false;
   hipGraphExec_t cg_graph = nullptr;  // one batch of PCG iterations, captured once
   bool cg_graph_failed = false;
+  int cg_graph_precond = -1;          // preconditioner the captured batch was recorded with
+  ba::Amg *amg = nullptr;             // multilevel preconditioner (built at the first PCG solve)
   // state
   bool have_params = false;
   // multi-GPU
@@ -430,12 +429,6 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
     BA_TRY(p->dalloc(&p->d_part_qc, npart * std::max(p->ncam, 1)));
     BA_TRY(p->dalloc(&p->d_part_rz, npart));
     BA_TRY(p->dalloc(&p->d_cg2scal, 16));
-    BA_TRY(p->dalloc(&p->d_sync, 4));
-    {
-      int dev = 0;
-      HIP_OK(hipGetDevice(&dev));
-      HIP_OK(hipDeviceGetAttribute(&p->n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
   }
   if (C == 1 && p->ncmax > 0 && p->ncmax <= border_ncb()) BA_TRY(p->dalloc(&p->d_Jt, 2 * (size_t)border_ncb() * N));
   p->n_partial = 4 * std::max(std::max(linearize_blocks(P), cost_blocks(N)), cost_blocks(6 * (int64_t)S + 3 * (int64_t)P)) + 16;
@@ -663,30 +656,43 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
   a.S = p->S; a.ncam = p->ncam; a.rowptr = p->d_bsr_rowptr; a.col = p->d_bsr_col; a.val = p->d_bsr_val; a.Ssc = p->d_Ssc;
   a.Scc = p->d_Scc; a.Lcc = p->d_Lcc; a.Minv = p->d_Minv; a.b = p->d_b; a.x = p->d_x; a.r = p->d_r; a.z = p->d_z; a.p = p->d_p;
   a.q = p->d_q; a.scal = p->d_cg2scal; a.part_pq = p->d_part_pq; a.part_qc = p->d_part_qc; a.part_rz = p->d_part_rz;
-  if (!p->persistent_failed && opt->reserved == 0 && p->n_cu > 0) {
-    // the whole PCG loop in one launch (grid barriers instead of kernel boundaries)
-    launch_pcg_persistent(s, a, p->d_sync, opt->pcg_rtol, opt->pcg_max_iters, p->n_cu);
-    unsigned words[4] = {0, 0, 0, 0};
-    HIP_OK(hipMemcpyAsync(p->h_cgscal, p->d_cg2scal, 10 * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_OK(hipMemcpyAsync(words, p->d_sync, sizeof words, hipMemcpyDeviceToHost, s));
-    HIP_OK(hipStreamSynchronize(s));
-    BA_TRY(p->check_kernels());
-    if (words[1] == 0) {
-      *iters = (int)p->h_cgscal[3];
-      if (p->h_cgscal[8] == 2.0) return fail(BA_ERR_NUMERIC, "PCG breakdown at iteration %d (p.Sp = %g)", *iters, p->h_cgscal[4]);
-      if (!std::isfinite(p->h_cgscal[2])) return fail(BA_ERR_NUMERIC, "PCG: non-finite right-hand side");
-      return 0;
+  // multilevel preconditioner: structure once (it needs the values of a first linearisation),
+  // numbers after every change of the matrix
+  bool use_amg = opt->preconditioner == 0 && p->S > 1;
+  if (use_amg) {
+    if (!p->amg) {
+      p->amg = amg_create();
+      if (amg_build(p->amg, s, p->S, p->bsr_rowptr_h, p->bsr_col_h, p->sta_used_h, p->d_bsr_rowptr, p->d_bsr_col, p->d_bsr_val,
+                    p->d_Minv, 0.5) != 0) {
+        const int rc = fail(BA_ERR_DEVICE, "%s", amg_error(p->amg));
+        amg_destroy(p->amg);
+        p->amg = nullptr;
+        return rc;
+      }
+    } else {
+      amg_numeric(p->amg, s, p->d_bsr_val, p->d_Minv);
     }
-    p->persistent_failed = true;  // a grid barrier timed out: use kernel boundaries from now on
+    if (amg_levels(p->amg) < 2) use_amg = false;  // nothing to coarsen: plain block-Jacobi
   }
-  launch_cg2_init(s, a, opt->pcg_rtol);
+  const int precond = use_amg ? 0 : 1;
+  auto iteration = [&](int parity) {
+    if (use_amg) launch_amg_cg_iteration(s, a, p->amg, parity);
+    else launch_cg2_iteration(s, a, parity);
+  };
+  if (use_amg) launch_amg_cg_init(s, a, p->amg, opt->pcg_rtol);
+  else launch_cg2_init(s, a, opt->pcg_rtol);
   const int batch = 32;  // even, so that the parity pattern of a batch repeats
+  if (p->cg_graph && p->cg_graph_precond != precond) {
+    hipGraphExecDestroy(p->cg_graph);
+    p->cg_graph = nullptr;
+  }
   if (!p->cg_graph && !p->cg_graph_failed) {
+    p->cg_graph_precond = precond;
     // the launch sequence of a batch never changes for this problem: capture it into a graph once
     hipGraph_t graph = nullptr;
     bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
     if (ok) {
-      for (int k = 0; k < batch; ++k) launch_cg2_iteration(s, a, k & 1);
+      for (int k = 0; k < batch; ++k) iteration(k & 1);
       ok = hipStreamEndCapture(s, &graph) == hipSuccess && graph != nullptr;
     }
     if (ok) ok = hipGraphInstantiate(&p->cg_graph, graph, nullptr, nullptr, 0) == hipSuccess;
@@ -709,7 +715,7 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
     if (p->cg_graph && n == batch && (it & 1) == 0) {
       HIP_OK(hipGraphLaunch(p->cg_graph, s));
     } else {
-      for (int k = 0; k < n; ++k) launch_cg2_iteration(s, a, (it + k) & 1);
+      for (int k = 0; k < n; ++k) iteration((it + k) & 1);
     }
   }
   *iters = it;
@@ -936,6 +942,7 @@ void ba_destroy(ba_problem *p) {
   if (p->stream) hipStreamSynchronize(p->stream);
   if (p->comm) ncclCommDestroy(p->comm);
   if (p->cg_graph) hipGraphExecDestroy(p->cg_graph);
+  if (p->amg) ba::amg_destroy(p->amg);
   for (void *q : p->allocs) hipFree(q);
   if (p->h_scal) hipHostFree(p->h_scal);
   if (p->h_cgscal) hipHostFree(p->h_cgscal);
@@ -1400,6 +1407,10 @@ static int sync_shards(ba_problem *p) {
   if (p->cg_graph) {
     hipGraphExecDestroy(p->cg_graph);
     p->cg_graph = nullptr;
+  }
+  if (p->amg) {  // built on the old pattern
+    amg_destroy(p->amg);
+    p->amg = nullptr;
   }
   return 0;
 }

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 struct CamRec;
 
 namespace ba {
@@ -143,7 +145,22 @@ int cg2_blocks_vec(int S);
 void launch_cg2_init(hipStream_t s, const BsrCgArgs &a, double rtol);
 void launch_cg2_iteration(hipStream_t s, const BsrCgArgs &a, int parity);
 void launch_bsr_spmv(hipStream_t s, const BsrCgArgs &a, int parity);
-int launch_pcg_persistent(hipStream_t s, const BsrCgArgs &a, unsigned *sync_words, double rtol, int max_iters, int n_cu);
+void launch_cg2_start(hipStream_t s, const BsrCgArgs &a);                     // x = 0, r = b, z = D^-1 r, partials of r.z
+void launch_cg2_spmv_update1(hipStream_t s, const BsrCgArgs &a, int parity);  // first two kernels of an iteration
+
+// ba_amg.hip: multilevel preconditioner of the PCG above
+struct Amg;
+Amg *amg_create();
+void amg_destroy(Amg *a);
+const char *amg_error(const Amg *a);
+int amg_levels(const Amg *a);
+int amg_level_blocks(const Amg *a, int level);
+int amg_build(Amg *a, hipStream_t s, int nb0, const std::vector<int> &rowptr, const std::vector<int> &col,
+              const std::vector<int> &used0, const int *d_rowptr, const int *d_col, const double *d_val, const double *d_Dinv,
+              double theta);
+void amg_numeric(Amg *a, hipStream_t s, const double *d_val, const double *d_Dinv);
+void launch_amg_cg_init(hipStream_t s, const BsrCgArgs &cg, const Amg *a, double rtol);
+void launch_amg_cg_iteration(hipStream_t s, const BsrCgArgs &cg, const Amg *a, int parity);
 
 // ba_chol.hip: in-place lower Cholesky of a dense row-major n x n matrix (ld = n) and the
 // solve L L^T x = b (b overwritten).  info[0] != 0 after the factorisation when a pivot was

@@ -555,6 +555,14 @@ void launch_cg2_init(hipStream_t s, const BsrCgArgs &a, double rtol) {
   hipLaunchKernelGGL(k_cg2_init, dim3(nb), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_cg2_init_finish, dim3(1), dim3(256), 0, s, a, nb, rtol);
 }
+void launch_cg2_start(hipStream_t s, const BsrCgArgs &a) {
+  hipLaunchKernelGGL(k_cg2_init, dim3(cg2_blocks_vec(a.S)), dim3(256), 0, s, a);
+}
+void launch_cg2_spmv_update1(hipStream_t s, const BsrCgArgs &a, int parity) {
+  const int nbs = cg2_blocks_spmv(a.S), nbv = cg2_blocks_vec(a.S);
+  if (nbs > 0) hipLaunchKernelGGL(k_bsr_spmv, dim3(nbs), dim3(64 * SPMV_WAVES), 0, s, a, parity);
+  hipLaunchKernelGGL(k_cg2_update1, dim3(nbv), dim3(256), 0, s, a, parity, nbs);
+}
 void launch_bsr_spmv(hipStream_t s, const BsrCgArgs &a, int parity) {
   const int nbs = cg2_blocks_spmv(a.S);
   if (nbs > 0) hipLaunchKernelGGL(k_bsr_spmv, dim3(nbs), dim3(64 * SPMV_WAVES), 0, s, a, parity);
@@ -564,239 +572,6 @@ void launch_cg2_iteration(hipStream_t s, const BsrCgArgs &a, int parity) {
   if (nbs > 0) hipLaunchKernelGGL(k_bsr_spmv, dim3(nbs), dim3(64 * SPMV_WAVES), 0, s, a, parity);
   hipLaunchKernelGGL(k_cg2_update1, dim3(nbv), dim3(256), 0, s, a, parity, nbs);
   hipLaunchKernelGGL(k_cg2_update2, dim3(nbv), dim3(256), 0, s, a, parity, nbv);
-}
-
-
-// ------------------------------------------------------------------------------------------
-// Persistent PCG: the whole iteration loop in ONE launch
-// ------------------------------------------------------------------------------------------
-// One workgroup per compute unit (the grid is sized from the device so that every workgroup is
-// resident), three grid-wide barriers per iteration instead of three kernel boundaries.  The
-// arithmetic, the order of every sum and the stopping rule are those of the kernels above
-// (same per-row SpMV, partials folded in index order), so the two paths agree to rounding.
-//
-// Barrier: monotonic arrival counter; producer side = workgroup barrier (all waves' stores
-// issued and waited for), one lane's agent-scope release, relaxed agent-scope add; consumer
-// side = relaxed agent-scope polling, one agent-scope acquire, workgroup barrier.  Every spin is
-// bounded: after PCG_SPIN_LIMIT polls a workgroup raises the abort word, which all pollers watch,
-// and the kernel drains; the host then falls back to the multi-kernel path.
-#define PCG_THREADS 512
-#define PCG_SPIN_LIMIT (1 << 22)
-
-struct GridBarrier {
-  unsigned *count;  // zeroed before the launch
-  unsigned *abort;  // zeroed before the launch
-  unsigned nblocks;
-  unsigned epoch;   // per-thread copy, advanced identically by all threads
-};
-
-__device__ __forceinline__ bool grid_sync(GridBarrier &gb) {
-  __syncthreads();
-  gb.epoch += 1;
-  __shared__ int ok_s;
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __hip_atomic_fetch_add(gb.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned target = gb.epoch * gb.nblocks;
-    int ok = 1;
-    unsigned spins = 0;
-    while (__hip_atomic_load(gb.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (__hip_atomic_load(gb.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
-      if (++spins > PCG_SPIN_LIMIT) {
-        __hip_atomic_store(gb.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    ok_s = ok;
-  }
-  __syncthreads();
-  return ok_s != 0;
-}
-
-// sum of n per-workgroup partials, same order in every workgroup (n <= 1024)
-__device__ __forceinline__ double fold_partials(const double *__restrict__ part, int n, int stride, double *lds, double *bc) {
-  double s = 0.0;
-  for (int k = threadIdx.x; k < n; k += blockDim.x) s += part[(int64_t)k * stride];
-  const double t = block_sum(s, lds);
-  if (threadIdx.x == 0) *bc = t;
-  __syncthreads();
-  const double v = *bc;
-  __syncthreads();
-  return v;
-}
-
-__global__ void __launch_bounds__(PCG_THREADS)
-k_pcg_persistent(BsrCgArgs a, unsigned *sync_words, double rtol, int max_iters) {
-  __shared__ double lds[PCG_THREADS / 64];
-  __shared__ double bc;
-  __shared__ double lds_qc[PCG_THREADS / 64][80];
-  __shared__ double red[80];
-  __shared__ double pcs[80];
-  GridBarrier gb{sync_words, sync_words + 1, gridDim.x, 0u};
-  const int NW = PCG_THREADS / 64;
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 3, r = lane & 7;
-  const int gthreads = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t o = 6 * (int64_t)a.S;
-  const bool cam_owner = (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0);
-  // ---- x = 0, r = b, z = M^-1 r, p = z
-  double dot = 0.0;
-  for (int i = gtid; i < a.S; i += gthreads) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      a.x[6 * (int64_t)i + k] = 0.0;
-      a.r[6 * (int64_t)i + k] = a.b[6 * (int64_t)i + k];
-    }
-    dot += station_precond(a.Minv, a.r, a.z, i);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) a.p[6 * (int64_t)i + k] = a.z[6 * (int64_t)i + k];
-  }
-  if (cam_owner && a.ncam > 0) {
-    for (int k = 0; k < a.ncam; ++k) {
-      a.x[o + k] = 0.0;
-      a.r[o + k] = a.b[o + k];
-    }
-    cam_precond(a.ncam, a.Lcc, a.r + o, a.z + o);
-    for (int k = 0; k < a.ncam; ++k) {
-      a.p[o + k] = a.z[o + k];
-      dot += a.r[o + k] * a.z[o + k];
-    }
-  }
-  {
-    const double t = block_sum(dot, lds);
-    if (threadIdx.x == 0) a.part_rz[blockIdx.x] = t;
-  }
-  if (!grid_sync(gb)) return;
-  double rz = fold_partials(a.part_rz, gridDim.x, 1, lds, &bc);
-  const double rz0 = rz, target = rtol * sqrt(fmax(rz0, 0.0));
-  int it = 0;
-  double done = (rz0 > 0.0) ? 0.0 : 1.0, last_pq = 0.0;
-  while (done == 0.0 && it < max_iters) {
-    // ---- q = S p (station rows), partials of p.q and of the camera rows
-    double pq = 0.0, tcam0 = 0.0, tcam1 = 0.0;
-    const double *pcam = a.p + o;
-    for (int i = blockIdx.x * NW + w; i < a.S; i += gridDim.x * NW) {
-      double s = 0.0;
-      if (r < 6) {
-        for (int b = a.rowptr[i] + g; b < a.rowptr[i + 1]; b += 8) {
-          const double2 *B = reinterpret_cast<const double2 *>(a.val + 36 * (int64_t)b + 6 * r);
-          const double2 *pc = reinterpret_cast<const double2 *>(a.p + 6 * (int64_t)a.col[b]);
-          const double2 b0 = B[0], b1 = B[1], b2 = B[2], p0 = pc[0], p1 = pc[1], p2 = pc[2];
-          s += b0.x * p0.x + b0.y * p0.y + b1.x * p1.x + b1.y * p1.y + b2.x * p2.x + b2.y * p2.y;
-        }
-      }
-      s += __shfl_xor(s, 8, 64);
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      if (lane < 6) {
-        const double *row = a.Ssc + (6 * (int64_t)i + lane) * a.ncam;
-        for (int k = 0; k < a.ncam; ++k) s += row[k] * pcam[k];
-        a.q[6 * (int64_t)i + lane] = s;
-        pq += s * a.p[6 * (int64_t)i + lane];
-      }
-      if (lane < a.ncam) {
-        const double *pi = a.p + 6 * (int64_t)i;
-#pragma unroll
-        for (int rr = 0; rr < 6; ++rr) tcam0 += a.Ssc[(6 * (int64_t)i + rr) * a.ncam + lane] * pi[rr];
-      }
-      if (lane + 64 < a.ncam) {
-        const double *pi = a.p + 6 * (int64_t)i;
-#pragma unroll
-        for (int rr = 0; rr < 6; ++rr) tcam1 += a.Ssc[(6 * (int64_t)i + rr) * a.ncam + lane + 64] * pi[rr];
-      }
-    }
-    pq = wave_sum(pq);
-    __syncthreads();
-    if (lane == 0) lds[w] = pq;
-    if (lane < a.ncam) lds_qc[w][lane] = tcam0;
-    if (lane + 64 < a.ncam) lds_qc[w][lane + 64] = tcam1;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double t = 0.0;
-      for (int m = 0; m < NW; ++m) t += lds[m];
-      a.part_pq[blockIdx.x] = t;
-    }
-    for (int k = threadIdx.x; k < a.ncam; k += blockDim.x) {
-      double t = 0.0;
-      for (int m = 0; m < NW; ++m) t += lds_qc[m][k];
-      a.part_qc[(int64_t)blockIdx.x * a.ncam + k] = t;
-    }
-    if (!grid_sync(gb)) return;
-    // ---- alpha; x, r, z; partials of the new r.z
-    for (int k = threadIdx.x; k < a.ncam; k += blockDim.x) pcs[k] = a.p[o + k];
-    double pqs = fold_partials(a.part_pq, gridDim.x, 1, lds, &bc);
-    for (int k = 0; k < a.ncam; ++k) {
-      const double v = fold_partials(a.part_qc + k, gridDim.x, a.ncam, lds, &bc);
-      if (threadIdx.x == 0) red[k] = v;
-    }
-    __syncthreads();
-    double qk = 0.0;
-    if (threadIdx.x < a.ncam) {
-      qk = red[threadIdx.x];
-      for (int m = 0; m < a.ncam; ++m) qk += a.Scc[threadIdx.x * a.ncam + m] * pcs[m];
-    }
-    __syncthreads();
-    if (threadIdx.x < a.ncam) red[threadIdx.x] = qk;
-    __syncthreads();
-    for (int k = 0; k < a.ncam; ++k) pqs += red[k] * pcs[k];  // same order in every thread
-    last_pq = pqs;
-    const double alpha = rz / pqs;
-    dot = 0.0;
-    for (int i = gtid; i < a.S; i += gthreads) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        a.x[6 * (int64_t)i + k] += alpha * a.p[6 * (int64_t)i + k];
-        a.r[6 * (int64_t)i + k] -= alpha * a.q[6 * (int64_t)i + k];
-      }
-      dot += station_precond(a.Minv, a.r, a.z, i);
-    }
-    if (cam_owner) {
-      for (int k = 0; k < a.ncam; ++k) {
-        a.x[o + k] += alpha * pcs[k];
-        a.r[o + k] -= alpha * red[k];
-      }
-      if (a.ncam > 0) cam_precond(a.ncam, a.Lcc, a.r + o, a.z + o);
-      for (int k = 0; k < a.ncam; ++k) dot += a.r[o + k] * a.z[o + k];
-    }
-    {
-      const double t = block_sum(dot, lds);
-      if (threadIdx.x == 0) a.part_rz[blockIdx.x] = t;
-    }
-    if (!grid_sync(gb)) return;
-    // ---- beta; p; stopping test (identical in every workgroup)
-    const double rzn = fold_partials(a.part_rz, gridDim.x, 1, lds, &bc);
-    const double beta = rzn / rz;
-    for (int i = gtid; i < a.S; i += gthreads) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) a.p[6 * (int64_t)i + k] = a.z[6 * (int64_t)i + k] + beta * a.p[6 * (int64_t)i + k];
-    }
-    if (cam_owner)
-      for (int k = 0; k < a.ncam; ++k) a.p[o + k] = a.z[o + k] + beta * a.p[o + k];
-    rz = rzn;
-    ++it;
-    if (!(pqs > 0.0) || !(rzn == rzn)) done = 2.0;
-    else if (sqrt(fmax(rzn, 0.0)) <= target) done = 1.0;
-    if (!grid_sync(gb)) return;  // p is complete before the next SpMV reads it
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    a.scal[0] = a.scal[1] = rz;
-    a.scal[2] = rz0;
-    a.scal[3] = (double)it;
-    a.scal[4] = last_pq;
-    a.scal[8] = a.scal[9] = done;
-  }
-}
-
-// returns the number of workgroups used (0 when the problem is too small to bother)
-int launch_pcg_persistent(hipStream_t s, const BsrCgArgs &a, unsigned *sync_words, double rtol, int max_iters, int n_cu) {
-  int nb = n_cu;
-  if (nb > 1024) nb = 1024;
-  if (nb < 1) return 0;
-  hipMemsetAsync(sync_words, 0, 4 * sizeof(unsigned), s);
-  hipLaunchKernelGGL(k_pcg_persistent, dim3(nb), dim3(PCG_THREADS), 0, s, a, sync_words, rtol, max_iters);
-  return nb;
 }
 
 }  // namespace ba

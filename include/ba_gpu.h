@@ -116,8 +116,8 @@ typedef struct {
   int32_t linear_solver;           /* enum ba_linear_solver */
   double pcg_rtol;                 /* PCG stops when |r|_M^-1 <= pcg_rtol * |b|_M^-1 */
   int32_t pcg_max_iters;
-  int32_t reserved;                /* 0; 1 = run the block-sparse PCG as one kernel launch per phase instead of
-                                      the single persistent launch (same arithmetic; for comparison and tests) */
+  int32_t preconditioner;          /* of BA_SOLVER_PCG_SCHUR: 0 = multilevel (smoothed aggregation over the station
+                                      graph, additive, block-Jacobi on every level); 1 = block-Jacobi only           */
 } ba_options;
 
 /* One row of the iteration log; same columns as Ceres' minimizer_progress_to_stdout table. */
