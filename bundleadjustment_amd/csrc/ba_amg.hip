@@ -159,25 +159,52 @@ __device__ __forceinline__ double coarse_jacobi(const double *__restrict__ D, do
   return r < 6 ? s * y : 0.0;
 }
 
-// restriction between two large levels: rc = P^T v, y = Dc^-1 rc ; one wave per coarse block;
-// per-workgroup partials of rc . y
+// rc[c] = sum over the blocks of column c of P^T v ; result (per r = lane & 7 < 6) in every group of
+// 8 lanes of the wave.  The indices of up to 64 blocks are fetched with one coalesced load and
+// handed round by shuffles, so that all value loads of a pass are independent of each other.
+__device__ __forceinline__ double restrict_column(const AmgTransfer &t, int c, const double *__restrict__ v, int lane) {
+  const int g = lane >> 3, r = lane & 7, rr = r < 6 ? r : 0;
+  const int k0 = t.Pt_ptr[c], k1 = t.Pt_ptr[c + 1];
+  double s = 0.0;
+  for (int kb = k0; kb < k1; kb += 64) {
+    const int n = min(64, k1 - kb);
+    const int my_blk = lane < n ? t.Pt_blk[kb + lane] : 0, my_row = lane < n ? t.Pt_row[kb + lane] : 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      double pv[4][6], vv[4][6];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = g + 8 * (4 * h + u);
+        const int blk = __shfl(my_blk, e, 64), row = __shfl(my_row, e, 64);
+        const bool on = e < n;
+        const double *P = t.P_val + 36 * (int64_t)blk + rr, *vi = v + 6 * (int64_t)row;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+          pv[u][m] = on ? P[6 * m] : 0.0;
+          vv[u][m] = on ? vi[m] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int m = 0; m < 6; ++m) s += pv[u][m] * vv[u][m];
+    }
+  }
+  s += __shfl_xor(s, 8, 64);
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  return s;
+}
+
+// restriction: rc = P^T v, y = Dc^-1 rc ; one wave per coarse block; per-workgroup partials of rc . y
 __global__ void __launch_bounds__(256)
 k_amg_restrict(AmgTransfer t, const double *__restrict__ v, double *__restrict__ part) {
   __shared__ double lds[4];
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int g = lane >> 3, r = lane & 7;
+  const int r = lane & 7;
   double dot = 0.0;
   if (c < t.nc) {
-    double s = 0.0;
-    if (r < 6)
-      for (int k = t.Pt_ptr[c] + g; k < t.Pt_ptr[c + 1]; k += 8) {
-        const double *P = t.P_val + 36 * (int64_t)t.Pt_blk[k] + r, *vi = v + 6 * (int64_t)t.Pt_row[k];
-#pragma unroll
-        for (int m = 0; m < 6; ++m) s += P[6 * m] * vi[m];
-      }
-    s += __shfl_xor(s, 8, 64);
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
+    const double s = restrict_column(t, c, v, lane);
     double y;
     const double d = coarse_jacobi(t.Dinv_c + 36 * (int64_t)c, s, lane, r, &y);
     if (lane < 6) {
@@ -190,18 +217,42 @@ k_amg_restrict(AmgTransfer t, const double *__restrict__ v, double *__restrict__
   if (threadIdx.x == 0) part[blockIdx.x] = tot;
 }
 
-// prolongation between two large levels: yf += P yc ; 8 lanes per fine block row
+// (P yc)[i][r] for the 8 lanes of a group (r = lane & 7 < 6): column indices of up to 8 blocks come
+// from one load and shuffles, so the value loads do not wait for one another
+__device__ __forceinline__ double prolong_row(const AmgTransfer &t, int i, int lane) {
+  const int r = lane & 7, rr = r < 6 ? r : 0, base = lane & ~7;
+  const int k0 = t.P_rowptr[i], k1 = t.P_rowptr[i + 1];
+  double s = 0.0;
+  for (int kb = k0; kb < k1; kb += 8) {
+    const int n = min(8, k1 - kb);
+    const int my_col = r < n ? t.P_col[kb + r] : 0;
+    double pv[8][6], yv[8][6];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int col = __shfl(my_col, base + u, 64);
+      const bool on = u < n;
+      const double *P = t.P_val + 36 * (int64_t)(kb + (on ? u : 0)) + 6 * rr, *yc = t.y + 6 * (int64_t)col;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) {
+        pv[u][m] = on ? P[m] : 0.0;
+        yv[u][m] = on ? yc[m] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int m = 0; m < 6; ++m) s += pv[u][m] * yv[u][m];
+  }
+  return s;
+}
+
+// prolongation: yf += P yc ; 8 lanes per fine block row (whole waves stay converged for the shuffles)
 __global__ void __launch_bounds__(256)
 k_amg_prolong(AmgTransfer t, double *__restrict__ yf) {
-  const int i = blockIdx.x * 32 + (threadIdx.x >> 3), r = threadIdx.x & 7;
-  if (i >= t.nb || r >= 6) return;
-  double s = 0.0;
-  for (int k = t.P_rowptr[i]; k < t.P_rowptr[i + 1]; ++k) {
-    const double *P = t.P_val + 36 * (int64_t)k + 6 * r, *yc = t.y + 6 * (int64_t)t.P_col[k];
-#pragma unroll
-    for (int m = 0; m < 6; ++m) s += P[m] * yc[m];
-  }
-  yf[6 * (int64_t)i + r] += s;
+  const int i = blockIdx.x * 32 + (threadIdx.x >> 3), r = threadIdx.x & 7, lane = threadIdx.x & 63;
+  const bool on = i < t.nb;
+  const double s = prolong_row(t, on ? i : 0, lane);
+  if (on && r < 6) yf[6 * (int64_t)i + r] += s;
 }
 
 // Last kernel of an iteration.  Every workgroup folds the partials of r.z = r.D0^-1 r + sum_l rc_l.y_l
@@ -229,16 +280,10 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restr
   const double rzn = rzn_s;
   const double beta = (mode == 1) ? rzn / cg.scal[parity] : 0.0;
   const int i = blockIdx.x * 32 + (threadIdx.x >> 3), r = threadIdx.x & 7;
-  if (i < cg.S && r < 6) {
-    double z = cg.z[6 * (int64_t)i + r];
-    if (has_coarse) {
-      const int k0 = t.P_rowptr[i], k1 = t.P_rowptr[i + 1];
-      for (int k = k0; k < k1; ++k) {
-        const double *P = t.P_val + 36 * (int64_t)k + 6 * r, *yc = t.y + 6 * (int64_t)t.P_col[k];
-#pragma unroll
-        for (int m = 0; m < 6; ++m) z += P[m] * yc[m];
-      }
-    }
+  const bool on = i < cg.S;
+  const double corr = has_coarse ? prolong_row(t, on ? i : 0, threadIdx.x & 63) : 0.0;
+  if (on && r < 6) {
+    const double z = cg.z[6 * (int64_t)i + r] + corr;
     cg.p[6 * (int64_t)i + r] = (mode == 1) ? z + beta * cg.p[6 * (int64_t)i + r] : z;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {

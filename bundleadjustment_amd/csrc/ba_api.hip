@@ -105,7 +105,7 @@ struct ba_problem {
   int64_t n_pairs = 0;
   int *d_bsr_rowptr = nullptr, *d_bsr_col = nullptr, *d_ublk_cstart = nullptr;
   int2 *d_ublk_dst = nullptr, *d_pairs = nullptr;
-  double *d_Y = nullptr, *d_bsr_val = nullptr, *d_Sdiag = nullptr, *d_Jt = nullptr, *d_corner = nullptr;
+  double *d_Y = nullptr, *d_bsr_val = nullptr, *d_Sdiag = nullptr, *d_Jt = nullptr, *d_corner = nullptr, *d_campart = nullptr;
   double *d_part_pq = nullptr, *d_part_qc = nullptr, *d_part_rz = nullptr, *d_cg2scal = nullptr;
   std::vector<int> ub_lo_h, ub_hi_h, bsr_rowptr_h, bsr_col_h;  // host copies of the block structure
   std::vector<int> cam_used_h;
@@ -430,7 +430,12 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
     BA_TRY(p->dalloc(&p->d_part_rz, npart));
     BA_TRY(p->dalloc(&p->d_cg2scal, 16));
   }
-  if (C == 1 && p->ncmax > 0 && p->ncmax <= border_ncb()) BA_TRY(p->dalloc(&p->d_Jt, 2 * (size_t)border_ncb() * N));
+  if (C == 1 && p->ncmax > 0 && p->ncmax <= border_ncb() && border_ncb() == lin_ncb()) {
+    // single camera with few free parameters: the linearisation kernel also produces the camera border's inputs
+    BA_TRY(p->dalloc(&p->d_Jt, 2 * (size_t)border_ncb() * N));
+    const size_t ncorner = (size_t)border_ncb() * (border_ncb() + 1) / 2;
+    BA_TRY(p->dalloc(&p->d_campart, std::max((size_t)linearize_blocks(P) * 2 * lin_ncb(), (size_t)camera_corner_blocks(N) * ncorner)));
+  }
   p->n_partial = 4 * std::max(std::max(linearize_blocks(P), cost_blocks(N)), cost_blocks(6 * (int64_t)S + 3 * (int64_t)P)) + 16;
   BA_TRY(p->dalloc(&p->d_partial, (size_t)p->n_partial));
   BA_TRY(p->dalloc(&p->d_scal, (size_t)SC_COUNT));
@@ -526,6 +531,8 @@ int linearize(ba_problem *p, const LmState &st) {
   la.colnorm_pt = p->d_colnorm_pt; la.diag_pt = p->d_diag_pt; la.cost_partial = p->d_partial; la.flags = p->d_flags;
   la.huber_a = p->huber_a; la.lm_min = st.lm_min; la.lm_max = st.lm_max; la.radius = st.radius; la.reuse_diag = st.reuse_diag;
   la.Y = (st.reduced == 2) ? p->d_Y : nullptr;
+  la.Jt = p->d_Jt;
+  la.cam_partial = p->d_campart;
   launch_linearize(s, la);
   launch_sum_partials(s, p->d_partial, linearize_blocks(p->P), p->d_scal, SC_COST);
   BA_TRY(p->allreduce(p->d_scal + SC_COST, 1, 0));
@@ -543,8 +550,14 @@ int linearize(ba_problem *p, const LmState &st) {
   launch_station_finish(s, fa);
   // camera rows of the gradient and of the reduced right-hand side
   if (p->ncam > 0) {
-    BA_TRY(camera_rows(p, 6, p->d_g + 6 * (size_t)p->S));
-    BA_TRY(camera_rows(p, 7, p->d_b + 6 * (size_t)p->S));
+    if (p->d_Jt) {
+      launch_camera_rows_fold(s, p->d_campart, linearize_blocks(p->P), p->ncam, p->d_g + 6 * (size_t)p->S, p->d_b + 6 * (size_t)p->S);
+      BA_TRY(p->allreduce(p->d_g + 6 * (size_t)p->S, p->ncam, 0));
+      BA_TRY(p->allreduce(p->d_b + 6 * (size_t)p->S, p->ncam, 0));
+    } else {
+      BA_TRY(camera_rows(p, 6, p->d_g + 6 * (size_t)p->S));
+      BA_TRY(camera_rows(p, 7, p->d_b + 6 * (size_t)p->S));
+    }
     if (st.need_norms) {
       StationArgs sn = station_args(p, 6, BA_NCAMPAR);
       launch_station_pass(s, sn, SMODE_CAMNORM);
@@ -625,10 +638,10 @@ int build_reduced(ba_problem *p, bool explicit_blocks) {
   if (p->ncam == 0) return 0;
   if (p->d_Jt) {
     // one camera, few free parameters: the border comes out of one point sweep and one station sweep
-    launch_border_point(s, p->P, p->ncmax, p->d_pt_start, p->d_Jp, p->d_Jc, p->d_Vinv, p->d_Jt);
     StationArgs sa = station_args(p, 6, border_nacc());
     launch_border_station(s, sa, p->d_Jt);
-    launch_border_fold(s, p->S, p->ncam, p->n_chunks, p->d_sta_chunk0, p->d_part, border_nacc(), p->d_Ssc, p->d_corner);
+    launch_border_fold(s, p->S, p->ncam, p->n_chunks, p->d_sta_chunk0, p->d_part, border_nacc(), p->d_Ssc);
+    launch_camera_corner(s, p->N, p->ncmax, p->d_Jc, p->d_Jt, p->d_campart, p->d_corner);
     BA_TRY(p->allreduce(p->d_Ssc, (int64_t)ns * p->ncam, 0));
     BA_TRY(p->allreduce(p->d_corner, border_ncb() * (border_ncb() + 1) / 2, 0));
     launch_border_corner(s, p->ncam, p->d_corner, p->d_diagfull + ns, p->d_Scc);
@@ -1216,6 +1229,8 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
   la.colnorm_pt = p->d_colnorm_pt; la.diag_pt = p->d_diag_pt; la.cost_partial = p->d_partial; la.flags = p->d_flags;
   la.huber_a = p->huber_a; la.lm_min = st.lm_min; la.lm_max = st.lm_max; la.radius = st.radius; la.reuse_diag = 0;
   la.Y = p->explicit_ok ? p->d_Y : nullptr;
+  la.Jt = p->d_Jt;
+  la.cam_partial = p->d_campart;
   BsrCgArgs ba{};
   ba.S = p->S; ba.ncam = p->ncam; ba.rowptr = p->d_bsr_rowptr; ba.col = p->d_bsr_col; ba.val = p->d_bsr_val; ba.Ssc = p->d_Ssc;
   ba.Scc = p->d_Scc; ba.Lcc = p->d_Lcc; ba.Minv = p->d_Minv; ba.b = p->d_b; ba.x = p->d_x; ba.r = p->d_r; ba.z = p->d_z; ba.p = p->d_p;

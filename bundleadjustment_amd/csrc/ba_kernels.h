@@ -22,6 +22,7 @@ struct LinArgs {
   const CamRec *cam;
   double *rec, *Jp, *Jc, *Mo, *Vinv, *g_pt, *colnorm_pt, *diag_pt, *cost_partial;
   double *Y;  // may be null
+  double *Jt, *cam_partial;  // single-camera fast path (null otherwise): projected camera rows, partials of the camera sums
   unsigned *flags;
   double huber_a, lm_min, lm_max, radius;
   int reuse_diag;
@@ -92,6 +93,10 @@ struct CgArgs {
 void launch_station_prep(hipStream_t s, int S, const double *eop, const double *scale_sta, const int *sta_cam, double *sta);
 int linearize_blocks(int P);
 void launch_linearize(hipStream_t s, const LinArgs &a);
+int lin_ncb();
+void launch_camera_rows_fold(hipStream_t s, const double *cam_partial, int nblocks, int ncam, double *out_g, double *out_b);
+int camera_corner_blocks(int64_t N);
+void launch_camera_corner(hipStream_t s, int64_t N, int ncmax, const double *Jc, const double *Jt, double *part, double *corner);
 void launch_point_pass(hipStream_t s, const PointArgs &a, int mode, bool withcam);
 void launch_station_pass(hipStream_t s, const StationArgs &a, int smode);
 void launch_station_fold(hipStream_t s, int S, const int *sta_chunk0, const double *part, int stride, int ncols, double *out);
@@ -134,11 +139,9 @@ void launch_bsr_to_dense(hipStream_t s, int S, int ncam, const int *rowptr, cons
 void launch_store_border_col(hipStream_t s, int S, int ncam, int k, const double *v, double *Ssc, double *Scc);
 int border_ncb();   // largest number of free camera parameters the explicit border kernels handle
 int border_nacc();  // partial sums per chunk of the border station sweep
-void launch_border_point(hipStream_t s, int P, int ncmax, const int *pt_start, const double *Jp, const double *Jc,
-                         const double *Vinv, double *Jt);
 void launch_border_station(hipStream_t s, const StationArgs &sa, const double *Jt);
 void launch_border_fold(hipStream_t s, int S, int ncam, int n_chunks, const int *sta_chunk0, const double *part, int stride,
-                        double *Ssc, double *corner);
+                        double *Ssc);
 void launch_border_corner(hipStream_t s, int ncam, const double *corner, const double *camdiag, double *Scc);
 int cg2_blocks_spmv(int S);
 int cg2_blocks_vec(int S);

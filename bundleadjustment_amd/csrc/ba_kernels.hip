@@ -44,17 +44,35 @@ __global__ void k_station_prep(int S, const double *__restrict__ eop, const doub
 // ------------------------------------------------------------------------------------------
 // point sweep 1: residuals, Jacobians, point elimination
 // ------------------------------------------------------------------------------------------
+// One lane per object point, two walks over its observations.  The first walk only accumulates
+// what the elimination needs (V, its gradient and, when CAM1, B = sum Jc^T Jp); the second
+// evaluates the observation again and writes every per-observation record exactly once.
+// Recomputing the projection is cheaper than writing the rows, reading them back and writing
+// them a second time.
+//
+// CAM1 (one camera with at most LIN_NCB free parameters): also writes the projected camera rows
+// Jt = Jc - Jp V^-1 B^T and per-workgroup partial sums of Jc^T r (gradient) and Jc^T rhat
+// (reduced right-hand side), so that no further sweep is needed for the camera border.
+#define LIN_NCB 8
+template <bool CAM1>
 __global__ void __launch_bounds__(256)
 k_linearize(LinArgs a) {
   __shared__ double lds[8];
+  __shared__ double lds_cam[4][2 * LIN_NCB];
   const int jj = blockIdx.x * blockDim.x + threadIdx.x;
   double cost = 0.0;
+  double gc[CAM1 ? 2 * LIN_NCB : 1];
+#pragma unroll
+  for (int k = 0; k < (CAM1 ? 2 * LIN_NCB : 1); ++k) gc[k] = 0.0;
   int bad = 0;
   if (jj < a.P) {
     const int e0 = a.pt_start[jj], e1 = a.pt_start[jj + 1];
     const double X = a.xyz[3 * (int64_t)jj], Y = a.xyz[3 * (int64_t)jj + 1], Z = a.xyz[3 * (int64_t)jj + 2];
     const double s0 = a.scale_pt[3 * (int64_t)jj], s1 = a.scale_pt[3 * (int64_t)jj + 1], s2 = a.scale_pt[3 * (int64_t)jj + 2];
     double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    double B[CAM1 ? LIN_NCB : 1][3];
+#pragma unroll
+    for (int k = 0; k < (CAM1 ? LIN_NCB : 1); ++k) B[k][0] = B[k][1] = B[k][2] = 0.0;
     for (int e = e0; e < e1; ++e) {
       const ObsIn o = load_obs(a.obs, e);
       const double *st = a.sta + (int64_t)BA_STA_STRIDE * o.sta;
@@ -66,23 +84,8 @@ k_linearize(LinArgs a) {
       cost += 0.5 * huber_rho(a.huber_a, r0 * r0 + r1 * r1, sc);
       r0 *= sc;
       r1 *= sc;
-      // rows of the scaled, corrected Jacobian
-      double2 *rec = reinterpret_cast<double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const double cs = sc * st[14 + k];
-        Js[k] *= cs;
-        Js[6 + k] *= cs;
-      }
-#pragma unroll
-      for (int k = 0; k < 6; ++k) rec[k] = make_double2(Js[2 * k], Js[2 * k + 1]);
-      rec[6] = make_double2(r0, r1);
       Jp[0] *= sc * s0; Jp[1] *= sc * s1; Jp[2] *= sc * s2;
       Jp[3] *= sc * s0; Jp[4] *= sc * s1; Jp[5] *= sc * s2;
-      double2 *jp = reinterpret_cast<double2 *>(a.Jp + 6 * (int64_t)e);
-      jp[0] = make_double2(Jp[0], Jp[1]);
-      jp[1] = make_double2(Jp[2], Jp[3]);
-      jp[2] = make_double2(Jp[4], Jp[5]);
       V[0] += Jp[0] * Jp[0] + Jp[3] * Jp[3];
       V[1] += Jp[0] * Jp[1] + Jp[3] * Jp[4];
       V[2] += Jp[0] * Jp[2] + Jp[3] * Jp[5];
@@ -93,6 +96,7 @@ k_linearize(LinArgs a) {
       g[1] += Jp[1] * r0 + Jp[4] * r1;
       g[2] += Jp[2] * r0 + Jp[5] * r1;
       if (a.ncmax > 0) {
+        // free camera columns, compacted; written here, read back below and in the second walk
         const CamRec &cr = a.cam[c];
         double *jc = a.Jc + 2 * (int64_t)a.ncmax * e;
         int pos = 0;
@@ -104,6 +108,16 @@ k_linearize(LinArgs a) {
             jc[a.ncmax + pos] = dc1[p] * cs;
             ++pos;
           }
+        }
+        if (CAM1) {
+#pragma unroll
+          for (int k = 0; k < LIN_NCB; ++k)
+            if (k < a.ncmax) {
+              const double c0 = jc[k], c1 = jc[a.ncmax + k];
+              B[k][0] += c0 * Jp[0] + c1 * Jp[3];
+              B[k][1] += c0 * Jp[1] + c1 * Jp[4];
+              B[k][2] += c0 * Jp[2] + c1 * Jp[5];
+            }
         }
       }
     }
@@ -142,11 +156,41 @@ k_linearize(LinArgs a) {
     const double l00 = sqrt(Vi[0]), l10 = Vi[1] / l00, l20 = Vi[2] / l00;
     const double l11 = sqrt(Vi[3] - l10 * l10), l21 = (Vi[4] - l20 * l10) / l11;
     const double l22 = sqrt(Vi[5] - l20 * l20 - l21 * l21);
-    // second walk: M = I - Jp Vinv Jp^T, the reduced residual r - Jp Vinv g, and Y
+    double Zc[CAM1 ? LIN_NCB : 1][3];
+    if (CAM1) {
+#pragma unroll
+      for (int k = 0; k < LIN_NCB; ++k) sym3_mul(Vi, B[k][0], B[k][1], B[k][2], Zc[k][0], Zc[k][1], Zc[k][2]);
+    }
+    // second walk: the rows themselves, M = I - Jp Vinv Jp^T, the reduced residual r - Jp Vinv g, Y, Jt
     for (int e = e0; e < e1; ++e) {
-      const double2 *jp = reinterpret_cast<const double2 *>(a.Jp + 6 * (int64_t)e);
-      const double2 q0 = jp[0], q1 = jp[1], q2 = jp[2];
-      const double p0 = q0.x, p1 = q0.y, p2 = q1.x, p3 = q1.y, p4 = q2.x, p5 = q2.y;
+      const ObsIn o = load_obs(a.obs, e);
+      const double *st = a.sta + (int64_t)BA_STA_STRIDE * o.sta;
+      const int c = __double2loint(st[20]);
+      const CamIn cm = load_cam(a.cam, c);
+      double r0, r1, Js[12], Jp[6], dc0[BA_NCAMPAR], dc1[BA_NCAMPAR];
+      eval_obs<true>(o, st, X, Y, Z, cm, r0, r1, Js, Jp, dc0, dc1);
+      double sc;
+      (void)huber_rho(a.huber_a, r0 * r0 + r1 * r1, sc);
+      r0 *= sc;
+      r1 *= sc;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const double cs = sc * st[14 + k];
+        Js[k] *= cs;
+        Js[6 + k] *= cs;
+      }
+      const double p0 = Jp[0] * (sc * s0), p1 = Jp[1] * (sc * s1), p2 = Jp[2] * (sc * s2);
+      const double p3 = Jp[3] * (sc * s0), p4 = Jp[4] * (sc * s1), p5 = Jp[5] * (sc * s2);
+      const double h0 = r0 - (p0 * u0 + p1 * u1 + p2 * u2), h1 = r1 - (p3 * u0 + p4 * u1 + p5 * u2);
+      double2 *rec = reinterpret_cast<double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) rec[k] = make_double2(Js[2 * k], Js[2 * k + 1]);
+      rec[6] = make_double2(r0, r1);
+      rec[7] = make_double2(h0, h1);
+      double2 *jp = reinterpret_cast<double2 *>(a.Jp + 6 * (int64_t)e);
+      jp[0] = make_double2(p0, p1);
+      jp[1] = make_double2(p2, p3);
+      jp[2] = make_double2(p4, p5);
       double t0, t1, t2, w0, w1, w2;
       sym3_mul(Vi, p0, p1, p2, t0, t1, t2);
       sym3_mul(Vi, p3, p4, p5, w0, w1, w2);
@@ -154,28 +198,109 @@ k_linearize(LinArgs a) {
       mo[0] = 1.0 - (p0 * t0 + p1 * t1 + p2 * t2);
       mo[1] = -(p0 * w0 + p1 * w1 + p2 * w2);
       mo[2] = 1.0 - (p3 * w0 + p4 * w1 + p5 * w2);
-      double2 *rec = reinterpret_cast<double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
-      const double2 r = rec[6];
-      rec[7] = make_double2(r.x - (p0 * u0 + p1 * u1 + p2 * u2), r.y - (p3 * u0 + p4 * u1 + p5 * u2));
       if (a.Y) {
         // G = Jp L (2x3);  Y[r][m] = Js0[r] G0[m] + Js1[r] G1[m], rows padded to 4 doubles
         const double g00 = p0 * l00 + p1 * l10 + p2 * l20, g01 = p1 * l11 + p2 * l21, g02 = p2 * l22;
         const double g10 = p3 * l00 + p4 * l10 + p5 * l20, g11 = p4 * l11 + p5 * l21, g12 = p5 * l22;
         double2 *yo = reinterpret_cast<double2 *>(a.Y + (int64_t)BA_Y_STRIDE * e);
 #pragma unroll
-        for (int h = 0; h < 3; ++h) {
-          const double2 ja = rec[h], jb = rec[3 + h];  // Js row 0 and row 1, columns 2h, 2h+1
-          yo[4 * h] = make_double2(ja.x * g00 + jb.x * g10, ja.x * g01 + jb.x * g11);
-          yo[4 * h + 1] = make_double2(ja.x * g02 + jb.x * g12, 0.0);
-          yo[4 * h + 2] = make_double2(ja.y * g00 + jb.y * g10, ja.y * g01 + jb.y * g11);
-          yo[4 * h + 3] = make_double2(ja.y * g02 + jb.y * g12, 0.0);
+        for (int r = 0; r < 6; ++r) {
+          yo[2 * r] = make_double2(Js[r] * g00 + Js[6 + r] * g10, Js[r] * g01 + Js[6 + r] * g11);
+          yo[2 * r + 1] = make_double2(Js[r] * g02 + Js[6 + r] * g12, 0.0);
+        }
+      }
+      if (CAM1) {
+        const double *jc = a.Jc + 2 * (int64_t)a.ncmax * e;
+        double2 *jt = reinterpret_cast<double2 *>(a.Jt + 2 * (int64_t)LIN_NCB * e);
+        double t0v[LIN_NCB], t1v[LIN_NCB];
+#pragma unroll
+        for (int k = 0; k < LIN_NCB; ++k) {
+          t0v[k] = 0.0;
+          t1v[k] = 0.0;
+          if (k < a.ncmax) {
+            const double c0 = jc[k], c1 = jc[a.ncmax + k];
+            t0v[k] = c0 - (p0 * Zc[k][0] + p1 * Zc[k][1] + p2 * Zc[k][2]);
+            t1v[k] = c1 - (p3 * Zc[k][0] + p4 * Zc[k][1] + p5 * Zc[k][2]);
+            gc[k] += c0 * r0 + c1 * r1;
+            gc[LIN_NCB + k] += c0 * h0 + c1 * h1;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < LIN_NCB / 2; ++k) {
+          jt[k] = make_double2(t0v[2 * k], t0v[2 * k + 1]);
+          jt[LIN_NCB / 2 + k] = make_double2(t1v[2 * k], t1v[2 * k + 1]);
         }
       }
     }
   }
   const double t = block_sum(cost, lds);
   if (threadIdx.x == 0) a.cost_partial[blockIdx.x] = t;
+  if (CAM1) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 2 * LIN_NCB; ++k) {
+      const double v = wave_sum(gc[k]);
+      if (lane == 0) lds_cam[w][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * LIN_NCB)
+      a.cam_partial[(int64_t)blockIdx.x * (2 * LIN_NCB) + threadIdx.x] =
+          (lds_cam[0][threadIdx.x] + lds_cam[1][threadIdx.x]) + (lds_cam[2][threadIdx.x] + lds_cam[3][threadIdx.x]);
+  }
   if (bad) atomicOr(a.flags, 1);
+}
+
+// corner of the camera border: upper triangle of sum Jc^T Jt over all observations, one lane per
+// observation (both arrays are read as whole lines), per-workgroup partial sums
+#define LIN_NCORNER (LIN_NCB * (LIN_NCB + 1) / 2)
+__global__ void __launch_bounds__(256)
+k_camera_corner(int64_t N, int ncmax, const double *__restrict__ Jc, const double *__restrict__ Jt, double *__restrict__ part) {
+  __shared__ double lds[4][LIN_NCORNER];
+  double acc[LIN_NCORNER];
+#pragma unroll
+  for (int k = 0; k < LIN_NCORNER; ++k) acc[k] = 0.0;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < N; e += (int64_t)gridDim.x * blockDim.x) {
+    const double *jc = Jc + 2 * (int64_t)ncmax * e;
+    const double2 *jt = reinterpret_cast<const double2 *>(Jt + 2 * (int64_t)LIN_NCB * e);
+    double c0[LIN_NCB], c1[LIN_NCB], t0[LIN_NCB], t1[LIN_NCB];
+#pragma unroll
+    for (int k = 0; k < LIN_NCB; ++k) {
+      c0[k] = (k < ncmax) ? jc[k] : 0.0;
+      c1[k] = (k < ncmax) ? jc[ncmax + k] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < LIN_NCB / 2; ++k) {
+      const double2 x = jt[k], y = jt[LIN_NCB / 2 + k];
+      t0[2 * k] = x.x; t0[2 * k + 1] = x.y;
+      t1[2 * k] = y.x; t1[2 * k + 1] = y.y;
+    }
+    int idx = 0;
+#pragma unroll
+    for (int k = 0; k < LIN_NCB; ++k)
+#pragma unroll
+      for (int m = k; m < LIN_NCB; ++m) acc[idx++] += c0[k] * t0[m] + c1[k] * t1[m];
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < LIN_NCORNER; ++k) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) lds[w][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < LIN_NCORNER)
+    part[(int64_t)blockIdx.x * LIN_NCORNER + threadIdx.x] =
+        (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
+}
+
+// out[k] = sum over rows of part[row][k]: one workgroup per column, fixed order
+__global__ void __launch_bounds__(256)
+k_fold_columns(const double *__restrict__ part, int nrows, int ncols, int out_cols, double *__restrict__ out) {
+  __shared__ double lds[8];
+  const int k = blockIdx.x;
+  double s = 0.0;
+  for (int r = threadIdx.x; r < nrows; r += blockDim.x) s += part[(int64_t)r * ncols + k];
+  const double t = block_sum(s, lds);
+  if (threadIdx.x == 0 && k < out_cols) out[k] = t;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -895,7 +1020,26 @@ void launch_station_prep(hipStream_t s, int S, const double *eop, const double *
 }
 int linearize_blocks(int P) { return nblk(P, 256); }
 void launch_linearize(hipStream_t s, const LinArgs &a) {
-  if (a.P > 0) hipLaunchKernelGGL(k_linearize, dim3(nblk(a.P, 256)), dim3(256), 0, s, a);
+  if (a.P <= 0) return;
+  if (a.Jt) hipLaunchKernelGGL(k_linearize<true>, dim3(nblk(a.P, 256)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_linearize<false>, dim3(nblk(a.P, 256)), dim3(256), 0, s, a);
+}
+int lin_ncb() { return LIN_NCB; }
+// camera rows of the gradient (out_g) and of the reduced right-hand side (out_b) from the partials
+// that k_linearize<true> left; out arrays have ncam entries
+void launch_camera_rows_fold(hipStream_t s, const double *cam_partial, int nblocks, int ncam, double *out_g, double *out_b) {
+  hipLaunchKernelGGL(k_fold_columns, dim3(LIN_NCB), dim3(256), 0, s, cam_partial, nblocks, 2 * LIN_NCB, ncam, out_g);
+  hipLaunchKernelGGL(k_fold_columns, dim3(LIN_NCB), dim3(256), 0, s, cam_partial + LIN_NCB, nblocks, 2 * LIN_NCB, ncam, out_b);
+}
+int camera_corner_blocks(int64_t N) {
+  const int b = nblk(N, 256);
+  return b < 1 ? 1 : (b > 2048 ? 2048 : b);
+}
+// corner[0 .. NCB(NCB+1)/2) = upper triangle of sum Jc^T Jt
+void launch_camera_corner(hipStream_t s, int64_t N, int ncmax, const double *Jc, const double *Jt, double *part, double *corner) {
+  const int nb = camera_corner_blocks(N);
+  hipLaunchKernelGGL(k_camera_corner, dim3(nb), dim3(256), 0, s, N, ncmax, Jc, Jt, part);
+  hipLaunchKernelGGL(k_fold_columns, dim3(LIN_NCORNER), dim3(256), 0, s, part, nb, LIN_NCORNER, LIN_NCORNER, corner);
 }
 void launch_point_pass(hipStream_t s, const PointArgs &a, int mode, bool withcam) {
   if (a.P <= 0) return;

@@ -118,55 +118,11 @@ __global__ void k_store_border_col(int S, int ncam, int k, const double *__restr
 // ------------------------------------------------------------------------------------------
 // explicit border for one camera with at most 8 free parameters
 // ------------------------------------------------------------------------------------------
-// Point sweep: B = sum_a Jc_a^T Jp_a (nc x 3), Z = V^-1 B^T, then per observation the projected
-// camera Jacobian  Jt_a = Jc_a - Jp_a Z  (2 x nc).
+// The projected camera rows Jt = Jc - Jp V^-1 B^T (2 x nc per observation) come from the linearisation
+// kernel; the corner sum Jc^T Jt from k_camera_corner.
 #define NCB 8
-__global__ void __launch_bounds__(256)
-k_border_point(int P, int ncmax, const int *__restrict__ pt_start, const double *__restrict__ Jp, const double *__restrict__ Jc,
-               const double *__restrict__ Vinv, double *__restrict__ Jt) {
-  const int jj = blockIdx.x * blockDim.x + threadIdx.x;
-  if (jj >= P) return;
-  const int e0 = pt_start[jj], e1 = pt_start[jj + 1];
-  double B[NCB][3];
-#pragma unroll
-  for (int k = 0; k < NCB; ++k) B[k][0] = B[k][1] = B[k][2] = 0.0;
-  for (int e = e0; e < e1; ++e) {
-    const double *jp = Jp + 6 * (int64_t)e, *jc = Jc + 2 * (int64_t)ncmax * e;
-    const double p0 = jp[0], p1 = jp[1], p2 = jp[2], p3 = jp[3], p4 = jp[4], p5 = jp[5];
-#pragma unroll
-    for (int k = 0; k < NCB; ++k)
-      if (k < ncmax) {
-        const double c0 = jc[k], c1 = jc[ncmax + k];
-        B[k][0] += c0 * p0 + c1 * p3;
-        B[k][1] += c0 * p1 + c1 * p4;
-        B[k][2] += c0 * p2 + c1 * p5;
-      }
-  }
-  const double *vi = Vinv + 6 * (int64_t)jj;
-  const double Vi[6] = {vi[0], vi[1], vi[2], vi[3], vi[4], vi[5]};
-  double Z[NCB][3];
-#pragma unroll
-  for (int k = 0; k < NCB; ++k) sym3_mul(Vi, B[k][0], B[k][1], B[k][2], Z[k][0], Z[k][1], Z[k][2]);
-  for (int e = e0; e < e1; ++e) {
-    const double *jp = Jp + 6 * (int64_t)e, *jc = Jc + 2 * (int64_t)ncmax * e;
-    double *jt = Jt + 2 * (int64_t)NCB * e;
-    const double p0 = jp[0], p1 = jp[1], p2 = jp[2], p3 = jp[3], p4 = jp[4], p5 = jp[5];
-#pragma unroll
-    for (int k = 0; k < NCB; ++k) {
-      double t0 = 0.0, t1 = 0.0;
-      if (k < ncmax) {
-        t0 = jc[k] - (p0 * Z[k][0] + p1 * Z[k][1] + p2 * Z[k][2]);
-        t1 = jc[ncmax + k] - (p3 * Z[k][0] + p4 * Z[k][1] + p5 * Z[k][2]);
-      }
-      jt[k] = t0;
-      jt[NCB + k] = t1;
-    }
-  }
-}
-
-// Station sweep over the chunks: out[chunk][0..6*NCB) = sum Js^T Jt (6 x nc), then the upper
-// triangle of sum Jc^T Jt (nc x nc, symmetric) in out[chunk][6*NCB .. 6*NCB + NCB*(NCB+1)/2).
-#define NBORDER (6 * NCB + NCB * (NCB + 1) / 2)
+// Station sweep over the chunks: out[chunk][0..6*NCB) = sum Js^T Jt (6 x nc)
+#define NBORDER (6 * NCB)
 __global__ void __launch_bounds__(256)
 k_border_station(StationArgs a, const double *__restrict__ Jt) {
   __shared__ double lds[4 * NBORDER];
@@ -184,24 +140,18 @@ k_border_station(StationArgs a, const double *__restrict__ Jt) {
       r0[0] = j0.x; r0[1] = j0.y; r0[2] = j1.x; r0[3] = j1.y; r0[4] = j2.x; r0[5] = j2.y;
       r1[0] = j3.x; r1[1] = j3.y; r1[2] = j4.x; r1[3] = j4.y; r1[4] = j5.x; r1[5] = j5.y;
     }
-    const double *jt = Jt + 2 * (int64_t)NCB * e, *jc = a.Jc + 2 * (int64_t)a.ncmax * e;
-    double t0[NCB], t1[NCB], c0[NCB], c1[NCB];
+    const double2 *jt = reinterpret_cast<const double2 *>(Jt + 2 * (int64_t)NCB * e);
+    double t0[NCB], t1[NCB];
 #pragma unroll
-    for (int k = 0; k < NCB; ++k) {
-      t0[k] = jt[k];
-      t1[k] = jt[NCB + k];
-      c0[k] = (k < a.ncmax) ? jc[k] : 0.0;
-      c1[k] = (k < a.ncmax) ? jc[a.ncmax + k] : 0.0;
+    for (int k = 0; k < NCB / 2; ++k) {
+      const double2 x = jt[k], y = jt[NCB / 2 + k];
+      t0[2 * k] = x.x; t0[2 * k + 1] = x.y;
+      t1[2 * k] = y.x; t1[2 * k + 1] = y.y;
     }
 #pragma unroll
     for (int p = 0; p < 6; ++p)
 #pragma unroll
       for (int k = 0; k < NCB; ++k) acc[p * NCB + k] += r0[p] * t0[k] + r1[p] * t1[k];
-    int idx = 6 * NCB;
-#pragma unroll
-    for (int k = 0; k < NCB; ++k)
-#pragma unroll
-      for (int m = k; m < NCB; ++m) acc[idx++] += c0[k] * t0[m] + c1[k] * t1[m];
   }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -216,11 +166,10 @@ k_border_station(StationArgs a, const double *__restrict__ Jt) {
   }
 }
 
-// fold the border chunks: Ssc[i][r][k] (row-major, ncam columns) and the raw corner sums
+// fold the border chunks: Ssc[i][r][k] (row-major, ncam columns)
 __global__ void __launch_bounds__(256)
-k_border_fold(int S, int ncam, int n_chunks, const int *__restrict__ sta_chunk0, const double *__restrict__ part, int stride,
-              double *__restrict__ Ssc, double *__restrict__ corner /* NCB*(NCB+1)/2 */) {
-  __shared__ double lds[8];
+k_border_fold(int S, int ncam, const int *__restrict__ sta_chunk0, const double *__restrict__ part, int stride,
+              double *__restrict__ Ssc) {
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (t < 6 * (int64_t)S * ncam) {
     const int i = (int)(t / (6 * ncam));
@@ -228,14 +177,6 @@ k_border_fold(int S, int ncam, int n_chunks, const int *__restrict__ sta_chunk0,
     double s = 0.0;
     for (int ch = sta_chunk0[i]; ch < sta_chunk0[i + 1]; ++ch) s += part[(int64_t)stride * ch + r * NCB + k];
     Ssc[t] = s;
-  }
-  if (blockIdx.x == 0) {
-    for (int m = 0; m < NCB * (NCB + 1) / 2; ++m) {
-      double s = 0.0;
-      for (int ch = threadIdx.x; ch < n_chunks; ch += blockDim.x) s += part[(int64_t)stride * ch + 6 * NCB + m];
-      const double v = block_sum(s, lds);
-      if (threadIdx.x == 0) corner[m] = v;
-    }
   }
 }
 
@@ -412,27 +353,39 @@ k_cg2_update1(BsrCgArgs a, int parity, int nblk_spmv) {
   __shared__ double red[80];   // [0] p.q over the station rows, [1 + k] camera row k of S p
   __shared__ double pcs[80];   // camera part of p
   __shared__ double pq_s;
+  __shared__ double fold4[4][8];
   if (a.scal[8 + parity] != 0.0) return;
   // Every workgroup folds the SpMV partials in the same order -> identical alpha everywhere.
-  // The 1 + ncam sums are dealt to the four waves; each is one strided walk and a wave reduction.
+  // Eight sums at a time: thread t takes sum (t & 7) and every 32nd partial from (t >> 3) on, so all
+  // its loads are independent; then the 8 threads-classes are reduced across the wave and the waves.
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t o = 6 * (int64_t)a.S;
   for (int k = threadIdx.x; k < a.ncam; k += blockDim.x) pcs[k] = a.p[o + k];
-  for (int qn = w; qn < 1 + a.ncam; qn += 4) {
-    // four independent accumulators keep four loads in flight per lane (fixed order: deterministic)
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    const double *src = (qn == 0) ? a.part_pq : a.part_qc + (qn - 1);
-    const int64_t st = (qn == 0) ? 1 : a.ncam;
-    int m = lane;
-    for (; m + 192 < nblk_spmv; m += 256) {
-      s0 += src[st * m];
-      s1 += src[st * (m + 64)];
-      s2 += src[st * (m + 128)];
-      s3 += src[st * (m + 192)];
+  for (int q0 = 0; q0 < 1 + a.ncam; q0 += 8) {
+    const int qn = q0 + (threadIdx.x & 7);
+    double s = 0.0;
+    if (qn < 1 + a.ncam) {
+      const double *src = (qn == 0) ? a.part_pq : a.part_qc + (qn - 1);
+      const int64_t st = (qn == 0) ? 1 : a.ncam;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int m = threadIdx.x >> 3;
+      for (; m + 96 < nblk_spmv; m += 128) {
+        s0 += src[st * m];
+        s1 += src[st * (m + 32)];
+        s2 += src[st * (m + 64)];
+        s3 += src[st * (m + 96)];
+      }
+      for (; m < nblk_spmv; m += 32) s0 += src[st * m];
+      s = (s0 + s1) + (s2 + s3);
     }
-    for (; m < nblk_spmv; m += 64) s0 += src[st * m];
-    double s = wave_sum((s0 + s1) + (s2 + s3));
-    if (lane == 0) red[qn] = s;
+    s += __shfl_xor(s, 8, 64);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    __syncthreads();
+    if (lane < 8) fold4[w][lane] = s;
+    __syncthreads();
+    if (threadIdx.x < 8 && q0 + threadIdx.x < 1 + a.ncam)
+      red[q0 + threadIdx.x] = (fold4[0][threadIdx.x] + fold4[1][threadIdx.x]) + (fold4[2][threadIdx.x] + fold4[3][threadIdx.x]);
   }
   __syncthreads();
   // camera rows: add the corner, S_cc p_c
@@ -530,24 +483,22 @@ void launch_store_border_col(hipStream_t s, int S, int ncam, int k, const double
 }
 int border_ncb() { return NCB; }
 int border_nacc() { return NBORDER; }
-void launch_border_point(hipStream_t s, int P, int ncmax, const int *pt_start, const double *Jp, const double *Jc,
-                         const double *Vinv, double *Jt) {
-  if (P > 0) hipLaunchKernelGGL(k_border_point, dim3(nblk(P, 256)), dim3(256), 0, s, P, ncmax, pt_start, Jp, Jc, Vinv, Jt);
-}
 void launch_border_station(hipStream_t s, const StationArgs &sa, const double *Jt) {
   if (sa.n_chunks > 0) hipLaunchKernelGGL(k_border_station, dim3(sa.n_chunks), dim3(256), 0, s, sa, Jt);
 }
 void launch_border_fold(hipStream_t s, int S, int ncam, int n_chunks, const int *sta_chunk0, const double *part, int stride,
-                        double *Ssc, double *corner) {
+                        double *Ssc) {
+  (void)n_chunks;
   const int nb = nblk(6 * (int64_t)S * ncam, 256);
-  hipLaunchKernelGGL(k_border_fold, dim3(nb > 0 ? nb : 1), dim3(256), 0, s, S, ncam, n_chunks, sta_chunk0, part, stride, Ssc, corner);
+  if (nb > 0) hipLaunchKernelGGL(k_border_fold, dim3(nb), dim3(256), 0, s, S, ncam, sta_chunk0, part, stride, Ssc);
 }
 void launch_border_corner(hipStream_t s, int ncam, const double *corner, const double *camdiag, double *Scc) {
   hipLaunchKernelGGL(k_border_corner, dim3(1), dim3(1), 0, s, ncam, corner, camdiag, Scc);
 }
 int cg2_blocks_spmv(int S) {
+  // two 16-wave workgroups fit a compute unit: no more than one resident round of them
   const int nb = nblk(S, SPMV_WAVES);
-  return nb > 2048 ? 2048 : nb;
+  return nb > 512 ? 512 : nb;
 }
 int cg2_blocks_vec(int S) { return nblk(S, 256) > 0 ? nblk(S, 256) : 1; }
 void launch_cg2_init(hipStream_t s, const BsrCgArgs &a, double rtol) {
