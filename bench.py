@@ -23,6 +23,20 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
 
+def measured_traffic(kernel, config, scale, world):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (FETCH_SIZE / WRITE_SIZE
+    passes of this same workload, corrected as the summary says); None when the run is not that workload."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if world != 1 or scale != 1.0 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        tab = json.load(f)
+    if tab.get("config") != config:
+        return None
+    ent = tab.get("kernels", {}).get(kernel)
+    return None if ent is None else ent["bytes_per_launch"]
+
+
 def kernel_bytes(which, n_obs, n_pts, n_sta, n_blocks=0, n_pairs=0, ncam=0):
     """Algorithmic bytes one launch must move (per-unit figures x units; written out in DESIGN.md).
     0 linearize      : per observation 56 (record) + 48 (station) + 24 (point) + 16 (residual) + 144 (coupling block W),
@@ -32,7 +46,9 @@ def kernel_bytes(which, n_obs, n_pts, n_sta, n_blocks=0, n_pairs=0, ncam=0):
     3 cost           : per observation record 56 + point 24
     4 schur_blocks   : per observation pair two 144-B coupling blocks + the 8-B pair record, per 6x6 block 288 written twice
     5 pcg_iteration  : the block-sparse matrix once (288 B per block + 4-B column index), the border once,
-                       and the six vectors of the iteration (x r z p q read, x r z p q written: 10 x 48 B per station)"""
+                       and the six vectors of the iteration (x r z p q read, x r z p q written: 10 x 48 B per station);
+                       the multilevel preconditioner's transfer operators are not counted (they are a design choice,
+                       not something the iteration must move)"""
     if which == 0:
         return 288.0 * n_obs + 72.0 * n_pts + 216.0 * n_sta
     if which == 1:
@@ -49,7 +65,7 @@ def kernel_bytes(which, n_obs, n_pts, n_sta, n_blocks=0, n_pairs=0, ncam=0):
 
 
 KERNEL_NAMES = {0: "k_linearize", 1: "k_point_pass<APPLY>", 2: "k_station_pass<GATHER>", 3: "k_cost_obs",
-                4: "k_schur_blocks", 5: "pcg iteration (k_bsr_spmv + k_cg2_update1 + k_cg2_update2)", 6: "k_bsr_spmv"}
+                4: "k_schur_blocks", 5: "pcg iteration (k_bsr_spmv + k_cg2_update1 + k_amg_restrict x levels + k_amg_prolong + k_amg_update2)", 6: "k_bsr_spmv"}
 
 
 def structure_counts(net):
@@ -222,14 +238,14 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"{args.config}: {full.n_cam} camera(s), {full.n_sta} stations, {full.n_pts} points, "
-                               f"{full.n_obs} observations, self-calibrating (IOP + k1 k2 p1 p2), point elimination + block-Jacobi PCG "
-                               f"on the block-sparse reduced system",
+                               f"{full.n_obs} observations, self-calibrating (IOP + k1 k2 p1 p2), point elimination + PCG with a multilevel "
+                               f"(smoothed aggregation) preconditioner on the block-sparse reduced system",
                    "scale": args.scale, "pcg_rtol": args.pcg_rtol, "sharding": f"points/{world}"},
         "jacobian_obs_per_s": full.n_obs / ktime[0],
         "pcg_iterations_per_step": lin_iters / args.steps,
         "final_cost": sm["final_cost"],
         "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(KERNEL_NAMES[dom], args.config, args.scale, world)},
         "kernels": kernels,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -1236,7 +1236,16 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
   ba.Scc = p->d_Scc; ba.Lcc = p->d_Lcc; ba.Minv = p->d_Minv; ba.b = p->d_b; ba.x = p->d_x; ba.r = p->d_r; ba.z = p->d_z; ba.p = p->d_p;
   ba.q = p->d_q; ba.scal = p->d_cg2scal; ba.part_pq = p->d_part_pq; ba.part_qc = p->d_part_qc; ba.part_rz = p->d_part_rz;
   if ((which == 4 || which == 5 || which == 6) && !p->explicit_ok) return fail(BA_ERR_INVALID, "ba_time_kernel: the block-sparse system was not built for this network");
-  if (which == 5 || which == 6) launch_cg2_init(s, ba, 0.0);
+  // the PCG iteration is timed with the preconditioner the last solve used (multilevel once it has been built)
+  const bool with_amg = p->amg && amg_levels(p->amg) >= 2;
+  if (which == 5 || which == 6) {
+    if (with_amg) {
+      amg_numeric(p->amg, s, p->d_bsr_val, p->d_Minv);
+      launch_amg_cg_init(s, ba, p->amg, 0.0);
+    } else {
+      launch_cg2_init(s, ba, 0.0);
+    }
+  }
   PointArgs pa = point_args(p, p->d_p);
   StationArgs sa = station_args(p, 7, 6);
   CostArgs ca{};
@@ -1252,7 +1261,10 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
       case 2: launch_station_pass(s, sa, SMODE_GATHER); break;
       case 3: launch_cost_obs(s, ca, cost_blocks(p->N)); break;
       case 4: launch_schur_blocks(s, p->n_ublk, p->d_ublk_cstart, p->d_ublk_dst, p->d_pairs, p->d_Y, p->d_bsr_val); break;
-      case 5: launch_cg2_iteration(s, ba, 0); break;
+      case 5:
+        if (with_amg) launch_amg_cg_iteration(s, ba, p->amg, 0);
+        else launch_cg2_iteration(s, ba, 0);
+        break;
       case 6: launch_bsr_spmv(s, ba, 0); break;
       default: break;
     }

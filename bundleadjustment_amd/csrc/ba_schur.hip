@@ -266,6 +266,7 @@ k_bsr_spmv(BsrCgArgs a, int parity) {
   }
 }
 
+#define CAM_STAGE 16  // camera blocks up to this order are staged in LDS by the vector kernel
 // camera part of z = M^-1 r with the dense Cholesky factor of the corner (one thread)
 __device__ void cam_precond(int n, const double *__restrict__ L, const double *__restrict__ rc, double *__restrict__ zc) {
   for (int i = 0; i < n; ++i) {
@@ -354,6 +355,7 @@ k_cg2_update1(BsrCgArgs a, int parity, int nblk_spmv) {
   __shared__ double pcs[80];   // camera part of p
   __shared__ double pq_s;
   __shared__ double fold4[4][8];
+  __shared__ double Ls[CAM_STAGE * CAM_STAGE], rcs[CAM_STAGE], zcs[CAM_STAGE];
   if (a.scal[8 + parity] != 0.0) return;
   // Every workgroup folds the SpMV partials in the same order -> identical alpha everywhere.
   // Eight sums at a time: thread t takes sum (t & 7) and every 32nd partial from (t >> 3) on, so all
@@ -367,16 +369,15 @@ k_cg2_update1(BsrCgArgs a, int parity, int nblk_spmv) {
     if (qn < 1 + a.ncam) {
       const double *src = (qn == 0) ? a.part_pq : a.part_qc + (qn - 1);
       const int64_t st = (qn == 0) ? 1 : a.ncam;
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      int m = threadIdx.x >> 3;
-      for (; m + 96 < nblk_spmv; m += 128) {
-        s0 += src[st * m];
-        s1 += src[st * (m + 32)];
-        s2 += src[st * (m + 64)];
-        s3 += src[st * (m + 96)];
+      // at most 512 partials (cg2_blocks_spmv): 16 independent loads per thread, summed in a fixed tree
+      double v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int m = (threadIdx.x >> 3) + 32 * j;
+        v[j] = (m < nblk_spmv) ? src[st * m] : 0.0;
       }
-      for (; m < nblk_spmv; m += 32) s0 += src[st * m];
-      s = (s0 + s1) + (s2 + s3);
+      s = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
+          (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
     }
     s += __shfl_xor(s, 8, 64);
     s += __shfl_xor(s, 16, 64);
@@ -416,15 +417,36 @@ k_cg2_update1(BsrCgArgs a, int parity, int nblk_spmv) {
     }
     dot = station_precond(a.Minv, a.r, a.z, i);
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-    // the last workgroup is the least loaded one: it also carries the camera entries
-    for (int k = 0; k < a.ncam; ++k) {
-      a.x[o + k] += alpha * pcs[k];
-      a.r[o + k] -= alpha * red[1 + k];
+  if (blockIdx.x == gridDim.x - 1) {
+    // the last workgroup is the least loaded one: it also carries the camera entries.  A small
+    // camera block is staged in LDS first: the substitution is one thread's chain of dependent loads.
+    const bool staged = a.ncam > 0 && a.ncam <= CAM_STAGE;
+    if (staged) {
+      for (int k = threadIdx.x; k < a.ncam * a.ncam; k += blockDim.x) Ls[k] = a.Lcc[k];
+      if (threadIdx.x < a.ncam) {
+        a.x[o + threadIdx.x] += alpha * pcs[threadIdx.x];
+        rcs[threadIdx.x] = a.r[o + threadIdx.x] - alpha * red[1 + threadIdx.x];
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        cam_precond(a.ncam, Ls, rcs, zcs);
+        for (int k = 0; k < a.ncam; ++k) dot += rcs[k] * zcs[k];
+        a.scal[4] = pq;
+      }
+      __syncthreads();
+      if (threadIdx.x < a.ncam) {
+        a.r[o + threadIdx.x] = rcs[threadIdx.x];
+        a.z[o + threadIdx.x] = zcs[threadIdx.x];
+      }
+    } else if (threadIdx.x == 0) {
+      for (int k = 0; k < a.ncam; ++k) {
+        a.x[o + k] += alpha * pcs[k];
+        a.r[o + k] -= alpha * red[1 + k];
+      }
+      if (a.ncam > 0) cam_precond(a.ncam, a.Lcc, a.r + o, a.z + o);
+      for (int k = 0; k < a.ncam; ++k) dot += a.r[o + k] * a.z[o + k];
+      a.scal[4] = pq;
     }
-    if (a.ncam > 0) cam_precond(a.ncam, a.Lcc, a.r + o, a.z + o);
-    for (int k = 0; k < a.ncam; ++k) dot += a.r[o + k] * a.z[o + k];
-    a.scal[4] = pq;
   }
   const double t = block_sum(dot, lds);
   if (threadIdx.x == 0) a.part_rz[blockIdx.x] = t;

@@ -6,7 +6,7 @@ rtol = float(sys.argv[4]) if len(sys.argv) > 4 else 1e-12
 t=time.time(); hn = host.synth_config(name, scale=scale); net = hn.net
 print(name, net.n_obs, net.n_sta, net.n_pts, net.n_cam, "gen %.1fs"%(time.time()-t), flush=True)
 t=time.time(); P = solver.Problem(net); P.set_parameters(); print("create %.2fs"%(time.time()-t), flush=True)
-for which,nm,bytes_per_obs in ((0,"linearize",0),(1,"point_apply",0),(2,"station_gather",0),(3,"cost",0),(4,"schur_blocks",0),(5,"cg2_iteration",0)):
+for which,nm,bytes_per_obs in ((0,"linearize",0),(1,"point_apply",0),(2,"station_gather",0),(3,"cost",0),(4,"schur_blocks",0),(5,"cg2_iteration",0),(6,"spmv",0)):
     dt = P.time_kernel(which, 5)
     print("kernel %-15s %.3f ms  %.2f Gobs/s"%(nm, dt*1e3, net.n_obs/dt/1e9), flush=True)
 opt = solver.default_options(); opt.linear_solver = capi.SOLVER_PCG_SCHUR; opt.max_num_iterations = iters; opt.pcg_rtol = rtol; opt.pcg_max_iters=5000

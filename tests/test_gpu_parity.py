@@ -133,6 +133,31 @@ def test_scaled_configs_solve_parity(name, scale, ls):
     assert_solve_parity(g, o)
 
 
+def test_multilevel_preconditioner_same_answer_fewer_iterations():
+    # 300 stations: three levels of the aggregation hierarchy; the preconditioner must not change what
+    # the PCG converges to, only how fast
+    net = host.synth_config("cfg4", scale=0.03).net
+    opt_ml = options(capi.SOLVER_PCG_SCHUR, preconditioner=0)
+    opt_bj = options(capi.SOLVER_PCG_SCHUR, preconditioner=1)
+    g_ml = gpu_solve(net, opt_ml)
+    g_bj = gpu_solve(net, opt_bj)
+    o = po.solve(net, opt_ml, po.SCHUR_DENSE)
+    assert o[4]["termination"] == capi.CONVERGENCE
+    assert_solve_parity(g_ml, o)
+    assert_solve_parity(g_bj, o)
+    assert g_ml[4]["total_linear_iterations"] < 0.6 * g_bj[4]["total_linear_iterations"]
+
+
+def test_multilevel_preconditioner_several_cameras():
+    # more than one camera: the camera border comes from the general (probing) path
+    net = host.synth(n_cam=3, n_sta=90, n_pts=6000, rays_per_point=6, ap_free_mask=host.AP_K1K2P1P2, seed=5).net
+    opt = options(capi.SOLVER_PCG_SCHUR)
+    g = gpu_solve(net, opt)
+    o = po.solve(net, opt, po.SCHUR_DENSE)
+    assert o[4]["termination"] == capi.CONVERGENCE
+    assert_solve_parity(g, o)
+
+
 @pytest.mark.parametrize("ls", ALL_SOLVERS)
 @pytest.mark.parametrize("clamp", [True, False])
 def test_rejected_steps(ls, clamp):
