@@ -209,13 +209,41 @@ def apply_weighted(levels, x, wts):
         if y is not None: yk = yk + lev["P"] @ y
         y = yk
     return y
-for theta in (0.35, 0.5, 0.7):
+for theta in (0.5,):
     levels = build_hierarchy(Sc, theta)
-    print("theta %.2f: levels %s P blocks/row %s" % (theta, [l["nb"] for l in levels], ["%.1f" % (l["P"].nnz / 36 / l["nb"]) for l in levels[:-1]]), flush=True)
-    for depth in (2, 3):
-        lv = levels[:depth]
-        for wts in ((1, 1, 1), (1, 0.7, 0.7), (1, 1, 0.5), (1, 1.3, 1)):
-            run("all-Jacobi %d levels weights %s" % (depth, wts), lambda x: apply_weighted(lv, x, wts))
+    lv = levels[:3]
+    run("all-Jacobi 3 levels", lambda x: apply_additive(lv, x))
+    # level-0 smoother = exact solves on the aggregates (cluster Jacobi)
+    B0 = bsr_sorted(Sc)
+    agg, na = aggregate_graph(B0, theta)
+    order = np.argsort(agg, kind="stable")
+    starts = np.concatenate([[0], np.cumsum(np.bincount(agg, minlength=na))])
+    Sd = Sc.tocsr()
+    invs = []
+    dofs = []
+    for c in range(na):
+        st = order[starts[c]:starts[c + 1]]
+        d = (6 * st[:, None] + np.arange(6)[None, :]).ravel()
+        dofs.append(d)
+        invs.append(np.linalg.inv(Sd[d][:, d].toarray()))
+    def cluster_jacobi(x):
+        z = np.zeros_like(x)
+        for d, iv in zip(dofs, invs):
+            z[d] = iv @ x[d]
+        return z
+    run("cluster-Jacobi alone (aggregate blocks)", cluster_jacobi)
+    def ml_cluster(x):
+        rs = [x]
+        for lev in lv[:-1]:
+            rs.append(lev["P"].T @ rs[-1])
+        y = None
+        for k in range(len(lv) - 1, 0, -1):
+            lev = lv[k]
+            yk = np.einsum("sij,sj->si", lev["dinv"], rs[k].reshape(lev["nb"], 6)).ravel()
+            if y is not None: yk = yk + lev["P"] @ y
+            y = yk
+        return cluster_jacobi(x) + lv[0]["P"] @ y
+    run("3 levels, level 0 cluster-Jacobi", ml_cluster)
 sys.exit(0)
 def nested(aggf, a2):
     cx = np.bincount(aggf, XY[:, 0]) / np.bincount(aggf); cy = np.bincount(aggf, XY[:, 1]) / np.bincount(aggf)
