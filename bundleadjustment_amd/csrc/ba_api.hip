@@ -105,7 +105,7 @@ struct ba_problem {
   int64_t n_pairs = 0;
   int *d_bsr_rowptr = nullptr, *d_bsr_col = nullptr, *d_ublk_cstart = nullptr;
   int2 *d_ublk_dst = nullptr, *d_pairs = nullptr;
-  double *d_Y = nullptr, *d_bsr_val = nullptr, *d_Sdiag = nullptr, *d_Jt = nullptr, *d_corner = nullptr, *d_campart = nullptr;
+  double *d_Y = nullptr, *d_bsr_val = nullptr, *d_Sdiag = nullptr, *d_Jt = nullptr, *d_corner = nullptr, *d_campart = nullptr, *d_elim = nullptr;
   double *d_part_pq = nullptr, *d_part_qc = nullptr, *d_part_rz = nullptr, *d_cg2scal = nullptr;
   std::vector<int> ub_lo_h, ub_hi_h, bsr_rowptr_h, bsr_col_h;  // host copies of the block structure
   std::vector<int> cam_used_h;
@@ -399,6 +399,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   BA_TRY(p->dalloc(&p->d_Jc, 2 * (size_t)p->ncmax * N));
   BA_TRY(p->dalloc(&p->d_Mo, 3 * (size_t)N));
   BA_TRY(p->dalloc(&p->d_Vinv, 6 * (size_t)P));
+  BA_TRY(p->dalloc(&p->d_elim, (size_t)elim_stride() * P));
   BA_TRY(p->dalloc(&p->d_g_pt, 3 * (size_t)P));
   BA_TRY(p->dalloc(&p->d_y_pt, 3 * (size_t)P));
   BA_TRY(p->dalloc(&p->d_colnorm_pt, 3 * (size_t)P));
@@ -434,7 +435,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
     // single camera with few free parameters: the linearisation kernel also produces the camera border's inputs
     BA_TRY(p->dalloc(&p->d_Jt, 2 * (size_t)border_ncb() * N));
     const size_t ncorner = (size_t)border_ncb() * (border_ncb() + 1) / 2;
-    BA_TRY(p->dalloc(&p->d_campart, std::max((size_t)linearize_blocks(P) * 2 * lin_ncb(), (size_t)camera_corner_blocks(N) * ncorner)));
+    BA_TRY(p->dalloc(&p->d_campart, std::max((size_t)obs_rows_blocks(N) * 2 * lin_ncb(), (size_t)camera_corner_blocks(N) * ncorner)));
   }
   p->n_partial = 4 * std::max(std::max(linearize_blocks(P), cost_blocks(N)), cost_blocks(6 * (int64_t)S + 3 * (int64_t)P)) + 16;
   BA_TRY(p->dalloc(&p->d_partial, (size_t)p->n_partial));
@@ -525,7 +526,8 @@ int linearize(ba_problem *p, const LmState &st) {
   hipStream_t s = p->stream;
   launch_station_prep(s, p->S, p->d_eop, p->d_scale_sta, p->d_sta_cam, p->d_sta);
   LinArgs la{};
-  la.P = p->P; la.ncmax = p->ncmax; la.pt_start = p->d_pt_start; la.obs = p->d_obs; la.sta = p->d_sta; la.xyz = p->d_xyz;
+  la.P = p->P; la.ncmax = p->ncmax; la.N = p->N; la.pt_start = p->d_pt_start; la.obs_pt = p->d_obs_pt; la.elim = p->d_elim;
+  la.obs = p->d_obs; la.sta = p->d_sta; la.xyz = p->d_xyz;
   la.scale_pt = p->d_scale_pt; la.pt_prior = p->d_pt_prior; la.pt_isig = p->d_pt_isig; la.cam = p->d_cam;
   la.rec = p->d_rec; la.Jp = p->d_Jp; la.Jc = p->d_Jc; la.Mo = p->d_Mo; la.Vinv = p->d_Vinv; la.g_pt = p->d_g_pt;
   la.colnorm_pt = p->d_colnorm_pt; la.diag_pt = p->d_diag_pt; la.cost_partial = p->d_partial; la.flags = p->d_flags;
@@ -551,7 +553,7 @@ int linearize(ba_problem *p, const LmState &st) {
   // camera rows of the gradient and of the reduced right-hand side
   if (p->ncam > 0) {
     if (p->d_Jt) {
-      launch_camera_rows_fold(s, p->d_campart, linearize_blocks(p->P), p->ncam, p->d_g + 6 * (size_t)p->S, p->d_b + 6 * (size_t)p->S);
+      launch_camera_rows_fold(s, p->d_campart, obs_rows_blocks(p->N), p->ncam, p->d_g + 6 * (size_t)p->S, p->d_b + 6 * (size_t)p->S);
       BA_TRY(p->allreduce(p->d_g + 6 * (size_t)p->S, p->ncam, 0));
       BA_TRY(p->allreduce(p->d_b + 6 * (size_t)p->S, p->ncam, 0));
     } else {
@@ -1223,7 +1225,8 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
   BA_TRY(linearize(p, st));
   launch_copy(s, p->nr, p->d_b, p->d_p);
   LinArgs la{};
-  la.P = p->P; la.ncmax = p->ncmax; la.pt_start = p->d_pt_start; la.obs = p->d_obs; la.sta = p->d_sta; la.xyz = p->d_xyz;
+  la.P = p->P; la.ncmax = p->ncmax; la.N = p->N; la.pt_start = p->d_pt_start; la.obs_pt = p->d_obs_pt; la.elim = p->d_elim;
+  la.obs = p->d_obs; la.sta = p->d_sta; la.xyz = p->d_xyz;
   la.scale_pt = p->d_scale_pt; la.pt_prior = p->d_pt_prior; la.pt_isig = p->d_pt_isig; la.cam = p->d_cam;
   la.rec = p->d_rec; la.Jp = p->d_Jp; la.Jc = p->d_Jc; la.Mo = p->d_Mo; la.Vinv = p->d_Vinv; la.g_pt = p->d_g_pt;
   la.colnorm_pt = p->d_colnorm_pt; la.diag_pt = p->d_diag_pt; la.cost_partial = p->d_partial; la.flags = p->d_flags;

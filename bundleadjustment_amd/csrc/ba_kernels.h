@@ -17,12 +17,14 @@ enum { BA_CHUNK = 1024 };  // observations of one station handled by one workgro
 
 struct LinArgs {
   int P, ncmax;
-  const int *pt_start;
+  int64_t N;
+  const int *pt_start, *obs_pt;
   const double *obs, *sta, *xyz, *scale_pt, *pt_prior, *pt_isig;
   const CamRec *cam;
   double *rec, *Jp, *Jc, *Mo, *Vinv, *g_pt, *colnorm_pt, *diag_pt, *cost_partial;
   double *Y;  // may be null
   double *Jt, *cam_partial;  // single-camera fast path (null otherwise): projected camera rows, partials of the camera sums
+  double *elim;              // per-point record handed from the point kernel to the observation kernel
   unsigned *flags;
   double huber_a, lm_min, lm_max, radius;
   int reuse_diag;
@@ -94,6 +96,8 @@ void launch_station_prep(hipStream_t s, int S, const double *eop, const double *
 int linearize_blocks(int P);
 void launch_linearize(hipStream_t s, const LinArgs &a);
 int lin_ncb();
+int elim_stride();
+int obs_rows_blocks(int64_t N);
 void launch_camera_rows_fold(hipStream_t s, const double *cam_partial, int nblocks, int ncam, double *out_g, double *out_b);
 int camera_corner_blocks(int64_t N);
 void launch_camera_corner(hipStream_t s, int64_t N, int ncmax, const double *Jc, const double *Jt, double *part, double *corner);

@@ -42,37 +42,37 @@ __global__ void k_station_prep(int S, const double *__restrict__ eop, const doub
 }
 
 // ------------------------------------------------------------------------------------------
-// point sweep 1: residuals, Jacobians, point elimination
+// linearisation: residuals, Jacobians, point elimination
 // ------------------------------------------------------------------------------------------
-// One lane per object point, two walks over its observations.  The first walk only accumulates
-// what the elimination needs (V, its gradient and, when CAM1, B = sum Jc^T Jp); the second
-// evaluates the observation again and writes every per-observation record exactly once.
-// Recomputing the projection is cheaper than writing the rows, reading them back and writing
-// them a second time.
+// Two kernels.  k_point_elim (one lane per object point) walks the point's observations and only
+// accumulates what the elimination needs: V, its gradient and, in the single-camera case, the
+// coupling B = sum Jc^T Jp; it writes per-point records only.  k_obs_rows (one lane per
+// observation, in point-sorted order) evaluates the observation again and writes every
+// per-observation record exactly once; a wave's 64 records of one kind are contiguous in memory,
+// so they are transposed through LDS and leave as whole cache lines.  Recomputing the projection
+// is cheaper than writing the rows, reading them back and writing them a second time.
 //
-// CAM1 (one camera with at most LIN_NCB free parameters): also writes the projected camera rows
-// Jt = Jc - Jp V^-1 B^T and per-workgroup partial sums of Jc^T r (gradient) and Jc^T rhat
-// (reduced right-hand side), so that no further sweep is needed for the camera border.
+// CAM1 (one camera with at most LIN_NCB free parameters): k_obs_rows also writes the projected
+// camera rows Jt = Jc - Jp V^-1 B^T and per-workgroup partial sums of Jc^T r (gradient) and
+// Jc^T rhat (reduced right-hand side), so that no further sweep is needed for those.
 #define LIN_NCB 8
+#define ELIM_STRIDE 40  // per point: u = V^-1 g (3) | L, V^-1 = L L^T (6) | pad (7) | Z = V^-1 B^T (LIN_NCB x 3)
+
 template <bool CAM1>
 __global__ void __launch_bounds__(256)
-k_linearize(LinArgs a) {
+k_point_elim(LinArgs a) {
   __shared__ double lds[8];
-  __shared__ double lds_cam[4][2 * LIN_NCB];
   const int jj = blockIdx.x * blockDim.x + threadIdx.x;
   double cost = 0.0;
-  double gc[CAM1 ? 2 * LIN_NCB : 1];
-#pragma unroll
-  for (int k = 0; k < (CAM1 ? 2 * LIN_NCB : 1); ++k) gc[k] = 0.0;
   int bad = 0;
   if (jj < a.P) {
     const int e0 = a.pt_start[jj], e1 = a.pt_start[jj + 1];
     const double X = a.xyz[3 * (int64_t)jj], Y = a.xyz[3 * (int64_t)jj + 1], Z = a.xyz[3 * (int64_t)jj + 2];
     const double s0 = a.scale_pt[3 * (int64_t)jj], s1 = a.scale_pt[3 * (int64_t)jj + 1], s2 = a.scale_pt[3 * (int64_t)jj + 2];
     double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-    double B[CAM1 ? LIN_NCB : 1][3];
+    double B[CAM1 ? BA_NCAMPAR : 1][3];  // all camera columns; the free ones are picked at the end
 #pragma unroll
-    for (int k = 0; k < (CAM1 ? LIN_NCB : 1); ++k) B[k][0] = B[k][1] = B[k][2] = 0.0;
+    for (int k = 0; k < (CAM1 ? BA_NCAMPAR : 1); ++k) B[k][0] = B[k][1] = B[k][2] = 0.0;
     for (int e = e0; e < e1; ++e) {
       const ObsIn o = load_obs(a.obs, e);
       const double *st = a.sta + (int64_t)BA_STA_STRIDE * o.sta;
@@ -95,30 +95,16 @@ k_linearize(LinArgs a) {
       g[0] += Jp[0] * r0 + Jp[3] * r1;
       g[1] += Jp[1] * r0 + Jp[4] * r1;
       g[2] += Jp[2] * r0 + Jp[5] * r1;
-      if (a.ncmax > 0) {
-        // free camera columns, compacted; written here, read back below and in the second walk
-        const CamRec &cr = a.cam[c];
-        double *jc = a.Jc + 2 * (int64_t)a.ncmax * e;
-        int pos = 0;
+      if (CAM1) {
+        const uint32_t mask = a.cam[0].mask;
 #pragma unroll
-        for (int p = 0; p < BA_NCAMPAR; ++p) {
-          if (cr.mask & (1u << p)) {
-            const double cs = sc * cr.scale[pos];
-            jc[pos] = dc0[p] * cs;
-            jc[a.ncmax + pos] = dc1[p] * cs;
-            ++pos;
+        for (int p = 0; p < BA_NCAMPAR; ++p)
+          if (mask & (1u << p)) {  // uniform: one camera
+            const double c0 = dc0[p] * sc, c1 = dc1[p] * sc;
+            B[p][0] += c0 * Jp[0] + c1 * Jp[3];
+            B[p][1] += c0 * Jp[1] + c1 * Jp[4];
+            B[p][2] += c0 * Jp[2] + c1 * Jp[5];
           }
-        }
-        if (CAM1) {
-#pragma unroll
-          for (int k = 0; k < LIN_NCB; ++k)
-            if (k < a.ncmax) {
-              const double c0 = jc[k], c1 = jc[a.ncmax + k];
-              B[k][0] += c0 * Jp[0] + c1 * Jp[3];
-              B[k][1] += c0 * Jp[1] + c1 * Jp[4];
-              B[k][2] += c0 * Jp[2] + c1 * Jp[5];
-            }
-        }
       }
     }
     // prior rows (src/main.cpp:1064-1071, 4596-4599): r = (p - p0)/sigma, J = 1/sigma
@@ -150,93 +136,184 @@ k_linearize(LinArgs a) {
     for (int k = 0; k < 6; ++k) vo[k] = Vi[k];
     double *go = a.g_pt + 3 * (int64_t)jj;
     go[0] = g[0]; go[1] = g[1]; go[2] = g[2];
-    double u0, u1, u2;
-    sym3_mul(Vi, g[0], g[1], g[2], u0, u1, u2);
+    double *el = a.elim + (int64_t)ELIM_STRIDE * jj;
+    sym3_mul(Vi, g[0], g[1], g[2], el[0], el[1], el[2]);
     // Vinv = L L^T (lower Cholesky), for the whitened coupling blocks Y = Js^T Jp L
     const double l00 = sqrt(Vi[0]), l10 = Vi[1] / l00, l20 = Vi[2] / l00;
     const double l11 = sqrt(Vi[3] - l10 * l10), l21 = (Vi[4] - l20 * l10) / l11;
     const double l22 = sqrt(Vi[5] - l20 * l20 - l21 * l21);
-    double Zc[CAM1 ? LIN_NCB : 1][3];
+    el[3] = l00; el[4] = l10; el[5] = l20; el[6] = l11; el[7] = l21; el[8] = l22;
     if (CAM1) {
+      const CamRec &cr = a.cam[0];
+      int pos = 0;
 #pragma unroll
-      for (int k = 0; k < LIN_NCB; ++k) sym3_mul(Vi, B[k][0], B[k][1], B[k][2], Zc[k][0], Zc[k][1], Zc[k][2]);
+      for (int p = 0; p < BA_NCAMPAR; ++p)
+        if (cr.mask & (1u << p)) {
+          const double cs = cr.scale[pos];
+          double z0, z1, z2;
+          sym3_mul(Vi, cs * B[p][0], cs * B[p][1], cs * B[p][2], z0, z1, z2);
+          if (pos < LIN_NCB) {
+            el[16 + 3 * pos] = z0;
+            el[17 + 3 * pos] = z1;
+            el[18 + 3 * pos] = z2;
+          }
+          ++pos;
+        }
     }
-    // second walk: the rows themselves, M = I - Jp Vinv Jp^T, the reduced residual r - Jp Vinv g, Y, Jt
-    for (int e = e0; e < e1; ++e) {
-      const ObsIn o = load_obs(a.obs, e);
-      const double *st = a.sta + (int64_t)BA_STA_STRIDE * o.sta;
-      const int c = __double2loint(st[20]);
-      const CamIn cm = load_cam(a.cam, c);
-      double r0, r1, Js[12], Jp[6], dc0[BA_NCAMPAR], dc1[BA_NCAMPAR];
-      eval_obs<true>(o, st, X, Y, Z, cm, r0, r1, Js, Jp, dc0, dc1);
-      double sc;
-      (void)huber_rho(a.huber_a, r0 * r0 + r1 * r1, sc);
-      r0 *= sc;
-      r1 *= sc;
+  }
+  const double t = block_sum(cost, lds);
+  if (threadIdx.x == 0) a.cost_partial[blockIdx.x] = t;
+  if (bad) atomicOr(a.flags, 1);
+}
+
+// 64 records of R doubles, one per lane, to contiguous global memory through a wave-private LDS
+// buffer of 64 * (R + 1) doubles: each store instruction then covers 512 contiguous bytes.
+// Only the first nvalid records are written.
+template <int R>
+__device__ __forceinline__ void tile_store(double *buf, const double (&v)[R], double *__restrict__ g, int lane, int nvalid) {
+#pragma unroll
+  for (int k = 0; k < R; ++k) buf[lane * (R + 1) + k] = v[k];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int q = i * 64 + lane;
+    const double x = buf[(q / R) * (R + 1) + q % R];
+    if (q < nvalid * R) g[q] = x;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#define ROWS_LDS(CAM1) (64 * ((CAM1) ? 25 : 2 * BA_NCAMPAR + 1))
+template <bool CAM1>
+__global__ void __launch_bounds__(256)
+k_obs_rows(LinArgs a) {
+  __shared__ double lds[4][ROWS_LDS(CAM1)];
+  __shared__ double lds_cam[4][2 * LIN_NCB];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double *buf = lds[w];
+  double gc[CAM1 ? 2 * LIN_NCB : 1];
+#pragma unroll
+  for (int k = 0; k < (CAM1 ? 2 * LIN_NCB : 1); ++k) gc[k] = 0.0;
+  const int64_t n_tiles = (a.N + 63) / 64;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t e0 = tile * 64;
+    const int nvalid = (int)((a.N - e0 < 64) ? (a.N - e0) : 64);
+    const bool on = lane < nvalid;
+    const int64_t e = on ? e0 + lane : e0;  // idle lanes of the last tile redo its first observation and store nothing
+    const ObsIn o = load_obs(a.obs, e);
+    const int jj = a.obs_pt[e];
+    const double *st = a.sta + (int64_t)BA_STA_STRIDE * o.sta;
+    const int c = __double2loint(st[20]);
+    const CamIn cm = load_cam(a.cam, c);
+    const double X = a.xyz[3 * (int64_t)jj], Y = a.xyz[3 * (int64_t)jj + 1], Z = a.xyz[3 * (int64_t)jj + 2];
+    const double s0 = a.scale_pt[3 * (int64_t)jj], s1 = a.scale_pt[3 * (int64_t)jj + 1], s2 = a.scale_pt[3 * (int64_t)jj + 2];
+    double r0, r1, Js[12], Jp[6], dc0[BA_NCAMPAR], dc1[BA_NCAMPAR];
+    eval_obs<true>(o, st, X, Y, Z, cm, r0, r1, Js, Jp, dc0, dc1);
+    double sc;
+    (void)huber_rho(a.huber_a, r0 * r0 + r1 * r1, sc);
+    r0 *= sc;
+    r1 *= sc;
+    // free camera columns, compacted: into LDS at a run-time position, out as whole lines
+    double c0[CAM1 ? LIN_NCB : 1], c1[CAM1 ? LIN_NCB : 1];
+    if (a.ncmax > 0) {
+      const CamRec &cr = a.cam[c];
+      const int R = 2 * a.ncmax;
+      double *mine = buf + lane * (R + 1);
+      for (int k = cr.nc; k < a.ncmax; ++k) {  // cameras with fewer free parameters than the widest one
+        mine[k] = 0.0;
+        mine[a.ncmax + k] = 0.0;
+      }
+      int pos = 0;
+#pragma unroll
+      for (int p = 0; p < BA_NCAMPAR; ++p) {
+        if (cr.mask & (1u << p)) {
+          const double cs = sc * cr.scale[pos];
+          mine[pos] = dc0[p] * cs;
+          mine[a.ncmax + pos] = dc1[p] * cs;
+          ++pos;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      double *gj = a.Jc + (int64_t)R * e0;
+      for (int q = lane; q < nvalid * R; q += 64) gj[q] = buf[(q / R) * (R + 1) + q % R];
+      if (CAM1) {
+#pragma unroll
+        for (int k = 0; k < LIN_NCB; ++k) {
+          c0[k] = (k < a.ncmax) ? mine[k] : 0.0;
+          c1[k] = (k < a.ncmax) ? mine[a.ncmax + k] : 0.0;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // point data of the elimination
+    const double *vi = a.Vinv + 6 * (int64_t)jj, *el = a.elim + (int64_t)ELIM_STRIDE * jj;
+    const double Vi[6] = {vi[0], vi[1], vi[2], vi[3], vi[4], vi[5]};
+    const double u0 = el[0], u1 = el[1], u2 = el[2];
+    const double p0 = Jp[0] * (sc * s0), p1 = Jp[1] * (sc * s1), p2 = Jp[2] * (sc * s2);
+    const double p3 = Jp[3] * (sc * s0), p4 = Jp[4] * (sc * s1), p5 = Jp[5] * (sc * s2);
+    const double h0 = r0 - (p0 * u0 + p1 * u1 + p2 * u2), h1 = r1 - (p3 * u0 + p4 * u1 + p5 * u2);
+    {
+      double rec[16];
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         const double cs = sc * st[14 + k];
         Js[k] *= cs;
         Js[6 + k] *= cs;
+        rec[k] = Js[k];
+        rec[6 + k] = Js[6 + k];
       }
-      const double p0 = Jp[0] * (sc * s0), p1 = Jp[1] * (sc * s1), p2 = Jp[2] * (sc * s2);
-      const double p3 = Jp[3] * (sc * s0), p4 = Jp[4] * (sc * s1), p5 = Jp[5] * (sc * s2);
-      const double h0 = r0 - (p0 * u0 + p1 * u1 + p2 * u2), h1 = r1 - (p3 * u0 + p4 * u1 + p5 * u2);
-      double2 *rec = reinterpret_cast<double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) rec[k] = make_double2(Js[2 * k], Js[2 * k + 1]);
-      rec[6] = make_double2(r0, r1);
-      rec[7] = make_double2(h0, h1);
-      double2 *jp = reinterpret_cast<double2 *>(a.Jp + 6 * (int64_t)e);
-      jp[0] = make_double2(p0, p1);
-      jp[1] = make_double2(p2, p3);
-      jp[2] = make_double2(p4, p5);
+      rec[12] = r0; rec[13] = r1; rec[14] = h0; rec[15] = h1;
+      tile_store<16>(buf, rec, a.rec + (int64_t)BA_REC_STRIDE * e0, lane, nvalid);
+    }
+    {
+      const double jp[6] = {p0, p1, p2, p3, p4, p5};
+      tile_store<6>(buf, jp, a.Jp + 6 * e0, lane, nvalid);
       double t0, t1, t2, w0, w1, w2;
       sym3_mul(Vi, p0, p1, p2, t0, t1, t2);
       sym3_mul(Vi, p3, p4, p5, w0, w1, w2);
-      double *mo = a.Mo + 3 * (int64_t)e;
-      mo[0] = 1.0 - (p0 * t0 + p1 * t1 + p2 * t2);
-      mo[1] = -(p0 * w0 + p1 * w1 + p2 * w2);
-      mo[2] = 1.0 - (p3 * w0 + p4 * w1 + p5 * w2);
-      if (a.Y) {
-        // G = Jp L (2x3);  Y[r][m] = Js0[r] G0[m] + Js1[r] G1[m], rows padded to 4 doubles
-        const double g00 = p0 * l00 + p1 * l10 + p2 * l20, g01 = p1 * l11 + p2 * l21, g02 = p2 * l22;
-        const double g10 = p3 * l00 + p4 * l10 + p5 * l20, g11 = p4 * l11 + p5 * l21, g12 = p5 * l22;
-        double2 *yo = reinterpret_cast<double2 *>(a.Y + (int64_t)BA_Y_STRIDE * e);
+      const double mo[3] = {1.0 - (p0 * t0 + p1 * t1 + p2 * t2), -(p0 * w0 + p1 * w1 + p2 * w2), 1.0 - (p3 * w0 + p4 * w1 + p5 * w2)};
+      tile_store<3>(buf, mo, a.Mo + 3 * e0, lane, nvalid);
+    }
+    if (a.Y) {
+      // G = Jp L (2x3);  Y[r][m] = Js0[r] G0[m] + Js1[r] G1[m], rows padded to 4 doubles
+      const double l00 = el[3], l10 = el[4], l20 = el[5], l11 = el[6], l21 = el[7], l22 = el[8];
+      const double g00 = p0 * l00 + p1 * l10 + p2 * l20, g01 = p1 * l11 + p2 * l21, g02 = p2 * l22;
+      const double g10 = p3 * l00 + p4 * l10 + p5 * l20, g11 = p4 * l11 + p5 * l21, g12 = p5 * l22;
+      double y[24];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          yo[2 * r] = make_double2(Js[r] * g00 + Js[6 + r] * g10, Js[r] * g01 + Js[6 + r] * g11);
-          yo[2 * r + 1] = make_double2(Js[r] * g02 + Js[6 + r] * g12, 0.0);
+      for (int r = 0; r < 6; ++r) {
+        y[4 * r] = Js[r] * g00 + Js[6 + r] * g10;
+        y[4 * r + 1] = Js[r] * g01 + Js[6 + r] * g11;
+        y[4 * r + 2] = Js[r] * g02 + Js[6 + r] * g12;
+        y[4 * r + 3] = 0.0;
+      }
+      tile_store<24>(buf, y, a.Y + (int64_t)BA_Y_STRIDE * e0, lane, nvalid);
+    }
+    if (CAM1) {
+      double jt[2 * LIN_NCB];
+#pragma unroll
+      for (int k = 0; k < LIN_NCB; ++k) {
+        const double z0 = el[16 + 3 * k], z1 = el[17 + 3 * k], z2 = el[18 + 3 * k];
+        const bool free_k = k < a.ncmax;
+        jt[k] = free_k ? c0[k] - (p0 * z0 + p1 * z1 + p2 * z2) : 0.0;
+        jt[LIN_NCB + k] = free_k ? c1[k] - (p3 * z0 + p4 * z1 + p5 * z2) : 0.0;
+        if (on && free_k) {
+          gc[k] += c0[k] * r0 + c1[k] * r1;
+          gc[LIN_NCB + k] += c0[k] * h0 + c1[k] * h1;
         }
       }
-      if (CAM1) {
-        const double *jc = a.Jc + 2 * (int64_t)a.ncmax * e;
-        double2 *jt = reinterpret_cast<double2 *>(a.Jt + 2 * (int64_t)LIN_NCB * e);
-        double t0v[LIN_NCB], t1v[LIN_NCB];
-#pragma unroll
-        for (int k = 0; k < LIN_NCB; ++k) {
-          t0v[k] = 0.0;
-          t1v[k] = 0.0;
-          if (k < a.ncmax) {
-            const double c0 = jc[k], c1 = jc[a.ncmax + k];
-            t0v[k] = c0 - (p0 * Zc[k][0] + p1 * Zc[k][1] + p2 * Zc[k][2]);
-            t1v[k] = c1 - (p3 * Zc[k][0] + p4 * Zc[k][1] + p5 * Zc[k][2]);
-            gc[k] += c0 * r0 + c1 * r1;
-            gc[LIN_NCB + k] += c0 * h0 + c1 * h1;
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < LIN_NCB / 2; ++k) {
-          jt[k] = make_double2(t0v[2 * k], t0v[2 * k + 1]);
-          jt[LIN_NCB / 2 + k] = make_double2(t1v[2 * k], t1v[2 * k + 1]);
-        }
-      }
+      tile_store<2 * LIN_NCB>(buf, jt, a.Jt + 2 * (int64_t)LIN_NCB * e0, lane, nvalid);
     }
   }
-  const double t = block_sum(cost, lds);
-  if (threadIdx.x == 0) a.cost_partial[blockIdx.x] = t;
   if (CAM1) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 2 * LIN_NCB; ++k) {
       const double v = wave_sum(gc[k]);
@@ -247,7 +324,6 @@ k_linearize(LinArgs a) {
       a.cam_partial[(int64_t)blockIdx.x * (2 * LIN_NCB) + threadIdx.x] =
           (lds_cam[0][threadIdx.x] + lds_cam[1][threadIdx.x]) + (lds_cam[2][threadIdx.x] + lds_cam[3][threadIdx.x]);
   }
-  if (bad) atomicOr(a.flags, 1);
 }
 
 // corner of the camera border: upper triangle of sum Jc^T Jt over all observations, one lane per
@@ -1019,11 +1095,22 @@ void launch_station_prep(hipStream_t s, int S, const double *eop, const double *
   if (S > 0) hipLaunchKernelGGL(k_station_prep, dim3(nblk(S, 128)), dim3(128), 0, s, S, eop, scale_sta, sta_cam, sta);
 }
 int linearize_blocks(int P) { return nblk(P, 256); }
+int obs_rows_blocks(int64_t N) {
+  const int b = nblk((N + 63) / 64, 4);
+  return b < 1 ? 1 : (b > 4096 ? 4096 : b);
+}
 void launch_linearize(hipStream_t s, const LinArgs &a) {
   if (a.P <= 0) return;
-  if (a.Jt) hipLaunchKernelGGL(k_linearize<true>, dim3(nblk(a.P, 256)), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(k_linearize<false>, dim3(nblk(a.P, 256)), dim3(256), 0, s, a);
+  const dim3 gp(nblk(a.P, 256)), go(obs_rows_blocks(a.N)), b(256);
+  if (a.Jt) {
+    hipLaunchKernelGGL(k_point_elim<true>, gp, b, 0, s, a);
+    hipLaunchKernelGGL(k_obs_rows<true>, go, b, 0, s, a);
+  } else {
+    hipLaunchKernelGGL(k_point_elim<false>, gp, b, 0, s, a);
+    hipLaunchKernelGGL(k_obs_rows<false>, go, b, 0, s, a);
+  }
 }
+int elim_stride() { return ELIM_STRIDE; }
 int lin_ncb() { return LIN_NCB; }
 // camera rows of the gradient (out_g) and of the reduced right-hand side (out_b) from the partials
 // that k_linearize<true> left; out arrays have ncam entries
