@@ -255,6 +255,21 @@ k_amg_prolong(AmgTransfer t, double *__restrict__ yf) {
   if (on && r < 6) yf[6 * (int64_t)i + r] += s;
 }
 
+// L L^T z = t for a small dense factor (one thread)
+#define AMG_DEFL_NC 8
+__device__ __forceinline__ void cam_solve(int n, const double *L, const double *t, double *z) {
+  for (int i = 0; i < n; ++i) {
+    double s = t[i];
+    for (int k = 0; k < i; ++k) s -= L[i * n + k] * z[k];
+    z[i] = s / L[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = z[i];
+    for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * z[k];
+    z[i] = s / L[i * n + i];
+  }
+}
+
 // Last kernel of an iteration.  Every workgroup folds the partials of r.z = r.D0^-1 r + sum_l rc_l.y_l
 // in the same order (identical beta everywhere); z = D0^-1 r (already in cg.z) + P0 y1;
 // p = z + beta p (mode 1) or p = z (mode 0, start of the solve); 8 lanes per station.
@@ -264,6 +279,7 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restr
               int parity, int mode, double rtol) {
   __shared__ double lds[4];
   __shared__ double rzn_s;
+  __shared__ double Ls[AMG_DEFL_NC * AMG_DEFL_NC], gr4[4][16], zcs[AMG_DEFL_NC];
   if (mode == 1) {
     const double done = cg.scal[8 + parity];
     if (done != 0.0) {
@@ -271,11 +287,34 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restr
       return;
     }
   }
+  const int64_t o = 6 * (int64_t)cg.S;
+  const bool defl = cg.G != nullptr;  // then ncam <= AMG_DEFL_NC
+  if (defl) {
+    for (int k = threadIdx.x; k < cg.ncam * cg.ncam; k += blockDim.x) Ls[k] = cg.Lcc[k];
+    // G^T r_s: 16 lanes per sum, the partials dealt round-robin; then across the wave and the waves
+    const int k = threadIdx.x & 15, j = threadIdx.x >> 4;
+    double g = 0.0;
+    if (k < cg.ncam)
+      for (int m = j; m < n_part_rz; m += 16) g += cg.part_gr[(int64_t)m * cg.ncam + k];
+    g += __shfl_xor(g, 16, 64);
+    g += __shfl_xor(g, 32, 64);
+    if ((threadIdx.x & 63) < 16) gr4[threadIdx.x >> 6][k] = g;
+  }
   double s = 0.0;
   for (int k = threadIdx.x; k < n_part_rz; k += blockDim.x) s += cg.part_rz[k];
   for (int k = threadIdx.x; k < n_part; k += blockDim.x) s += part[k];
-  const double tot = block_sum(s, lds);
-  if (threadIdx.x == 0) rzn_s = tot;
+  const double tot = block_sum(s, lds);  // has the barriers that publish Ls and gr4
+  if (threadIdx.x == 0) {
+    double extra = 0.0;
+    if (defl) {
+      // z_c = (Q^T S Q)^-1 (r_c - G^T r_s); its share of r.z is (r_c - G^T r_s).z_c
+      double tc[AMG_DEFL_NC];
+      for (int k = 0; k < cg.ncam; ++k) tc[k] = cg.r[o + k] - ((gr4[0][k] + gr4[1][k]) + (gr4[2][k] + gr4[3][k]));
+      cam_solve(cg.ncam, Ls, tc, zcs);
+      for (int k = 0; k < cg.ncam; ++k) extra += tc[k] * zcs[k];
+    }
+    rzn_s = tot + extra;
+  }
   __syncthreads();
   const double rzn = rzn_s;
   const double beta = (mode == 1) ? rzn / cg.scal[parity] : 0.0;
@@ -283,12 +322,20 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restr
   const bool on = i < cg.S;
   const double corr = has_coarse ? prolong_row(t, on ? i : 0, threadIdx.x & 63) : 0.0;
   if (on && r < 6) {
-    const double z = cg.z[6 * (int64_t)i + r] + corr;
+    double z = cg.z[6 * (int64_t)i + r] + corr;
+    if (defl) {
+      const double *Gi = cg.G + (6 * (int64_t)i + r) * cg.ncam;
+      for (int k = 0; k < cg.ncam; ++k) z -= Gi[k] * zcs[k];
+    }
     cg.p[6 * (int64_t)i + r] = (mode == 1) ? z + beta * cg.p[6 * (int64_t)i + r] : z;
   }
+  if (defl && blockIdx.x == 0 && threadIdx.x < cg.ncam) cg.z[o + threadIdx.x] = zcs[threadIdx.x];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t o = 6 * (int64_t)cg.S;
-    for (int k = 0; k < cg.ncam; ++k) cg.p[o + k] = (mode == 1) ? cg.z[o + k] + beta * cg.p[o + k] : cg.z[o + k];
+    for (int k = 0; k < cg.ncam; ++k) {
+      const double zc = defl ? zcs[k] : cg.z[o + k];
+      cg.p[o + k] = (mode == 1) ? zc + beta * cg.p[o + k] : zc;
+    }
     if (mode == 0) {
       cg.scal[0] = cg.scal[1] = cg.scal[2] = rzn;
       cg.scal[3] = cg.scal[4] = cg.scal[5] = 0.0;

@@ -113,6 +113,10 @@ struct ba_problem {
   bool cg_graph_failed = false;
   int cg_graph_precond = -1;          // preconditioner the captured batch was recorded with
   ba::Amg *amg = nullptr;             // multilevel preconditioner (built at the first PCG solve)
+  // camera coarse space of that preconditioner: G ~ S_ss^-1 S_sc, computed once per problem
+  double *d_G = nullptr, *d_SG = nullptr, *d_defl_part = nullptr, *d_E = nullptr, *d_Lcc_defl = nullptr, *d_part_gr = nullptr;
+  double *d_defl_b = nullptr;
+  bool have_G = false;
   // state
   bool have_params = false;
   // multi-GPU
@@ -689,7 +693,48 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
     }
     if (amg_levels(p->amg) < 2) use_amg = false;  // nothing to coarsen: plain block-Jacobi
   }
-  const int precond = use_amg ? 0 : 1;
+  // Camera coarse space: the few camera columns couple to every station, which a block-diagonal
+  // preconditioner cannot see.  With G ~ S_ss^-1 S_sc (a dozen PCG iterations per column, once per
+  // problem: it only has to be roughly right) the vectors Q = [-G; I] are added as a coarse space,
+  //   z = [M_ss^-1 r_s; 0] + Q (Q^T S Q)^-1 Q^T r,
+  // which is symmetric positive definite for any G.
+  bool use_defl = use_amg && p->ncam > 0 && p->ncam <= defl_max_cam();
+  if (use_defl) {
+    const size_t ns = 6 * (size_t)p->S;
+    if (!p->d_G) {
+      BA_TRY(p->dalloc(&p->d_G, ns * p->ncam));
+      BA_TRY(p->dalloc(&p->d_SG, ns * p->ncam));
+      BA_TRY(p->dalloc(&p->d_defl_part, (size_t)defl_gram_blocks(p->S) * 64));
+      BA_TRY(p->dalloc(&p->d_E, 64));
+      BA_TRY(p->dalloc(&p->d_Lcc_defl, 64));
+      BA_TRY(p->dalloc(&p->d_part_gr, ((size_t)cg2_blocks_vec(p->S) + 1) * defl_max_cam()));
+      BA_TRY(p->dalloc(&p->d_defl_b, ns));
+    }
+    if (!p->have_G) {
+      BsrCgArgs g = a;
+      g.ncam = 0;
+      g.b = p->d_defl_b;
+      for (int k = 0; k < p->ncam; ++k) {
+        launch_defl_get_column(s, p->S, p->ncam, k, p->d_Ssc, p->d_defl_b);
+        launch_amg_cg_init(s, g, p->amg, 0.0);
+        for (int itg = 0; itg < 12; ++itg) launch_amg_cg_iteration(s, g, p->amg, itg & 1);
+        launch_defl_set_column(s, p->S, p->ncam, k, p->d_x, p->d_G);
+      }
+      p->have_G = true;
+    }
+    launch_defl_corner(s, a, p->d_G, p->d_SG, p->d_defl_part, p->d_E, p->d_Lcc_defl, p->d_info);
+    int info = 0;
+    HIP_OK(hipMemcpyAsync(&info, p->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    if (info) {
+      use_defl = false;  // cannot happen for a positive definite S; be safe and drop the coarse space
+    } else {
+      a.G = p->d_G;
+      a.Lcc = p->d_Lcc_defl;
+      a.part_gr = p->d_part_gr;
+    }
+  }
+  const int precond = use_amg ? (use_defl ? 2 : 0) : 1;
   auto iteration = [&](int parity) {
     if (use_amg) launch_amg_cg_iteration(s, a, p->amg, parity);
     else launch_cg2_iteration(s, a, parity);
@@ -1442,6 +1487,7 @@ static int sync_shards(ba_problem *p) {
     amg_destroy(p->amg);
     p->amg = nullptr;
   }
+  p->have_G = false;
   return 0;
 }
 

@@ -296,6 +296,35 @@ __device__ __forceinline__ double station_precond(const double *__restrict__ Min
   return dot;
 }
 
+// per-workgroup partials of G^T r_s (thread i holds station i; 256 threads)
+#define DEFL_NC 8
+__device__ __forceinline__ void defl_partials(const BsrCgArgs &a, int i) {
+  __shared__ double lds_gr[4][DEFL_NC];
+  double gr[DEFL_NC];
+#pragma unroll
+  for (int k = 0; k < DEFL_NC; ++k) gr[k] = 0.0;
+  if (i < a.S) {
+    const double *Gi = a.G + 6 * (int64_t)i * a.ncam, *ri = a.r + 6 * (int64_t)i;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+      const double rv = ri[m];
+#pragma unroll
+      for (int k = 0; k < DEFL_NC; ++k)
+        if (k < a.ncam) gr[k] += Gi[m * a.ncam + k] * rv;
+    }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < DEFL_NC; ++k) {
+    const double v = wave_sum(gr[k]);
+    if (lane == 0) lds_gr[w][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < a.ncam)
+    a.part_gr[(int64_t)blockIdx.x * a.ncam + threadIdx.x] =
+        (lds_gr[0][threadIdx.x] + lds_gr[1][threadIdx.x]) + (lds_gr[2][threadIdx.x] + lds_gr[3][threadIdx.x]);
+}
+
 // x = 0, r = b, z = M^-1 r, p = z; per-workgroup partials of r.z
 __global__ void __launch_bounds__(256)
 k_cg2_init(BsrCgArgs a) {
@@ -312,16 +341,19 @@ k_cg2_init(BsrCgArgs a) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) a.p[6 * (int64_t)i + k] = a.z[6 * (int64_t)i + k];
   }
+  if (a.G) defl_partials(a, i);
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.ncam > 0) {
     const int64_t o = 6 * (int64_t)a.S;
     for (int k = 0; k < a.ncam; ++k) {
       a.x[o + k] = 0.0;
       a.r[o + k] = a.b[o + k];
     }
-    cam_precond(a.ncam, a.Lcc, a.r + o, a.z + o);
-    for (int k = 0; k < a.ncam; ++k) {
-      a.p[o + k] = a.z[o + k];
-      dot += a.r[o + k] * a.z[o + k];
+    if (!a.G) {  // with the coarse space the camera part of z needs G^T r_s: the last kernel does it
+      cam_precond(a.ncam, a.Lcc, a.r + o, a.z + o);
+      for (int k = 0; k < a.ncam; ++k) {
+        a.p[o + k] = a.z[o + k];
+        dot += a.r[o + k] * a.z[o + k];
+      }
     }
   }
   const double t = block_sum(dot, lds);
@@ -417,11 +449,19 @@ k_cg2_update1(BsrCgArgs a, int parity, int nblk_spmv) {
     }
     dot = station_precond(a.Minv, a.r, a.z, i);
   }
+  if (a.G) defl_partials(a, i);
   if (blockIdx.x == gridDim.x - 1) {
     // the last workgroup is the least loaded one: it also carries the camera entries.  A small
     // camera block is staged in LDS first: the substitution is one thread's chain of dependent loads.
     const bool staged = a.ncam > 0 && a.ncam <= CAM_STAGE;
-    if (staged) {
+    if (a.G) {
+      // camera coarse space: only x and r here, the camera part of z follows in the last kernel
+      if (threadIdx.x < a.ncam) {
+        a.x[o + threadIdx.x] += alpha * pcs[threadIdx.x];
+        a.r[o + threadIdx.x] -= alpha * red[1 + threadIdx.x];
+      }
+      if (threadIdx.x == 0) a.scal[4] = pq;
+    } else if (staged) {
       for (int k = threadIdx.x; k < a.ncam * a.ncam; k += blockDim.x) Ls[k] = a.Lcc[k];
       if (threadIdx.x < a.ncam) {
         a.x[o + threadIdx.x] += alpha * pcs[threadIdx.x];
@@ -488,6 +528,101 @@ k_cg2_update2(BsrCgArgs a, int parity, int nblk) {
 }
 
 // ------------------------------------------------------------------------------------------
+// camera coarse space: set-up
+// ------------------------------------------------------------------------------------------
+__global__ void k_defl_get_column(int64_t n, int ncam, int k, const double *__restrict__ M, double *__restrict__ v) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t < n) v[t] = M[t * ncam + k];
+}
+__global__ void k_defl_set_column(int64_t n, int ncam, int k, const double *__restrict__ v, double *__restrict__ M) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t < n) M[t * ncam + k] = v[t];
+}
+
+// SG = S_ss G for the ncam <= DEFL_NC columns of G at once (row-major [6S x ncam]); one wave per block row
+__global__ void __launch_bounds__(256)
+k_defl_spmm(BsrCgArgs a, const double *__restrict__ G, double *__restrict__ SG) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= a.S) return;
+  const int g = lane >> 3, r = lane & 7;
+  double acc[DEFL_NC];
+#pragma unroll
+  for (int k = 0; k < DEFL_NC; ++k) acc[k] = 0.0;
+  if (r < 6)
+    for (int b = a.rowptr[i] + g; b < a.rowptr[i + 1]; b += 8) {
+      const double *B = a.val + 36 * (int64_t)b + 6 * r, *X = G + 6 * (int64_t)a.col[b] * a.ncam;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) {
+        const double bv = B[m];
+#pragma unroll
+        for (int k = 0; k < DEFL_NC; ++k)
+          if (k < a.ncam) acc[k] += bv * X[m * a.ncam + k];
+      }
+    }
+#pragma unroll
+  for (int k = 0; k < DEFL_NC; ++k) {
+    acc[k] += __shfl_xor(acc[k], 8, 64);
+    acc[k] += __shfl_xor(acc[k], 16, 64);
+    acc[k] += __shfl_xor(acc[k], 32, 64);
+  }
+  if (lane < 6)
+#pragma unroll
+    for (int k = 0; k < DEFL_NC; ++k)
+      if (k < a.ncam) SG[(6 * (int64_t)i + lane) * a.ncam + k] = acc[k];
+}
+
+// per-workgroup partials of G^T SG - Ssc^T G - G^T Ssc (ncam x ncam, stored DEFL_NC x DEFL_NC)
+__global__ void __launch_bounds__(256)
+k_defl_gram(int64_t n, int ncam, const double *__restrict__ G, const double *__restrict__ SG, const double *__restrict__ Ssc,
+            double *__restrict__ part) {
+  __shared__ double lds[4][DEFL_NC * DEFL_NC];
+  double acc[DEFL_NC * DEFL_NC];
+#pragma unroll
+  for (int k = 0; k < DEFL_NC * DEFL_NC; ++k) acc[k] = 0.0;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    double g[DEFL_NC], sg[DEFL_NC], sc[DEFL_NC];
+#pragma unroll
+    for (int k = 0; k < DEFL_NC; ++k) {
+      g[k] = (k < ncam) ? G[t * ncam + k] : 0.0;
+      sg[k] = (k < ncam) ? SG[t * ncam + k] : 0.0;
+      sc[k] = (k < ncam) ? Ssc[t * ncam + k] : 0.0;
+    }
+#pragma unroll
+    for (int p = 0; p < DEFL_NC; ++p)
+#pragma unroll
+      for (int q = 0; q < DEFL_NC; ++q) acc[p * DEFL_NC + q] += g[p] * sg[q] - sc[p] * g[q] - g[p] * sc[q];
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < DEFL_NC * DEFL_NC; ++k) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) lds[w][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < DEFL_NC * DEFL_NC)
+    part[(int64_t)blockIdx.x * (DEFL_NC * DEFL_NC) + threadIdx.x] =
+        (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
+}
+
+// E = Scc + folded partials, symmetrised; copied to Lcc for the factorisation
+__global__ void __launch_bounds__(64)
+k_defl_corner(int ncam, int nparts, const double *__restrict__ part, const double *__restrict__ Scc, double *__restrict__ E,
+              double *__restrict__ Lcc) {
+  __shared__ double e[DEFL_NC * DEFL_NC];
+  const int t = threadIdx.x;
+  double s = 0.0;
+  for (int b = 0; b < nparts; ++b) s += part[(int64_t)b * (DEFL_NC * DEFL_NC) + t];
+  e[t] = s;
+  __syncthreads();
+  const int p = t / DEFL_NC, q = t % DEFL_NC;
+  if (p < ncam && q < ncam) {
+    const double v = Scc[p * ncam + q] + 0.5 * (e[p * DEFL_NC + q] + e[q * DEFL_NC + p]);
+    E[p * ncam + q] = v;
+    Lcc[p * ncam + q] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 static inline int nblk(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
 
 void launch_schur_blocks(hipStream_t s, int nu, const int *cstart, const int2 *dst, const int2 *pairs, const double *Y, double *val) {
@@ -527,6 +662,26 @@ void launch_cg2_init(hipStream_t s, const BsrCgArgs &a, double rtol) {
   const int nb = cg2_blocks_vec(a.S);
   hipLaunchKernelGGL(k_cg2_init, dim3(nb), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_cg2_init_finish, dim3(1), dim3(256), 0, s, a, nb, rtol);
+}
+int defl_max_cam() { return DEFL_NC; }
+void launch_defl_get_column(hipStream_t s, int S, int ncam, int k, const double *M, double *v) {
+  const int64_t n = 6 * (int64_t)S;
+  if (n > 0) hipLaunchKernelGGL(k_defl_get_column, dim3(nblk(n, 256)), dim3(256), 0, s, n, ncam, k, M, v);
+}
+void launch_defl_set_column(hipStream_t s, int S, int ncam, int k, const double *v, double *M) {
+  const int64_t n = 6 * (int64_t)S;
+  if (n > 0) hipLaunchKernelGGL(k_defl_set_column, dim3(nblk(n, 256)), dim3(256), 0, s, n, ncam, k, v, M);
+}
+int defl_gram_blocks(int S) {
+  const int b = nblk(6 * (int64_t)S, 256);
+  return b < 1 ? 1 : (b > 256 ? 256 : b);
+}
+void launch_defl_corner(hipStream_t s, const BsrCgArgs &a, const double *G, double *SG, double *part, double *E, double *Lcc, int *info) {
+  const int nb = defl_gram_blocks(a.S);
+  hipLaunchKernelGGL(k_defl_spmm, dim3(nblk(a.S, 4)), dim3(256), 0, s, a, G, SG);
+  hipLaunchKernelGGL(k_defl_gram, dim3(nb), dim3(256), 0, s, 6 * (int64_t)a.S, a.ncam, G, SG, a.Ssc, part);
+  hipLaunchKernelGGL(k_defl_corner, dim3(1), dim3(64), 0, s, a.ncam, nb, part, a.Scc, E, Lcc);
+  launch_cholesky(s, Lcc, a.ncam, info);
 }
 void launch_cg2_start(hipStream_t s, const BsrCgArgs &a) {
   hipLaunchKernelGGL(k_cg2_init, dim3(cg2_blocks_vec(a.S)), dim3(256), 0, s, a);

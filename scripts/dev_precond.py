@@ -16,18 +16,20 @@ N, S, P = net.n_obs, net.n_sta, net.n_pts
 t0 = time.time()
 r, J = orc.residual_jacobian_all(net)
 print("N S P", N, S, P, "jac %.1fs" % (time.time() - t0), flush=True)
-Js = J[:, :, 0:6]; Jp = J[:, :, 6:9]
+Js = J[:, :, 0:6]; Jp = J[:, :, 6:9]; Jcam = J[:, :, [9, 10, 11, 14, 15, 17, 18]]
 rows = (2 * np.arange(N)[:, None, None] + np.arange(2)[None, :, None])
 cs = (6 * net.obs_sta.astype(np.int64)[:, None, None] + np.arange(6)[None, None, :])
 cp = (3 * net.obs_pt.astype(np.int64)[:, None, None] + np.arange(3)[None, None, :])
 A_s = sp.csr_matrix((Js.ravel(), (np.broadcast_to(rows, Js.shape).ravel(), np.broadcast_to(cs, Js.shape).ravel())), shape=(2 * N, 6 * S))
 A_p = sp.csr_matrix((Jp.ravel(), (np.broadcast_to(rows, Jp.shape).ravel(), np.broadcast_to(cp, Jp.shape).ravel())), shape=(2 * N, 3 * P))
+A_c = Jcam.reshape(2 * N, 7).copy()
 del J, Js, Jp
 isig = (1.0 / net.pt_sigma).ravel()
 # Jacobi scaling as the solver does it: 1 / (1 + column norm)
 ns = np.sqrt(np.asarray(A_s.multiply(A_s).sum(axis=0)).ravel())
 npn = np.sqrt(np.asarray(A_p.multiply(A_p).sum(axis=0)).ravel() + isig ** 2)
 A_s = A_s @ sp.diags(1.0 / (1.0 + ns)); A_p = A_p @ sp.diags(1.0 / (1.0 + npn))
+A_c = A_c / (1.0 + np.sqrt((A_c ** 2).sum(axis=0)))
 pri = isig / (1.0 + npn)
 lm = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-4
 U = (A_s.T @ A_s).tocsr()
@@ -209,41 +211,66 @@ def apply_weighted(levels, x, wts):
         if y is not None: yk = yk + lev["P"] @ y
         y = yk
     return y
-for theta in (0.5,):
-    levels = build_hierarchy(Sc, theta)
-    lv = levels[:3]
-    run("all-Jacobi 3 levels", lambda x: apply_additive(lv, x))
-    # level-0 smoother = exact solves on the aggregates (cluster Jacobi)
-    B0 = bsr_sorted(Sc)
-    agg, na = aggregate_graph(B0, theta)
-    order = np.argsort(agg, kind="stable")
-    starts = np.concatenate([[0], np.cumsum(np.bincount(agg, minlength=na))])
-    Sd = Sc.tocsr()
-    invs = []
-    dofs = []
-    for c in range(na):
-        st = order[starts[c]:starts[c + 1]]
-        d = (6 * st[:, None] + np.arange(6)[None, :]).ravel()
-        dofs.append(d)
-        invs.append(np.linalg.inv(Sd[d][:, d].toarray()))
-    def cluster_jacobi(x):
-        z = np.zeros_like(x)
-        for d, iv in zip(dofs, invs):
-            z[d] = iv @ x[d]
-        return z
-    run("cluster-Jacobi alone (aggregate blocks)", cluster_jacobi)
-    def ml_cluster(x):
-        rs = [x]
-        for lev in lv[:-1]:
-            rs.append(lev["P"].T @ rs[-1])
-        y = None
-        for k in range(len(lv) - 1, 0, -1):
-            lev = lv[k]
-            yk = np.einsum("sij,sj->si", lev["dinv"], rs[k].reshape(lev["nb"], 6)).ravel()
-            if y is not None: yk = yk + lev["P"] @ y
-            y = yk
-        return cluster_jacobi(x) + lv[0]["P"] @ y
-    run("3 levels, level 0 cluster-Jacobi", ml_cluster)
+# ---- bordered system with the 7 camera columns
+ApTAc = A_p.T @ A_c                      # 3P x 7
+T_ = Vinv @ ApTAc
+Ssc = A_s.T @ A_c - W @ T_               # 6S x 7
+Scc = A_c.T @ A_c - ApTAc.T @ T_
+Scc = Scc + np.diag(lm * np.diag(Scc))
+nfull = n + 7
+def Afull(x):
+    xs, xc = x[:n], x[n:]
+    return np.concatenate([Sc @ xs + Ssc @ xc, Ssc.T @ xs + Scc @ xc])
+Aop = spla.LinearOperator((nfull, nfull), matvec=Afull)
+bfull = Afull(rng.standard_normal(nfull))
+def runfull(name, M, tol=1e-10, maxit=5000):
+    it = [0]
+    def cb(xk): it[0] += 1
+    x, info = spla.cg(Aop, bfull, rtol=tol, maxiter=maxit, M=spla.LinearOperator((nfull, nfull), matvec=M), callback=cb)
+    print("%-60s iters %5d  relres %.2e" % (name, it[0], np.linalg.norm(bfull - Afull(x)) / np.linalg.norm(bfull)), flush=True)
+levels = build_hierarchy(Sc, 0.5)
+lv = levels[:3]
+Mss = lambda x: apply_additive(lv, x)
+Scc_inv = np.linalg.inv(Scc)
+run("stations only, 3-level additive", Mss)
+runfull("bordered, block-diagonal [AMG, Scc]", lambda x: np.concatenate([Mss(x[:n]), Scc_inv @ x[n:]]))
+# arrow preconditioner with G ~ Sss^-1 Ssc
+def arrow(G, scale=1.0):
+    Shat = Scc - Ssc.T @ G
+    w = np.linalg.eigvalsh(Shat)
+    print("   eig(Shat) min %.3e max %.3e" % (w.min(), w.max()))
+    Si = np.linalg.inv(Shat)
+    def M(x):
+        ts = Mss(x[:n]) * scale
+        tc = x[n:] - G.T @ x[:n]
+        zc = Si @ tc
+        return np.concatenate([ts - G @ zc, zc])
+    return M
+def pcg_cols(A, M, k_it, x0=None):
+    cols = []
+    for k in range(7):
+        x, info = spla.cg(A, Ssc[:, k], x0=None if x0 is None else x0[:, k], rtol=1e-30, maxiter=k_it, M=spla.LinearOperator((n, n), matvec=M))
+        cols.append(x)
+    return np.column_stack(cols)
+def coarse(G):
+    # z = [M^-1 r_s; 0] + Q (Q^T S Q)^-1 Q^T r,  Q = [-G; I]
+    SG = Sc @ G
+    E = Scc - Ssc.T @ G - G.T @ Ssc + G.T @ SG
+    Ei = np.linalg.inv(E)
+    def M(x):
+        zc = Ei @ (x[n:] - G.T @ x[:n])
+        return np.concatenate([Mss(x[:n]) - G @ zc, zc])
+    return M
+for k_it in (3, 10):
+    runfull("coarse space Q=[-G;I], G from %d PCG iterations" % k_it, coarse(pcg_cols(Sc, Mss, k_it)))
+# stale G: computed for a more strongly damped matrix (earlier LM iteration)
+U0 = (A_s.T @ A_s).tocsr()
+for lm_old in (1e-4, 1e-5):
+    S_old = (Sc + sp.diags((lm_old - lm) * U0.diagonal())).tocsr()
+    lev_old = build_hierarchy(S_old, 0.5)[:3]
+    G_old = pcg_cols(S_old, lambda x: apply_additive(lev_old, x), 10)
+    runfull("coarse space with G from the matrix damped %.0e (10 its)" % lm_old, coarse(G_old))
+    runfull("   same, refreshed by 2 warm-started PCG iterations", coarse(pcg_cols(Sc, Mss, 2, G_old)))
 sys.exit(0)
 def nested(aggf, a2):
     cx = np.bincount(aggf, XY[:, 0]) / np.bincount(aggf); cy = np.bincount(aggf, XY[:, 1]) / np.bincount(aggf)
