@@ -255,20 +255,7 @@ k_amg_prolong(AmgTransfer t, double *__restrict__ yf) {
   if (on && r < 6) yf[6 * (int64_t)i + r] += s;
 }
 
-// L L^T z = t for a small dense factor (one thread)
 #define AMG_DEFL_NC 8
-__device__ __forceinline__ void cam_solve(int n, const double *L, const double *t, double *z) {
-  for (int i = 0; i < n; ++i) {
-    double s = t[i];
-    for (int k = 0; k < i; ++k) s -= L[i * n + k] * z[k];
-    z[i] = s / L[i * n + i];
-  }
-  for (int i = n - 1; i >= 0; --i) {
-    double s = z[i];
-    for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * z[k];
-    z[i] = s / L[i * n + i];
-  }
-}
 
 // Last kernel of an iteration.  Every workgroup folds the partials of r.z = r.D0^-1 r + sum_l rc_l.y_l
 // in the same order (identical beta everywhere); z = D0^-1 r (already in cg.z) + P0 y1;
@@ -279,7 +266,7 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restr
               int parity, int mode, double rtol) {
   __shared__ double lds[4];
   __shared__ double rzn_s;
-  __shared__ double Ls[AMG_DEFL_NC * AMG_DEFL_NC], gr4[4][16], zcs[AMG_DEFL_NC];
+  __shared__ double Ls[AMG_DEFL_NC * AMG_DEFL_NC], gr4[4][16], zcs[AMG_DEFL_NC], tcs[AMG_DEFL_NC], tot_s;
   if (mode == 1) {
     const double done = cg.scal[8 + parity];
     if (done != 0.0) {
@@ -304,16 +291,21 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restr
   for (int k = threadIdx.x; k < n_part_rz; k += blockDim.x) s += cg.part_rz[k];
   for (int k = threadIdx.x; k < n_part; k += blockDim.x) s += part[k];
   const double tot = block_sum(s, lds);  // has the barriers that publish Ls and gr4
+  if (threadIdx.x == 0) tot_s = tot;
+  if (defl && threadIdx.x < cg.ncam)  // t_c = r_c - G^T r_s
+    tcs[threadIdx.x] = cg.r[o + threadIdx.x] - ((gr4[0][threadIdx.x] + gr4[1][threadIdx.x]) + (gr4[2][threadIdx.x] + gr4[3][threadIdx.x]));
+  __syncthreads();
+  if (defl && threadIdx.x < cg.ncam) {  // z_c = (Q^T S Q)^-1 t_c with the explicit inverse
+    double zc = 0.0;
+    for (int m = 0; m < cg.ncam; ++m) zc += Ls[threadIdx.x * cg.ncam + m] * tcs[m];
+    zcs[threadIdx.x] = zc;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    double extra = 0.0;
-    if (defl) {
-      // z_c = (Q^T S Q)^-1 (r_c - G^T r_s); its share of r.z is (r_c - G^T r_s).z_c
-      double tc[AMG_DEFL_NC];
-      for (int k = 0; k < cg.ncam; ++k) tc[k] = cg.r[o + k] - ((gr4[0][k] + gr4[1][k]) + (gr4[2][k] + gr4[3][k]));
-      cam_solve(cg.ncam, Ls, tc, zcs);
-      for (int k = 0; k < cg.ncam; ++k) extra += tc[k] * zcs[k];
-    }
-    rzn_s = tot + extra;
+    double extra = 0.0;  // the camera share of r.z is t_c . z_c
+    if (defl)
+      for (int k = 0; k < cg.ncam; ++k) extra += tcs[k] * zcs[k];
+    rzn_s = tot_s + extra;
   }
   __syncthreads();
   const double rzn = rzn_s;

@@ -114,7 +114,7 @@ struct ba_problem {
   int cg_graph_precond = -1;          // preconditioner the captured batch was recorded with
   ba::Amg *amg = nullptr;             // multilevel preconditioner (built at the first PCG solve)
   // camera coarse space of that preconditioner: G ~ S_ss^-1 S_sc, computed once per problem
-  double *d_G = nullptr, *d_SG = nullptr, *d_defl_part = nullptr, *d_E = nullptr, *d_Lcc_defl = nullptr, *d_part_gr = nullptr;
+  double *d_G = nullptr, *d_GT = nullptr, *d_SG = nullptr, *d_defl_part = nullptr, *d_E = nullptr, *d_Lcc_defl = nullptr, *d_part_gr = nullptr;
   double *d_defl_b = nullptr;
   bool have_G = false;
   // state
@@ -703,6 +703,7 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
     const size_t ns = 6 * (size_t)p->S;
     if (!p->d_G) {
       BA_TRY(p->dalloc(&p->d_G, ns * p->ncam));
+      BA_TRY(p->dalloc(&p->d_GT, ns * p->ncam));
       BA_TRY(p->dalloc(&p->d_SG, ns * p->ncam));
       BA_TRY(p->dalloc(&p->d_defl_part, (size_t)defl_gram_blocks(p->S) * 64));
       BA_TRY(p->dalloc(&p->d_E, 64));
@@ -718,7 +719,7 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
         launch_defl_get_column(s, p->S, p->ncam, k, p->d_Ssc, p->d_defl_b);
         launch_amg_cg_init(s, g, p->amg, 0.0);
         for (int itg = 0; itg < 12; ++itg) launch_amg_cg_iteration(s, g, p->amg, itg & 1);
-        launch_defl_set_column(s, p->S, p->ncam, k, p->d_x, p->d_G);
+        launch_defl_set_column(s, p->S, p->ncam, k, p->d_x, p->d_G, p->d_GT);
       }
       p->have_G = true;
     }
@@ -730,7 +731,8 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
       use_defl = false;  // cannot happen for a positive definite S; be safe and drop the coarse space
     } else {
       a.G = p->d_G;
-      a.Lcc = p->d_Lcc_defl;
+      a.GT = p->d_GT;
+      a.Lcc = p->d_E;  // the explicit inverse
       a.part_gr = p->d_part_gr;
     }
   }

@@ -136,9 +136,9 @@ struct BsrCgArgs {
   const double *val, *Ssc, *Scc, *Lcc, *Minv, *b;
   double *x, *r, *z, *p, *q, *scal, *part_pq, *part_qc, *part_rz;
   // camera coarse space of the multilevel preconditioner (null when not used): G [6S x ncam], an
-  // approximation of S_ss^-1 S_sc; Lcc is then the Cholesky factor of Q^T S Q, Q = [-G; I]
-  const double *G;
-  double *part_gr;  // per-workgroup partials of G^T r_s
+  // approximation of S_ss^-1 S_sc; Lcc is then the INVERSE of Q^T S Q, Q = [-G; I]
+  const double *G, *GT;  // by rows and by columns
+  double *part_gr;       // per-workgroup partials of G^T r_s
 };
 void launch_schur_blocks(hipStream_t s, int nu, const int *cstart, const int2 *dst, const int2 *pairs, const double *Y, double *val);
 void launch_bsr_add_diag(hipStream_t s, int S, const int *rowptr, const double *Sdiag, double *val);
@@ -158,8 +158,9 @@ void launch_cg2_iteration(hipStream_t s, const BsrCgArgs &a, int parity);
 void launch_bsr_spmv(hipStream_t s, const BsrCgArgs &a, int parity);
 int defl_max_cam();  // largest camera block the coarse space handles
 void launch_defl_get_column(hipStream_t s, int S, int ncam, int k, const double *M, double *v);
-void launch_defl_set_column(hipStream_t s, int S, int ncam, int k, const double *v, double *M);
-// Lcc = chol(Scc - Ssc^T G - G^T Ssc + G^T S_ss G); SG and part are work arrays ([6S x ncam], [defl_gram_blocks x 64])
+void launch_defl_set_column(hipStream_t s, int S, int ncam, int k, const double *v, double *M, double *MT);
+// E = (Scc - Ssc^T G - G^T Ssc + G^T S_ss G)^-1, Lcc its Cholesky factor before inversion; SG and part are work
+// arrays ([6S x ncam], [defl_gram_blocks x 64]); info[0] != 0 when the matrix was not positive definite
 int defl_gram_blocks(int S);
 void launch_defl_corner(hipStream_t s, const BsrCgArgs &a, const double *G, double *SG, double *part, double *E, double *Lcc, int *info);
 void launch_cg2_start(hipStream_t s, const BsrCgArgs &a);                     // x = 0, r = b, z = D^-1 r, partials of r.z

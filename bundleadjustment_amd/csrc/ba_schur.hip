@@ -304,14 +304,17 @@ __device__ __forceinline__ void defl_partials(const BsrCgArgs &a, int i) {
 #pragma unroll
   for (int k = 0; k < DEFL_NC; ++k) gr[k] = 0.0;
   if (i < a.S) {
-    const double *Gi = a.G + 6 * (int64_t)i * a.ncam, *ri = a.r + 6 * (int64_t)i;
+    // GT is G by columns: the six entries of a station are contiguous, neighbouring threads adjoin
+    const double *ri = a.r + 6 * (int64_t)i;
+    const double r0 = ri[0], r1 = ri[1], r2 = ri[2], r3 = ri[3], r4 = ri[4], r5 = ri[5];
+    const int64_t ld = 6 * (int64_t)a.S;
 #pragma unroll
-    for (int m = 0; m < 6; ++m) {
-      const double rv = ri[m];
-#pragma unroll
-      for (int k = 0; k < DEFL_NC; ++k)
-        if (k < a.ncam) gr[k] += Gi[m * a.ncam + k] * rv;
-    }
+    for (int k = 0; k < DEFL_NC; ++k)
+      if (k < a.ncam) {
+        const double2 *g = reinterpret_cast<const double2 *>(a.GT + k * ld + 6 * (int64_t)i);
+        const double2 g0 = g[0], g1 = g[1], g2 = g[2];
+        gr[k] = g0.x * r0 + g0.y * r1 + g1.x * r2 + g1.y * r3 + g2.x * r4 + g2.y * r5;
+      }
   }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -534,9 +537,13 @@ __global__ void k_defl_get_column(int64_t n, int ncam, int k, const double *__re
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (t < n) v[t] = M[t * ncam + k];
 }
-__global__ void k_defl_set_column(int64_t n, int ncam, int k, const double *__restrict__ v, double *__restrict__ M) {
+__global__ void k_defl_set_column(int64_t n, int ncam, int k, const double *__restrict__ v, double *__restrict__ M,
+                                  double *__restrict__ MT) {
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (t < n) M[t * ncam + k] = v[t];
+  if (t < n) {
+    M[t * ncam + k] = v[t];
+    MT[k * n + t] = v[t];
+  }
 }
 
 // SG = S_ss G for the ncam <= DEFL_NC columns of G at once (row-major [6S x ncam]); one wave per block row
@@ -663,14 +670,33 @@ void launch_cg2_init(hipStream_t s, const BsrCgArgs &a, double rtol) {
   hipLaunchKernelGGL(k_cg2_init, dim3(nb), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_cg2_init_finish, dim3(1), dim3(256), 0, s, a, nb, rtol);
 }
+// E <- (L L^T)^-1, column c by thread c (the factor is DEFL_NC x DEFL_NC at most)
+__global__ void __launch_bounds__(64)
+k_defl_invert(int n, const double *__restrict__ L, double *__restrict__ Einv) {
+  const int c = threadIdx.x;
+  if (c >= n) return;
+  double z[DEFL_NC];
+  for (int i = 0; i < n; ++i) {
+    double s = (i == c) ? 1.0 : 0.0;
+    for (int k = 0; k < i; ++k) s -= L[i * n + k] * z[k];
+    z[i] = s / L[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = z[i];
+    for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * z[k];
+    z[i] = s / L[i * n + i];
+  }
+  for (int i = 0; i < n; ++i) Einv[i * n + c] = z[i];
+}
+
 int defl_max_cam() { return DEFL_NC; }
 void launch_defl_get_column(hipStream_t s, int S, int ncam, int k, const double *M, double *v) {
   const int64_t n = 6 * (int64_t)S;
   if (n > 0) hipLaunchKernelGGL(k_defl_get_column, dim3(nblk(n, 256)), dim3(256), 0, s, n, ncam, k, M, v);
 }
-void launch_defl_set_column(hipStream_t s, int S, int ncam, int k, const double *v, double *M) {
+void launch_defl_set_column(hipStream_t s, int S, int ncam, int k, const double *v, double *M, double *MT) {
   const int64_t n = 6 * (int64_t)S;
-  if (n > 0) hipLaunchKernelGGL(k_defl_set_column, dim3(nblk(n, 256)), dim3(256), 0, s, n, ncam, k, v, M);
+  if (n > 0) hipLaunchKernelGGL(k_defl_set_column, dim3(nblk(n, 256)), dim3(256), 0, s, n, ncam, k, v, M, MT);
 }
 int defl_gram_blocks(int S) {
   const int b = nblk(6 * (int64_t)S, 256);
@@ -682,6 +708,7 @@ void launch_defl_corner(hipStream_t s, const BsrCgArgs &a, const double *G, doub
   hipLaunchKernelGGL(k_defl_gram, dim3(nb), dim3(256), 0, s, 6 * (int64_t)a.S, a.ncam, G, SG, a.Ssc, part);
   hipLaunchKernelGGL(k_defl_corner, dim3(1), dim3(64), 0, s, a.ncam, nb, part, a.Scc, E, Lcc);
   launch_cholesky(s, Lcc, a.ncam, info);
+  hipLaunchKernelGGL(k_defl_invert, dim3(1), dim3(64), 0, s, a.ncam, Lcc, E);
 }
 void launch_cg2_start(hipStream_t s, const BsrCgArgs &a) {
   hipLaunchKernelGGL(k_cg2_init, dim3(cg2_blocks_vec(a.S)), dim3(256), 0, s, a);
