@@ -75,7 +75,7 @@ struct ba_problem {
   std::vector<uint16_t> ap_mask_h;
   std::vector<uint8_t> iop_mask_h;
   // device: structure
-  int *d_pt_start = nullptr, *d_obs_pt = nullptr, *d_sta_list = nullptr, *d_chunk_sta = nullptr, *d_chunk_begin = nullptr;
+  int *d_pt_start = nullptr, *d_obs_pt = nullptr, *d_obs_sta = nullptr, *d_sta_list = nullptr, *d_chunk_sta = nullptr, *d_chunk_begin = nullptr;
   int *d_sta_chunk0 = nullptr, *d_sta_cam = nullptr, *d_pt_file = nullptr, *d_sta_used = nullptr, *d_info = nullptr;
   unsigned *d_flags = nullptr;
   double *d_obs = nullptr, *d_pt_prior = nullptr, *d_pt_isig = nullptr;
@@ -375,6 +375,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   HIP_OK(hipStreamCreate(&p->stream));
   BA_TRY(p->upload(&p->d_pt_start, pt_start));
   BA_TRY(p->upload(&p->d_obs_pt, obs_pt));
+  BA_TRY(p->upload(&p->d_obs_sta, e_sta));
   BA_TRY(p->upload(&p->d_sta_list, sta_list));
   BA_TRY(p->upload(&p->d_chunk_sta, chunk_sta));
   BA_TRY(p->upload(&p->d_chunk_begin, chunk_range));
@@ -506,7 +507,8 @@ StationArgs station_args(ba_problem *p, int voff, int stride) {
 PointArgs point_args(ba_problem *p, const double *vec) {
   PointArgs a{};
   a.P = p->P; a.S = p->S; a.ncmax = p->ncmax;
-  a.pt_start = p->d_pt_start; a.obs = p->d_obs; a.sta = p->d_sta; a.Jp = p->d_Jp; a.Jc = p->d_Jc; a.Vinv = p->d_Vinv;
+  a.pt_start = p->d_pt_start; a.obs_sta = p->d_obs_sta; a.sta_cam = p->d_sta_cam;
+  a.obs = p->d_obs; a.sta = p->d_sta; a.Jp = p->d_Jp; a.Jc = p->d_Jc; a.Vinv = p->d_Vinv;
   a.vec = vec; a.cam = p->d_cam; a.rec = p->d_rec;
   a.g_pt = p->d_g_pt; a.xyz = p->d_xyz; a.pt_prior = p->d_pt_prior; a.pt_isig = p->d_pt_isig; a.scale_pt = p->d_scale_pt;
   a.y_pt = p->d_y_pt; a.partial = p->d_partial;

@@ -393,17 +393,22 @@ k_point_pass(PointArgs a) {
   double acc = 0.0;
   if (jj < a.P) {
     const int e0 = a.pt_start[jj], e1 = a.pt_start[jj + 1];
+    // Back substitution keeps the products a = J_cam step of up to BS_KEEP observations in registers,
+    // so that the second walk neither reads nor writes the work slot of those rows.
+    constexpr int BS_KEEP = 8;
+    const bool keep = (MODE == MODE_BACKSUB) && (e1 - e0 <= BS_KEEP);
+    double ka0[BS_KEEP], ka1[BS_KEEP];
     double t0 = 0, t1 = 0, t2 = 0;
     for (int e = e0; e < e1; ++e) {
       double2 *rec = reinterpret_cast<double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
-      const int sta = __double2loint(a.obs[(int64_t)BA_OBS_STRIDE * e + 6]);
+      const int sta = a.obs_sta[e];
       const double2 *pv = reinterpret_cast<const double2 *>(a.vec + 6 * (int64_t)sta);
       const double2 v0 = pv[0], v1 = pv[1], v2 = pv[2];
       const double2 j0 = rec[0], j1 = rec[1], j2 = rec[2], j3 = rec[3], j4 = rec[4], j5 = rec[5];
       double a0 = j0.x * v0.x + j0.y * v0.y + j1.x * v1.x + j1.y * v1.y + j2.x * v2.x + j2.y * v2.y;
       double a1 = j3.x * v0.x + j3.y * v0.y + j4.x * v1.x + j4.y * v1.y + j5.x * v2.x + j5.y * v2.y;
       if (WITHCAM) {
-        const int c = __double2loint(a.sta[(int64_t)BA_STA_STRIDE * sta + 20]);
+        const int c = a.sta_cam[sta];
         const int nc = a.cam[c].nc, off = a.cam[c].off;
         const double *jc = a.Jc + 2 * (int64_t)a.ncmax * e;
         const double *vc = a.vec + 6 * (int64_t)a.S + off;
@@ -417,7 +422,16 @@ k_point_pass(PointArgs a) {
       t0 += q0.x * a0 + q1.y * a1;
       t1 += q0.y * a0 + q2.x * a1;
       t2 += q1.x * a0 + q2.y * a1;
-      rec[7] = make_double2(a0, a1);
+      if (keep) {
+#pragma unroll
+        for (int k = 0; k < BS_KEEP; ++k)
+          if (k == e - e0) {
+            ka0[k] = a0;
+            ka1[k] = a1;
+          }
+      } else {
+        rec[7] = make_double2(a0, a1);
+      }
     }
     const double *vi = a.Vinv + 6 * (int64_t)jj;
     const double Vi[6] = {vi[0], vi[1], vi[2], vi[3], vi[4], vi[5]};
@@ -436,14 +450,28 @@ k_point_pass(PointArgs a) {
       sym3_mul(Vi, g[0] - t0, g[1] - t1, g[2] - t2, u0, u1, u2);
       double *yo = a.y_pt + 3 * (int64_t)jj;
       yo[0] = u0; yo[1] = u1; yo[2] = u2;
-      for (int e = e0; e < e1; ++e) {
-        const double2 *rec = reinterpret_cast<const double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
-        const double2 *jp = reinterpret_cast<const double2 *>(a.Jp + 6 * (int64_t)e);
-        const double2 q0 = jp[0], q1 = jp[1], q2 = jp[2];
-        const double2 s = rec[7], r = rec[6];
-        const double m0 = -(s.x + q0.x * u0 + q0.y * u1 + q1.x * u2);
-        const double m1 = -(s.y + q1.y * u0 + q2.x * u1 + q2.y * u2);
-        acc += m0 * (r.x + 0.5 * m0) + m1 * (r.y + 0.5 * m1);
+      if (keep) {
+#pragma unroll
+        for (int k = 0; k < BS_KEEP; ++k)
+          if (k < e1 - e0) {
+            const int64_t e = e0 + k;
+            const double2 *jp = reinterpret_cast<const double2 *>(a.Jp + 6 * e);
+            const double2 q0 = jp[0], q1 = jp[1], q2 = jp[2];
+            const double2 r = reinterpret_cast<const double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e)[6];
+            const double m0 = -(ka0[k] + q0.x * u0 + q0.y * u1 + q1.x * u2);
+            const double m1 = -(ka1[k] + q1.y * u0 + q2.x * u1 + q2.y * u2);
+            acc += m0 * (r.x + 0.5 * m0) + m1 * (r.y + 0.5 * m1);
+          }
+      } else {
+        for (int e = e0; e < e1; ++e) {
+          const double2 *rec = reinterpret_cast<const double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
+          const double2 *jp = reinterpret_cast<const double2 *>(a.Jp + 6 * (int64_t)e);
+          const double2 q0 = jp[0], q1 = jp[1], q2 = jp[2];
+          const double2 s = rec[7], r = rec[6];
+          const double m0 = -(s.x + q0.x * u0 + q0.y * u1 + q1.x * u2);
+          const double m1 = -(s.y + q1.y * u0 + q2.x * u1 + q2.y * u2);
+          acc += m0 * (r.x + 0.5 * m0) + m1 * (r.y + 0.5 * m1);
+        }
       }
       // prior rows of this point
       const double *pr = a.pt_prior + 3 * (int64_t)jj, *is = a.pt_isig + 3 * (int64_t)jj;
