@@ -69,6 +69,7 @@ SOLVER_DENSE_SCHUR = 0
 SOLVER_PCG_SCHUR = 1
 SOLVER_PCG_IMPLICIT = 2
 CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
+ERR_INVALID, ERR_DEVICE, ERR_NUMERIC, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -4, -5
 STOP_REASONS = {0: "none", 1: "max_iterations", 2: "gradient_tol", 3: "parameter_tol",
                 4: "function_tol", 5: "min_radius", 6: "invalid_steps", 7: "linear_solver"}
 

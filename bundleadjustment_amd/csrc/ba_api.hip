@@ -830,7 +830,7 @@ int solve_pcg(ba_problem *p, const ba_options *opt, int *iters) {
 
 // dense reduced matrix (scattered from the block-sparse form, or one implicit-operator probe per
 // column when that form is not available), Cholesky on the matrix cores
-int solve_dense(ba_problem *p, bool explicit_blocks) {
+int build_dense(ba_problem *p, bool explicit_blocks) {
   hipStream_t s = p->stream;
   const size_t nr = (size_t)p->nr;
   if (!p->d_Sdense) {
@@ -843,6 +843,12 @@ int solve_dense(ba_problem *p, bool explicit_blocks) {
   } else {
     for (size_t k = 0; k < nr; ++k) BA_TRY(probe_column(p, (int64_t)k, p->d_Sdense + k * nr));
   }
+  return 0;
+}
+
+int solve_dense(ba_problem *p, bool explicit_blocks) {
+  hipStream_t s = p->stream;
+  BA_TRY(build_dense(p, explicit_blocks));
   launch_cholesky(s, p->d_Sdense, p->nr, p->d_info);
   launch_copy(s, p->nr, p->d_b, p->d_x);
   launch_chol_solve(s, p->d_Sdense, p->nr, p->d_x);
@@ -1213,6 +1219,75 @@ int ba_solve(ba_problem *p, const ba_options *opt, double *eop, double *xyz, dou
   BA_TRY(ba_set_parameters(p, eop, xyz, iop, ap));
   BA_TRY(ba_solve_resident(p, opt, summary, rows, rows_cap));
   return ba_get_parameters(p, eop, xyz, iop, ap);
+}
+
+int ba_covariance(ba_problem *p, double *var_eop, double *var_xyz, double *var_iop, double *var_ap) {
+  if (!p) return fail(BA_ERR_INVALID, "ba_covariance: null problem");
+  if (!p->have_params) return fail(BA_ERR_INVALID, "ba_covariance: no parameters set");
+  const int n = p->nr;
+  if (n > 8192) return fail(BA_ERR_UNSUPPORTED, "ba_covariance: reduced system of order %d (limit 8192: dense inverse)", n);
+  hipStream_t s = p->stream;
+  ba_options opt;
+  ba_default_options(&opt);
+  // Jacobi scaling for the conditioning of the factorisation (undone below); no LM damping
+  BA_TRY(init_scaling(p, &opt));
+  const bool use_explicit = p->explicit_ok;
+  LmState st{1e300, opt.min_lm_diagonal, opt.max_lm_diagonal, false, false, use_explicit ? 2 : 1};
+  BA_TRY(linearize(p, st));
+  std::vector<double> cs((size_t)std::max(n, 1), 0.0), vx(3 * (size_t)std::max(p->P, 1), 0.0);
+  if (n > 0) {
+    BA_TRY(build_dense(p, use_explicit));
+    launch_dense_fix_unused(s, p->S, n, p->d_sta_used, p->d_Sdense);
+    launch_cholesky(s, p->d_Sdense, n, p->d_info);
+    int info = 0;
+    HIP_OK(hipMemcpyAsync(&info, p->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    if (info) return fail(BA_ERR_NUMERIC, "ba_covariance: the reduced normal matrix is rank deficient (column %d of %d)", info - 1, n);
+  }
+  double *d_inv = nullptr, *d_tc = nullptr, *d_vx = nullptr, *d_cs = nullptr;
+  auto cleanup = [&]() {
+    if (d_inv) (void)hipFree(d_inv);
+    if (d_tc) (void)hipFree(d_tc);
+    if (d_vx) (void)hipFree(d_vx);
+    if (d_cs) (void)hipFree(d_cs);
+  };
+  const size_t nn = (size_t)std::max(n, 1);
+  if (hipMalloc((void **)&d_inv, nn * nn * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&d_tc, std::max<size_t>((size_t)p->P * p->ncam * 3, 1) * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&d_vx, vx.size() * sizeof(double)) != hipSuccess || hipMalloc((void **)&d_cs, nn * sizeof(double)) != hipSuccess) {
+    cleanup();
+    return fail(BA_ERR_DEVICE, "ba_covariance: out of device memory");
+  }
+  launch_chol_inverse(s, p->d_Sdense, n, d_inv);
+  CovArgs ca{};
+  ca.P = p->P; ca.S = p->S; ca.n = n; ca.ncmax = p->ncmax;
+  ca.pt_start = p->d_pt_start; ca.obs_sta = p->d_obs_sta; ca.sta_cam = p->d_sta_cam; ca.sta_used = p->d_sta_used; ca.pt_file = p->d_pt_file;
+  ca.rec = p->d_rec; ca.Jp = p->d_Jp; ca.Jc = p->d_Jc; ca.Vinv = p->d_Vinv; ca.Sinv = d_inv;
+  ca.scale_pt = p->d_scale_pt; ca.scale_sta = p->d_scale_sta; ca.scale_cam = p->d_scale_cam; ca.cam = p->d_cam;
+  ca.Tc = d_tc; ca.var_xyz = d_vx; ca.var_cs = d_cs;
+  launch_cov(s, ca);
+  hipError_t e1 = hipMemcpyAsync(vx.data(), d_vx, vx.size() * sizeof(double), hipMemcpyDeviceToHost, s);
+  hipError_t e2 = hipMemcpyAsync(cs.data(), d_cs, nn * sizeof(double), hipMemcpyDeviceToHost, s);
+  hipError_t e3 = hipStreamSynchronize(s);
+  cleanup();
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(BA_ERR_DEVICE, "ba_covariance: download failed");
+  BA_TRY(p->check_kernels());
+  if (var_xyz) std::copy(vx.begin(), vx.begin() + 3 * (size_t)p->P, var_xyz);
+  if (var_eop) std::copy(cs.begin(), cs.begin() + 6 * (size_t)p->S, var_eop);
+  for (int c = 0; c < p->C; ++c) {
+    const CamRec &r = p->cam_h[c];
+    if (var_iop) var_iop[3 * c] = var_iop[3 * c + 1] = var_iop[3 * c + 2] = 0.0;
+    if (var_ap) std::fill(var_ap + 16 * (size_t)c, var_ap + 16 * (size_t)c + 16, 0.0);
+    int pos = 0;
+    for (int q = 0; q < BA_NCAMPAR; ++q) {
+      if (!(r.mask & (1u << q))) continue;
+      const double v = cs[6 * (size_t)p->S + r.off + pos];
+      if (q < 3) { if (var_iop) var_iop[3 * c + q] = v; }
+      else if (var_ap) var_ap[16 * (size_t)c + q - 3] = v;
+      ++pos;
+    }
+  }
+  return 0;
 }
 
 int ba_evaluate(ba_problem *p, const double *eop, const double *xyz, const double *iop, const double *ap, int apply_loss,

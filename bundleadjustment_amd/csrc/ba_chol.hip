@@ -149,6 +149,47 @@ k_chol_solve(const double *__restrict__ L, int n, double *__restrict__ b) {
   }
 }
 
+// the same for many right-hand sides, one workgroup each: column c of B (stored as row c, n entries)
+__global__ void __launch_bounds__(256)
+k_chol_solve_many(const double *__restrict__ L, int n, double *__restrict__ B) {
+  __shared__ double xi;
+  double *b = B + (int64_t)blockIdx.x * n;
+  for (int i = 0; i < n; ++i) {
+    if (threadIdx.x == 0) {
+      xi = b[i] / L[(int64_t)i * n + i];
+      b[i] = xi;
+    }
+    __syncthreads();
+    const double v = xi;
+    if (v != 0.0)
+      for (int r = i + 1 + threadIdx.x; r < n; r += blockDim.x) b[r] -= L[(int64_t)r * n + i] * v;
+    __syncthreads();
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    if (threadIdx.x == 0) {
+      xi = b[i] / L[(int64_t)i * n + i];
+      b[i] = xi;
+    }
+    __syncthreads();
+    const double v = xi;
+    for (int r = threadIdx.x; r < i; r += blockDim.x) b[r] -= L[(int64_t)i * n + r] * v;
+    __syncthreads();
+  }
+}
+
+// B = identity (n x n)
+__global__ void k_identity(int n, double *__restrict__ B) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t < (int64_t)n * n) B[t] = (t / n == t % n) ? 1.0 : 0.0;
+}
+
+// inverse of L L^T into B (n x n, symmetric)
+void launch_chol_inverse(hipStream_t s, const double *L, int n, double *B) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_identity, dim3((unsigned)(((int64_t)n * n + 255) / 256)), dim3(256), 0, s, n, B);
+  hipLaunchKernelGGL(k_chol_solve_many, dim3(n), dim3(256), 0, s, L, n, B);
+}
+
 void launch_cholesky(hipStream_t s, double *A, int n, int *info) {
   hipMemsetAsync(info, 0, sizeof(int), s);
   for (int k0 = 0; k0 < n; k0 += NB) {

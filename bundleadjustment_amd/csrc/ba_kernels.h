@@ -185,5 +185,19 @@ void launch_amg_cg_iteration(hipStream_t s, const BsrCgArgs &cg, const Amg *a, i
 // not positive.
 void launch_cholesky(hipStream_t s, double *A, int n, int *info);
 void launch_chol_solve(hipStream_t s, const double *L, int n, double *b);
+void launch_chol_inverse(hipStream_t s, const double *L, int n, double *B);  // B = (L L^T)^-1, n x n
+
+// covariance of the parameters from the inverse of the dense reduced matrix
+struct CovArgs {
+  int P, S, n, ncmax;
+  const int *pt_start, *obs_sta, *sta_cam, *sta_used, *pt_file;
+  const double *rec, *Jp, *Jc, *Vinv, *Sinv, *scale_pt, *scale_sta, *scale_cam;
+  const CamRec *cam;
+  double *Tc;       // work: [P x ncam x 3]
+  double *var_xyz;  // [3P], file order
+  double *var_cs;   // [n]: stations then camera columns
+};
+void launch_cov(hipStream_t s, const CovArgs &a);
+void launch_dense_fix_unused(hipStream_t s, int S, int n, const int *sta_used, double *A);
 
 }  // namespace ba

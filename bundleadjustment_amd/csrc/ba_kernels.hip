@@ -1117,10 +1117,110 @@ k_resjac_dense(CostArgs a, double *__restrict__ r_out, double *__restrict__ J_ou
 // ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// covariance of the parameters (src/main.cpp:5261-5279, 5443-5565)
+// ------------------------------------------------------------------------------------------
+// With the points eliminated, Cx of the camera-side parameters is S^-1 and that of point j is
+//   V^-1 + V^-1 W^T S^-1 W V^-1,   W V^-1 = sum_a [Js_a | Jc_a]^T (Jp_a V^-1),
+// everything in the Jacobi-scaled variables; the scales are undone at the end.
+__global__ void k_cov_camside(CovArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.n) return;
+  const double v = a.Sinv[(int64_t)t * a.n + t];
+  const int ns = 6 * a.S;
+  double sc;
+  if (t < ns) sc = a.sta_used[t / 6] ? a.scale_sta[t] : 0.0;
+  else sc = a.scale_cam[t - ns];
+  a.var_cs[t] = v * sc * sc;
+}
+
+__global__ void __launch_bounds__(64)
+k_cov_points(CovArgs a) {
+  const int jj = blockIdx.x * blockDim.x + threadIdx.x;
+  if (jj >= a.P) return;
+  const int e0 = a.pt_start[jj], e1 = a.pt_start[jj + 1];
+  const int ns = 6 * a.S, ncam = a.n - ns;
+  const double *vi = a.Vinv + 6 * (int64_t)jj;
+  const double Vi[6] = {vi[0], vi[1], vi[2], vi[3], vi[4], vi[5]};
+  double *Tc = a.Tc + (int64_t)jj * ncam * 3;
+  for (int k = 0; k < 3 * ncam; ++k) Tc[k] = 0.0;
+  double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  // T_a = Js_a^T Q_a (6 x 3), Q_a = Jp_a V^-1 (2 x 3)
+  auto station_part = [&](int e, double T[6][3], double Q[2][3]) {
+    const double *rec = a.rec + (int64_t)BA_REC_STRIDE * e, *jp = a.Jp + 6 * (int64_t)e;
+    sym3_mul(Vi, jp[0], jp[1], jp[2], Q[0][0], Q[0][1], Q[0][2]);
+    sym3_mul(Vi, jp[3], jp[4], jp[5], Q[1][0], Q[1][1], Q[1][2]);
+    for (int r = 0; r < 6; ++r)
+      for (int m = 0; m < 3; ++m) T[r][m] = rec[r] * Q[0][m] + rec[6 + r] * Q[1][m];
+  };
+  for (int ea = e0; ea < e1; ++ea) {
+    double Ta[6][3], Qa[2][3];
+    station_part(ea, Ta, Qa);
+    const int ia = a.obs_sta[ea];
+    const int c = a.sta_cam[ia], nc = a.cam[c].nc, off = a.cam[c].off;
+    const double *jc = a.Jc + 2 * (int64_t)a.ncmax * ea;
+    for (int k = 0; k < nc; ++k)
+      for (int m = 0; m < 3; ++m) Tc[3 * (off + k) + m] += jc[k] * Qa[0][m] + jc[a.ncmax + k] * Qa[1][m];
+    for (int eb = e0; eb < e1; ++eb) {
+      double Tb[6][3], Qb[2][3];
+      station_part(eb, Tb, Qb);
+      const int ib = a.obs_sta[eb];
+      for (int r = 0; r < 6; ++r) {
+        const double *row = a.Sinv + (int64_t)(6 * ia + r) * a.n + 6 * ib;
+        double u[3] = {0, 0, 0};  // row r of Sinv[ia, ib] times T_b
+        for (int q = 0; q < 6; ++q)
+          for (int m = 0; m < 3; ++m) u[m] += row[q] * Tb[q][m];
+        for (int l = 0; l < 3; ++l)
+          for (int m = 0; m < 3; ++m) acc[l][m] += Ta[r][l] * u[m];
+      }
+    }
+  }
+  // camera columns: 2 T_s^T Sinv[s, c] T_c + T_c^T Sinv[c, c] T_c
+  for (int ea = e0; ea < e1; ++ea) {
+    double Ta[6][3], Qa[2][3];
+    station_part(ea, Ta, Qa);
+    const int ia = a.obs_sta[ea];
+    for (int r = 0; r < 6; ++r) {
+      const double *row = a.Sinv + (int64_t)(6 * ia + r) * a.n + ns;
+      double u[3] = {0, 0, 0};
+      for (int k = 0; k < ncam; ++k)
+        for (int m = 0; m < 3; ++m) u[m] += row[k] * Tc[3 * k + m];
+      for (int l = 0; l < 3; ++l)
+        for (int m = 0; m < 3; ++m) acc[l][m] += Ta[r][l] * u[m] + u[l] * Ta[r][m];
+    }
+  }
+  for (int k = 0; k < ncam; ++k) {
+    const double *row = a.Sinv + (int64_t)(ns + k) * a.n + ns;
+    double u[3] = {0, 0, 0};
+    for (int q = 0; q < ncam; ++q)
+      for (int m = 0; m < 3; ++m) u[m] += row[q] * Tc[3 * q + m];
+    for (int l = 0; l < 3; ++l)
+      for (int m = 0; m < 3; ++m) acc[l][m] += Tc[3 * k + l] * u[m];
+  }
+  const double *sp = a.scale_pt + 3 * (int64_t)jj;
+  double *out = a.var_xyz + 3 * (int64_t)a.pt_file[jj];
+  out[0] = (Vi[0] + acc[0][0]) * sp[0] * sp[0];
+  out[1] = (Vi[3] + acc[1][1]) * sp[1] * sp[1];
+  out[2] = (Vi[5] + acc[2][2]) * sp[2] * sp[2];
+}
+
+// stations without observations are not part of the program: unit diagonal keeps the factorisation defined
+__global__ void k_dense_fix_unused(int S, int n, const int *__restrict__ sta_used, double *__restrict__ A) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < 6 * S && !sta_used[t / 6]) A[(int64_t)t * n + t] = 1.0;
+}
+
 static inline int nblk(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
 
 void launch_station_prep(hipStream_t s, int S, const double *eop, const double *scale_sta, const int *sta_cam, double *sta) {
   if (S > 0) hipLaunchKernelGGL(k_station_prep, dim3(nblk(S, 128)), dim3(128), 0, s, S, eop, scale_sta, sta_cam, sta);
+}
+void launch_cov(hipStream_t s, const CovArgs &a) {
+  if (a.n > 0) hipLaunchKernelGGL(k_cov_camside, dim3(nblk(a.n, 256)), dim3(256), 0, s, a);
+  if (a.P > 0) hipLaunchKernelGGL(k_cov_points, dim3(nblk(a.P, 64)), dim3(64), 0, s, a);
+}
+void launch_dense_fix_unused(hipStream_t s, int S, int n, const int *sta_used, double *A) {
+  if (S > 0) hipLaunchKernelGGL(k_dense_fix_unused, dim3(nblk(6 * (int64_t)S, 256)), dim3(256), 0, s, S, n, sta_used, A);
 }
 int linearize_blocks(int P) { return nblk(P, 256); }
 int obs_rows_blocks(int64_t N) {

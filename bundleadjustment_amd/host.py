@@ -73,6 +73,7 @@ def lib():
         L.ba_net_set_free.argtypes = [C.c_void_p, C.c_uint16, C.c_uint8]
         L.ba_net_write_inputs.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         L.ba_net_write_results.argtypes = [C.c_void_p, C.c_char_p, c_double_p]
+        L.ba_net_set_variances.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]
         L.ba_net_num_ap_correction.argtypes = [C.c_void_p]
         L.ba_sigma0.restype = C.c_double
         L.ba_sigma0.argtypes = [C.POINTER(BaSummary), C.c_int32, C.c_int32, c_double_p]
@@ -157,6 +158,11 @@ class HostNetwork:
     def write_results(self, directory, residuals=None):
         r = None if residuals is None else np.ascontiguousarray(residuals, dtype=np.float64)
         _check(lib().ba_net_write_results(self._h, directory.encode(), r.ctypes.data_as(c_double_p) if r is not None else None))
+
+    def set_variances(self, var_eop=None, var_xyz=None, var_iop=None, var_ap=None):
+        """Variances for the sigma columns of the result files (the output of Problem.covariance()); None = default."""
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (var_eop, var_xyz, var_iop, var_ap)]
+        _check(lib().ba_net_set_variances(self._h, *[None if a is None else a.ctypes.data_as(c_double_p) for a in arrs]))
 
     def num_ap_correction(self):
         return lib().ba_net_num_ap_correction(self._h)

@@ -53,6 +53,8 @@ struct ba_network {
   std::vector<uint8_t> iopFree;
   // truth (synthetic only)
   std::vector<double> tEOP, tXYZ, tIOP, tAP;
+  // variances of the parameters (empty until ba_net_set_variances; src/main.cpp:5251-5256 defaults otherwise)
+  std::vector<double> vEOP, vXYZ, vIOP, vAP;
 };
 
 namespace {
@@ -561,11 +563,25 @@ int ba_net_write_inputs(const ba_network *n, const char *dir, const char *stem) 
   return 0;
 }
 
+int ba_net_set_variances(ba_network *n, const double *var_eop, const double *var_xyz, const double *var_iop, const double *var_ap) {
+  if (!n) return fail(BA_ERR_INVALID, "ba_net_set_variances: null network");
+  auto set = [](std::vector<double> &dst, const double *src, size_t cnt) {
+    if (src) dst.assign(src, src + cnt);
+    else dst.clear();
+  };
+  set(n->vEOP, var_eop, n->EOP.size());
+  set(n->vXYZ, var_xyz, n->XYZ.size());
+  set(n->vIOP, var_iop, n->IOP.size());
+  set(n->vAP, var_ap, n->AP.size());
+  return 0;
+}
+
 int ba_net_write_results(const ba_network *n, const char *dir, const double *residuals) {
   if (!n || !dir) return fail(BA_ERR_INVALID, "ba_net_write_results: null argument");
   const std::string d = std::string(dir) + "/";
   const double PI = kPi;
-  const double sentinel = std::sqrt(1E6);  // variances default to 1E6 when COMPUTECX is 0 (src/main.cpp:5251-5256)
+  // sqrt(variance) as at src/main.cpp:7085-7118; variances default to 1E6 when no covariance was computed (:5251-5256)
+  auto sd = [](const std::vector<double> &v, size_t k) { return std::sqrt(v.empty() ? 1E6 : v[k]); };
   FILE *fout = fopen((d + "temp.pho").c_str(), "w");
   if (!fout) return fail(BA_ERR_INVALID, "cannot write into %s", dir);
   for (size_t i = 0; i < n->imageTarget.size(); ++i)  // src/main.cpp:3130
@@ -577,8 +593,9 @@ int ba_net_write_results(const ba_network *n, const char *dir, const double *res
   for (size_t i = 0; i < n->eopStation.size(); ++i) {  // src/main.cpp:7096
     const double *E = &n->EOP[6 * i];
     fprintf(fout, "%i %.6lf %.6lf %.6lf %.6lf %.6lf %.6lf %.6lf %.6lf %.6lf %.6lf %.6lf %.6lf\n", n->eopStation[i],
-            E[0] * 180.0 / PI, E[1] * 180.0 / PI, E[2] * 180.0 / PI, E[3], E[4], E[5], sentinel * 180.0 / PI,
-            sentinel * 180.0 / PI, sentinel * 180.0 / PI, sentinel, sentinel, sentinel);
+            E[0] * 180.0 / PI, E[1] * 180.0 / PI, E[2] * 180.0 / PI, E[3], E[4], E[5], sd(n->vEOP, 6 * i) * 180.0 / PI,
+            sd(n->vEOP, 6 * i + 1) * 180.0 / PI, sd(n->vEOP, 6 * i + 2) * 180.0 / PI, sd(n->vEOP, 6 * i + 3),
+            sd(n->vEOP, 6 * i + 4), sd(n->vEOP, 6 * i + 5));
   }
   fclose(fout);
 
@@ -593,7 +610,7 @@ int ba_net_write_results(const ba_network *n, const char *dir, const double *res
   fout = fopen((d + "iop.jck").c_str(), "w");
   for (size_t i = 0; i < n->iopCamera.size(); ++i)  // src/main.cpp:7107
     fprintf(fout, "%i %.6lf %.6lf %.6lf %.6lf %.6lf %.6lf\n", n->iopCamera[i], n->IOP[3 * i], n->IOP[3 * i + 1],
-            n->IOP[3 * i + 2], sentinel, sentinel, sentinel);
+            n->IOP[3 * i + 2], sd(n->vIOP, 3 * i), sd(n->vIOP, 3 * i + 1), sd(n->vIOP, 3 * i + 2));
   fclose(fout);
 
   fout = fopen((d + "temp.iop").c_str(), "w");
@@ -610,7 +627,7 @@ int ba_net_write_results(const ba_network *n, const char *dir, const double *res
   for (size_t i = 0; i < n->iopCamera.size(); ++i) {  // src/main.cpp:7118
     fprintf(fout, "%i", n->iopCamera[i]);
     for (int k = 0; k < 16; ++k) fprintf(fout, " %.6lf", n->AP[16 * i + k]);
-    for (int k = 0; k < 16; ++k) fprintf(fout, " %.6lf", sentinel);
+    for (int k = 0; k < 16; ++k) fprintf(fout, " %.6lf", sd(n->vAP, 16 * i + k));
     fprintf(fout, "\n");
   }
   fclose(fout);
@@ -618,7 +635,7 @@ int ba_net_write_results(const ba_network *n, const char *dir, const double *res
   fout = fopen((d + "XYZ.jck").c_str(), "w");
   for (size_t i = 0; i < n->xyzTarget.size(); ++i)  // src/main.cpp:7085
     fprintf(fout, "%i %.6lf %.6lf %.6lf %.6lf %.6lf %.6lf\n", n->xyzTarget[i], n->XYZ[3 * i], n->XYZ[3 * i + 1],
-            n->XYZ[3 * i + 2], sentinel, sentinel, sentinel);
+            n->XYZ[3 * i + 2], sd(n->vXYZ, 3 * i), sd(n->vXYZ, 3 * i + 1), sd(n->vXYZ, 3 * i + 2));
   fclose(fout);
 
   if (residuals) {

@@ -15,17 +15,19 @@
 static void usage() {
   fprintf(stderr,
           "usage: ba_main <file.pho> <file.eop> <file.iop> <file.xyz> [--out DIR] [--free-ap MASK] [--free-iop MASK]\n"
-          "               [--solver dense|pcg] [--pcg-rtol X] [--max-iter N]\n"
+          "               [--solver dense|pcg] [--pcg-rtol X] [--max-iter N] [--covariance]\n"
           "       ba_main --synth C S P RAYS [same options]\n"
           "  MASK: bit k of --free-ap frees AP[k] (a1 a2 k1 k2 k3 p1 p2 ep1..ep9); default 0x4 = k1 only,\n"
-          "        the reference's choice (src/main.cpp:4487-4504).  --free-iop: bits xp yp c, default 7.\n");
+          "        the reference's choice (src/main.cpp:4487-4504).  --free-iop: bits xp yp c, default 7.\n"
+          "  --covariance: standard deviations of all parameters in the result files (the reference's COMPUTECX\n"
+          "        branch, src/main.cpp:5261); small networks only.\n");
 }
 
 int main(int argc, char **argv) {
   std::vector<std::string> pos;
   std::string out = ".";
   unsigned ap_mask = 0x4, iop_mask = 7;
-  bool synth = false;
+  bool synth = false, covariance = false;
   ba_options opt;
   ba_default_options(&opt);
   for (int i = 1; i < argc; ++i) {
@@ -38,6 +40,7 @@ int main(int argc, char **argv) {
     else if (a == "--pcg-rtol") opt.pcg_rtol = atof(next());
     else if (a == "--max-iter") opt.max_num_iterations = atoi(next());
     else if (a == "--synth") synth = true;
+    else if (a == "--covariance") covariance = true;
     else pos.push_back(a);
   }
   ba_network *net = nullptr;
@@ -83,6 +86,14 @@ int main(int argc, char **argv) {
   const double s0 = ba_sigma0(&sm, d.n_pts, ba_net_num_ap_correction(net), &red);
   printf("        *Ceres Quadratic Error: %g\n        *Ceres Redundancy: %g\n        *Ceres A Posteriori Variance: %g\n"
          "        *Ceres A Posteriori Std Dev: %g\n", 2 * sm.final_cost, red, s0 * s0, s0);
+  if (covariance) {
+    std::vector<double> ve(6 * (size_t)d.n_sta + 1), vx(3 * (size_t)d.n_pts + 1), vi(3 * (size_t)d.n_cam + 1), va(16 * (size_t)d.n_cam + 1);
+    if (ba_covariance(p, ve.data(), vx.data(), vi.data(), va.data())) {
+      fprintf(stderr, "error: %s\n", ba_last_error());
+      return 1;
+    }
+    ba_net_set_variances(net, ve.data(), vx.data(), vi.data(), va.data());
+  }
   std::vector<double> res(2 * (size_t)d.n_obs + 3 * (size_t)d.n_pts + 3 * (size_t)d.n_cam);
   double cost = 0;
   if (ba_evaluate(p, ba_net_eop(net), ba_net_xyz(net), ba_net_iop(net), ba_net_ap(net), 1, &cost, res.data())) {

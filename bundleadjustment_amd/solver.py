@@ -19,7 +19,7 @@ KERNEL_LINEARIZE, KERNEL_POINT_APPLY, KERNEL_STATION_GATHER, KERNEL_COST = 0, 1,
 
 # every entry point include/ba_gpu.h declares
 EXPORTS = ("ba_default_options", "ba_create", "ba_destroy", "ba_set_parameters", "ba_get_parameters",
-           "ba_solve_resident", "ba_solve", "ba_evaluate", "ba_sparsity", "ba_residual_jacobian", "ba_time_kernel",
+           "ba_solve_resident", "ba_solve", "ba_evaluate", "ba_covariance", "ba_sparsity", "ba_residual_jacobian", "ba_time_kernel",
            "ba_set_allreduce", "ba_copy_to_host", "ba_copy_to_device", "ba_rccl_unique_id", "ba_use_rccl", "ba_last_error")
 
 
@@ -150,6 +150,14 @@ class Problem:
         _check(lib().ba_evaluate(self._h, _dp(eop), _dp(xyz), _dp(iop), _dp(ap), int(bool(apply_loss)), C.byref(cost),
                                  _dp(res) if residuals else None))
         return cost.value, res
+
+    def covariance(self):
+        """Variances of all parameters at the values the problem holds: (var_eop [S,6], var_xyz [P,3], var_iop [C,3], var_ap [C,16])."""
+        n = self.net
+        ve, vx = np.zeros((n.n_sta, 6)), np.zeros((n.n_pts, 3))
+        vi, va = np.zeros((n.n_cam, 3)), np.zeros((n.n_cam, 16))
+        _check(lib().ba_covariance(self._h, _dp(ve), _dp(vx), _dp(vi), _dp(va)))
+        return ve, vx, vi, va
 
     def sparsity(self):
         nr, nc, nnz = C.c_int32(), C.c_int32(), C.c_int64()

@@ -205,6 +205,20 @@ int ba_evaluate(ba_problem *p, const double *eop, const double *xyz, const doubl
                 const double *ap, int apply_loss, double *cost, double *residuals);
 
 /*
+ * Variances of all parameters at the values the problem currently holds (after ba_set_parameters or
+ * ba_solve_resident).  Replaces the COMPUTECX block, src/main.cpp:5261-5279 (ceres::Covariance with
+ * apply_loss_function = true over all parameter blocks) and the extraction of the diagonals at
+ * :5443-5565 into xyzVariance, eopVariance, iopVariance and apVariance, whose layout the outputs keep:
+ * var_eop [6*n_sta], var_xyz [3*n_pts], var_iop [3*n_cam], var_ap [16*n_cam] (any may be NULL);
+ * parameters held constant and stations without observations get 0.  The reference multiplies by
+ * aposterioriVariance, which it has reset to 1 at :4955, so the values are not scaled here either.
+ * Computed from the inverse of the dense reduced camera system: networks with 6*n_sta + free camera
+ * parameters <= 8192 only (BA_ERR_UNSUPPORTED beyond).  A rank-deficient network is an error
+ * (the reference's DENSE_SVD pseudo-inverse would truncate it instead).
+ */
+int ba_covariance(ba_problem *p, double *var_eop, double *var_xyz, double *var_iop, double *var_ap);
+
+/*
  * Structure of the Jacobian that problem.Evaluate(..., &jacobian) returns at
  * src/main.cpp:6664 as a ceres::CRSMatrix: rows[] has num_rows+1 offsets, cols[] the column
  * of every structural non-zero.  Call with rows == cols == NULL to get the sizes.

@@ -79,8 +79,15 @@ int ba_net_write_inputs(const ba_network *net, const char *dir, const char *stem
 
 /* Writes temp.pho, EOP.jck, temp.eop, iop.jck, temp.iop, ap.jck, XYZ.jck, image.jck into dir.
  * residuals = the 2*n_obs leading entries of ba_evaluate(..., apply_loss=1, ...). The sigma
- * columns carry the reference's COMPUTECX=0 sentinels (sqrt(1e6); redundancy 1e6). */
+ * columns carry sqrt(variance) (src/main.cpp:7085-7118) of the variances given to
+ * ba_net_set_variances, else the reference's COMPUTECX=0 defaults (sqrt(1e6); redundancy 1e6). */
 int ba_net_write_results(const ba_network *net, const char *dir, const double *residuals);
+
+/* Variances of the parameters for the result files, in the layout of ba_covariance (src/main.cpp:5200-5203:
+ * eopVariance [6 per station], xyzVariance [3 per point], iopVariance [3 per camera], apVariance [16 per camera]);
+ * a NULL array goes back to the default. */
+int ba_net_set_variances(ba_network *net, const double *var_eop, const double *var_xyz, const double *var_iop,
+                         const double *var_ap);
 
 /* src/main.cpp:4907-4910: redundancy and a-posteriori standard deviation.
  * num_ap_correction = number of AP fixed by the subset parameterisation (:4509). */

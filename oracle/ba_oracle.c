@@ -999,6 +999,88 @@ double bao_linearize_once(const ba_dims *d, const ba_inputs *in, const double *e
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* Covariance of the estimated parameters                                                 */
+/* ------------------------------------------------------------------------------------ */
+/* src/main.cpp:5261-5279, 5443-5565: ceres::Covariance with apply_loss_function = true over all
+ * parameter blocks; the reference keeps the diagonal (xyzVariance, eopVariance, iopVariance,
+ * apVariance) and multiplies by aposterioriVariance, which it has reset to 1 (:4955).
+ * [CERES] Covariance: Cx = (J^T J)^-1 of the reduced program at the given point, J with the loss
+ * correction, in the tangent space of each block; coordinates held constant by a
+ * SubsetParameterization and constant blocks get zero rows and columns.  The reference asks for
+ * the DENSE_SVD pseudo-inverse (null_space_rank = -1); with the XYZ and IOP priors in place the
+ * matrix has full rank and the pseudo-inverse is the inverse, which is what is computed here (by
+ * Cholesky of the symmetrically scaled normal matrix).  A rank-deficient network is reported as an
+ * error instead of being truncated. */
+int bao_covariance(const ba_dims *d, const ba_inputs *in, const double *eop, const double *xyz, const double *iop,
+                   const double *ap, double *var_eop, double *var_xyz, double *var_iop, double *var_ap) {
+  prob_t q;
+  int rc = prob_init(&q, d, in, 1);
+  if (rc) { prob_free(&q); return rc; }
+  linearize(&q, eop, xyz, iop, ap);
+  const int nt = q.nt, ncm = q.ncmax ? q.ncmax : 1;
+  if ((double)nt * nt * 8.0 > 6e9) { prob_free(&q); FAIL(BA_ERR_INVALID, "covariance: %d unknowns is too many for the dense oracle", nt); }
+  double *H = calloc((size_t)nt * nt + 1, sizeof(double)), *sc = calloc(nt + 1, sizeof(double));
+  int idx[9 + NCAMPAR];
+  double v0[9 + NCAMPAR], v1[9 + NCAMPAR];
+  for (int n = 0; n < q.N; ++n) {
+    const int i = in->obs_sta[n], j = in->obs_pt[n], c = in->sta_cam[i];
+    const double *Js = q.Js + 12 * (size_t)n, *Jp = q.Jp + 6 * (size_t)n, *Jc = q.Jc + 2 * (size_t)ncm * n;
+    int m = 0;
+    for (int k = 0; k < 6; ++k, ++m) { idx[m] = COL_STA(&q, i) + k; v0[m] = Js[k]; v1[m] = Js[6 + k]; }
+    for (int k = 0; k < 3; ++k, ++m) { idx[m] = COL_PT(&q, j) + k; v0[m] = Jp[k]; v1[m] = Jp[3 + k]; }
+    for (int k = 0; k < q.cam_nc[c]; ++k, ++m) { idx[m] = COL_CAM(&q, c) + k; v0[m] = Jc[k]; v1[m] = Jc[ncm + k]; }
+    for (int a = 0; a < m; ++a)
+      for (int b = 0; b < m; ++b) H[(size_t)idx[a] * nt + idx[b]] += v0[a] * v0[b] + v1[a] * v1[b];
+  }
+  for (int j = 0; j < 3 * q.P; ++j) H[(size_t)(6 * q.S + j) * nt + 6 * q.S + j] += q.jp[j] * q.jp[j];
+  for (int k = 0; k < q.ncam; ++k) {
+    const size_t cidx = 6 * (size_t)q.S + 3 * (size_t)q.P + k;
+    H[cidx * nt + cidx] += q.jc[k] * q.jc[k];
+  }
+  /* stations without observations are not in the program: keep them out of the inverse */
+  for (int i = 0; i < q.S; ++i)
+    if (!q.sta_used[i])
+      for (int k = 0; k < 6; ++k) H[(size_t)(6 * i + k) * nt + 6 * i + k] = 1.0;
+  for (int i = 0; i < nt; ++i) {
+    const double dgl = H[(size_t)i * nt + i];
+    if (!(dgl > 0.0)) { free(H); free(sc); prob_free(&q); FAIL(BA_ERR_NUMERIC, "covariance: unknown %d has no information", i); }
+    sc[i] = 1.0 / sqrt(dgl);
+  }
+  for (int i = 0; i < nt; ++i)
+    for (int j = 0; j < nt; ++j) H[(size_t)i * nt + j] *= sc[i] * sc[j];
+  const int bad = chol_factor(H, nt);
+  if (bad) { free(H); free(sc); prob_free(&q); FAIL(BA_ERR_NUMERIC, "covariance: normal matrix is rank deficient (column %d of %d)", bad - 1, nt); }
+  /* diag((L L^T)^-1) = squared column norms of L^-1; L^-1 column c by forward substitution */
+  double *var = calloc(nt + 1, sizeof(double)), *x = calloc(nt + 1, sizeof(double));
+  for (int c = 0; c < nt; ++c) {
+    for (int i = c; i < nt; ++i) {
+      double sum = (i == c) ? 1.0 : 0.0;
+      const double *Li = H + (size_t)i * nt;
+      for (int k = c; k < i; ++k) sum -= Li[k] * x[k];
+      x[i] = sum / Li[i];
+    }
+    for (int i = c; i < nt; ++i) var[c] += x[i] * x[i];
+  }
+  for (int i = 0; i < nt; ++i) var[i] *= sc[i] * sc[i];
+  for (int i = 0; i < q.S; ++i)
+    for (int k = 0; k < 6; ++k) var_eop[6 * i + k] = q.sta_used[i] ? var[COL_STA(&q, i) + k] : 0.0;
+  for (int j = 0; j < 3 * q.P; ++j) var_xyz[j] = var[6 * q.S + j];
+  for (int c = 0; c < q.C; ++c) {
+    for (int k = 0; k < 3; ++k) var_iop[3 * c + k] = 0.0;
+    for (int k = 0; k < 16; ++k) var_ap[16 * c + k] = 0.0;
+    for (int k = 0; k < q.cam_nc[c]; ++k) {
+      const int par = q.cam_par[c * NCAMPAR + k];
+      const double v = var[COL_CAM(&q, c) + k];
+      if (par < 3) var_iop[3 * c + par] = v;
+      else var_ap[16 * c + par - 3] = v;
+    }
+  }
+  free(H); free(sc); free(var); free(x);
+  prob_free(&q);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* Trust-region loop  [CERES] TrustRegionMinimizer::Minimize (trust_region_minimizer.cc)  */
 /* ------------------------------------------------------------------------------------ */
 

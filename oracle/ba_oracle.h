@@ -67,6 +67,13 @@ int bao_solve(const ba_dims *d, const ba_inputs *in, const ba_options *opt, int 
 double bao_linearize_once(const ba_dims *d, const ba_inputs *in, const double *eop,
                           const double *xyz, const double *iop, const double *ap);
 
+/* Diagonal of the covariance matrix of all parameters (src/main.cpp:5261-5279, 5443-5565), in the
+ * reference's layout: var_eop [6S], var_xyz [3P], var_iop [3C], var_ap [16C]; zero for parameters held
+ * constant.  Dense: small networks only. */
+int bao_covariance(const ba_dims *d, const ba_inputs *in, const double *eop, const double *xyz,
+                   const double *iop, const double *ap, double *var_eop, double *var_xyz, double *var_iop,
+                   double *var_ap);
+
 const char *bao_last_error(void);
 
 #ifdef __cplusplus

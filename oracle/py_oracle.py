@@ -117,6 +117,19 @@ def solve(net, options, mode=SCHUR_DENSE, rows_cap=256):
     return eop, xyz, iop, ap, summary_to_dict(sm), rows_to_dicts(rows, min(sm.num_iterations, rows_cap))
 
 
+def covariance(net, eop=None, xyz=None, iop=None, ap=None):
+    """Variances of all parameters at the given point: (var_eop [S,6], var_xyz [P,3], var_iop [C,3], var_ap [C,16])."""
+    eop = net.eop if eop is None else eop
+    xyz = net.xyz if xyz is None else xyz
+    iop = net.iop if iop is None else iop
+    ap = net.ap if ap is None else ap
+    d, inp = net.dims(), net.inputs()
+    ve, vx = np.zeros((net.n_sta, 6)), np.zeros((net.n_pts, 3))
+    vi, va = np.zeros((net.n_cam, 3)), np.zeros((net.n_cam, 16))
+    _check(lib().bao_covariance(C.byref(d), C.byref(inp), _dp(eop), _dp(xyz), _dp(iop), _dp(ap), _dp(ve), _dp(vx), _dp(vi), _dp(va)))
+    return ve, vx, vi, va
+
+
 def linearize_once(net):
     d, inp = net.dims(), net.inputs()
     return lib().bao_linearize_once(C.byref(d), C.byref(inp), _dp(net.eop), _dp(net.xyz), _dp(net.iop), _dp(net.ap))

@@ -158,6 +158,40 @@ def test_multilevel_preconditioner_several_cameras():
     assert_solve_parity(g, o)
 
 
+@pytest.mark.parametrize("which", ["cfg1", "three_cameras", "fixed_camera"])
+def test_covariance_after_the_solve(which):
+    # a-posteriori variances (src/main.cpp:5261-5279, 5443-5565) at the adjusted parameters: the GPU's
+    # Schur-complement route against the oracle's inverse of the full normal matrix.  1e-7: the inverse
+    # amplifies rounding by the condition number of the network.
+    if which == "cfg1":
+        net = host.synth_config("cfg1").net
+    elif which == "three_cameras":
+        net = host.synth(n_cam=3, n_sta=12, n_pts=150, rays_per_point=6, ap_free_mask=host.AP_K1K2P1P2, seed=5).net
+    else:
+        net = host.synth(n_cam=1, n_sta=9, n_pts=80, rays_per_point=5, ap_free_mask=0, iop_free_mask=0, seed=7,
+                         outlier_fraction=0.1).net
+    with solver.Problem(net) as P:
+        P.set_parameters()
+        P.solve_resident(options(capi.SOLVER_DENSE_SCHUR))
+        eop, xyz, iop, ap = P.get_parameters()
+        got = P.covariance()
+    want = po.covariance(net, eop, xyz, iop, ap)
+    for g, w, name in zip(got, want, ("eop", "xyz", "iop", "ap")):
+        assert g.shape == w.shape
+        assert np.array_equal(g == 0.0, w == 0.0), name
+        nz = w != 0.0
+        assert np.all(np.abs(g[nz] - w[nz]) <= 1e-7 * w[nz]), (name, np.max(np.abs(g[nz] - w[nz]) / w[nz]))
+
+
+def test_covariance_too_large_is_refused():
+    net = host.synth(n_cam=1, n_sta=1400, n_pts=3000, rays_per_point=3, seed=1).net
+    with solver.Problem(net) as P:
+        P.set_parameters()
+        with pytest.raises(solver.BaError) as e:
+            P.covariance()
+        assert e.value.code == capi.ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("ls", ALL_SOLVERS)
 @pytest.mark.parametrize("clamp", [True, False])
 def test_rejected_steps(ls, clamp):

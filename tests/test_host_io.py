@@ -124,6 +124,22 @@ def test_result_files_format(net_files, tmp_path):
     assert len(open(out / "ap.jck").read().splitlines()[0].split()) == 33
     assert len(open(out / "XYZ.jck").read().splitlines()[0].split()) == 7
     assert len(open(out / "temp.pho").read().splitlines()) == net.n_obs
+    # with variances (the COMPUTECX branch, src/main.cpp:5443-5565): sigma columns = sqrt(variance) (:7085-7118)
+    ve, vx, vi, va = po.covariance(net)
+    hn.set_variances(ve, vx, vi, va)
+    hn.write_results(str(out), res)
+    f = open(out / "EOP.jck").read().splitlines()[2].split()
+    assert float(f[7]) == pytest.approx(np.degrees(np.sqrt(ve[2, 0])), abs=5e-7)
+    assert float(f[12]) == pytest.approx(np.sqrt(ve[2, 5]), abs=5e-7)
+    f = open(out / "XYZ.jck").read().splitlines()[5].split()
+    assert float(f[4]) == pytest.approx(np.sqrt(vx[5, 0]), abs=5e-7)
+    f = open(out / "iop.jck").read().splitlines()[0].split()
+    assert float(f[6]) == pytest.approx(np.sqrt(vi[0, 2]), abs=5e-7)
+    f = open(out / "ap.jck").read().splitlines()[0].split()
+    assert [float(x) for x in f[17:33]] == pytest.approx(list(np.sqrt(va[0])), abs=5e-7)
+    hn.set_variances()  # back to the defaults
+    hn.write_results(str(out), res)
+    assert open(out / "XYZ.jck").read().splitlines()[0].split()[4] == "1000.000000"
     # temp.* can be read back as inputs (the reference's outer loop does, src/main.cpp:3056)
     rd = host.read_network(str(out / "temp.pho"), str(out / "temp.eop"), str(out / "temp.iop"), paths(d)[3])
     assert rd.net.n_obs == net.n_obs

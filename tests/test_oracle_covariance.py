@@ -1,0 +1,66 @@
+"""The oracle's covariance (restating ceres::Covariance as the reference calls it, src/main.cpp:5261-5279)
+against an independent numpy computation from the oracle's own per-observation Jacobians.
+Parity with Ceres itself is unpinned: the reference holds no covariance output to compare with."""
+import numpy as np
+
+from bundleadjustment_amd import host
+from oracle import py_oracle as po
+
+
+def numpy_variances(net):
+    """diag((J^T J)^-1) with J assembled densely: image rows (loss-corrected), XYZ priors, IOP priors."""
+    N, S, P, Cn = net.n_obs, net.n_sta, net.n_pts, net.n_cam
+    r, J = po.residual_jacobian_all(net)
+    cols = []  # ambient column -> (kind, index); only the free ones
+    free_ap = [[k for k in range(16) if (int(net.ap_free_mask[c]) >> k) & 1] for c in range(Cn)]
+    free_iop = [[k for k in range(3) if (int(net.iop_free_mask[c]) >> k) & 1] for c in range(Cn)]
+    n_cols = 6 * S + 3 * P + sum(len(a) + len(b) for a, b in zip(free_ap, free_iop))
+    A = np.zeros((2 * N + 3 * P + 3 * Cn, n_cols))
+    cam_col, col = {}, 6 * S + 3 * P
+    for c in range(Cn):
+        for k in free_iop[c]:
+            cam_col[(c, k)] = col
+            col += 1
+        for k in free_ap[c]:
+            cam_col[(c, 3 + k)] = col
+            col += 1
+    for n in range(N):
+        i, j = net.obs_sta[n], net.obs_pt[n]
+        c = net.sta_cam[i]
+        rr = r[2 * n:2 * n + 2]
+        s = rr @ rr
+        w = 1.0 if s <= net.huber_a ** 2 else np.sqrt(net.huber_a / np.sqrt(s))  # sqrt(rho'), residuals here are uncorrected
+        for row in range(2):
+            A[2 * n + row, 6 * i:6 * i + 6] = w * J[n, row, 0:6]
+            A[2 * n + row, 6 * S + 3 * j:6 * S + 3 * j + 3] = w * J[n, row, 6:9]
+            for (cc, par), cidx in cam_col.items():
+                if cc == c:
+                    A[2 * n + row, cidx] = w * J[n, row, 9 + par]
+    for j in range(P):
+        for k in range(3):
+            A[2 * N + 3 * j + k, 6 * S + 3 * j + k] = 1.0 / net.pt_sigma[j, k]
+    for c in range(Cn):
+        for k in free_iop[c]:
+            A[2 * N + 3 * P + 3 * c + k, cam_col[(c, k)]] = 1.0 / net.iop_sigma[c, k]
+    d = np.sqrt((A * A).sum(axis=0))
+    Cx = np.linalg.inv((A / d).T @ (A / d)) / np.outer(d, d)
+    v = np.diag(Cx)
+    ve, vx = v[:6 * S].reshape(S, 6), v[6 * S:6 * S + 3 * P].reshape(P, 3)
+    vi, va = np.zeros((Cn, 3)), np.zeros((Cn, 16))
+    for (c, par), cidx in cam_col.items():
+        if par < 3:
+            vi[c, par] = v[cidx]
+        else:
+            va[c, par - 3] = v[cidx]
+    return ve, vx, vi, va
+
+
+def test_oracle_covariance_matches_numpy():
+    net = host.synth(n_cam=2, n_sta=8, n_pts=60, rays_per_point=5, ap_free_mask=host.AP_K1K2P1P2, control_every=4,
+                     outlier_fraction=0.1, seed=3).net
+    got = po.covariance(net)
+    want = numpy_variances(net)
+    for g, w in zip(got, want):
+        assert np.allclose(g, w, rtol=1e-7, atol=0.0)
+    # fixed AP coordinates have zero variance, free ones do not
+    assert np.all(got[3][:, [0, 1, 4]] == 0.0) and np.all(got[3][:, [2, 3, 5, 6]] > 0.0)
