@@ -117,6 +117,9 @@ struct ba_problem {
   double *d_G = nullptr, *d_GT = nullptr, *d_SG = nullptr, *d_defl_part = nullptr, *d_E = nullptr, *d_Lcc_defl = nullptr, *d_part_gr = nullptr;
   double *d_defl_b = nullptr;
   bool have_G = false;
+  // general explicit border (several cameras or many free camera parameters); null -> one probe per camera column
+  double *d_Zc = nullptr, *d_part_cc = nullptr, *d_corner_gen = nullptr;
+  int *d_col_cam = nullptr, *d_col_pos = nullptr;
   // state
   bool have_params = false;
   // multi-GPU
@@ -419,7 +422,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   BA_TRY(p->dalloc(&p->d_diagfull, (size_t)p->nr));
   p->d_d2_sta = p->d_diagfull;
   BA_TRY(p->dalloc(&p->d_F, 39 * (size_t)S));
-  BA_TRY(p->dalloc(&p->d_part, (size_t)std::max(39, border_nacc()) * p->n_chunks));
+  BA_TRY(p->dalloc(&p->d_part, (size_t)std::max(std::max(39, border_nacc()), 6 * p->ncam) * p->n_chunks));
   BA_TRY(p->dalloc(&p->d_Sdiag, 36 * (size_t)S));
   BA_TRY(p->dalloc(&p->d_corner, 64));
   if (p->explicit_ok) {
@@ -436,7 +439,21 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
     BA_TRY(p->dalloc(&p->d_part_rz, npart));
     BA_TRY(p->dalloc(&p->d_cg2scal, 16));
   }
-  if (C == 1 && p->ncmax > 0 && p->ncmax <= border_ncb() && border_ncb() == lin_ncb()) {
+  const bool single_camera_path = C == 1 && p->ncmax > 0 && p->ncmax <= border_ncb() && border_ncb() == lin_ncb();
+  if (p->ncam > 0 && !single_camera_path && (double)P * p->ncam * 24.0 <= 16e9) {
+    std::vector<int> col_cam(p->ncam), col_pos(p->ncam);
+    for (int c = 0; c < C; ++c)
+      for (int k = 0; k < p->cam_h[c].nc; ++k) {
+        col_cam[p->cam_h[c].off + k] = c;
+        col_pos[p->cam_h[c].off + k] = k;
+      }
+    BA_TRY(p->upload(&p->d_col_cam, col_cam));
+    BA_TRY(p->upload(&p->d_col_pos, col_pos));
+    BA_TRY(p->dalloc(&p->d_Zc, (size_t)P * p->ncam * 3));
+    BA_TRY(p->dalloc(&p->d_part_cc, (size_t)p->n_chunks * p->ncmax * p->ncam));
+    BA_TRY(p->dalloc(&p->d_corner_gen, (size_t)p->ncam * p->ncam));
+  }
+  if (single_camera_path) {
     // single camera with few free parameters: the linearisation kernel also produces the camera border's inputs
     BA_TRY(p->dalloc(&p->d_Jt, 2 * (size_t)border_ncb() * N));
     const size_t ncorner = (size_t)border_ncb() * (border_ncb() + 1) / 2;
@@ -653,8 +670,21 @@ int build_reduced(ba_problem *p, bool explicit_blocks) {
     BA_TRY(p->allreduce(p->d_Ssc, (int64_t)ns * p->ncam, 0));
     BA_TRY(p->allreduce(p->d_corner, border_ncb() * (border_ncb() + 1) / 2, 0));
     launch_border_corner(s, p->ncam, p->d_corner, p->d_diagfull + ns, p->d_Scc);
+  } else if (p->d_Zc) {
+    // several cameras / many free parameters: one point sweep for Z = V^-1 B^T, one station sweep for the sums
+    GenBorderArgs ga{};
+    ga.P = p->P; ga.S = p->S; ga.ncam = p->ncam; ga.ncmax = p->ncmax; ga.n_chunks = p->n_chunks;
+    ga.pt_start = p->d_pt_start; ga.obs_sta = p->d_obs_sta; ga.obs_pt = p->d_obs_pt; ga.sta_cam = p->d_sta_cam;
+    ga.col_cam = p->d_col_cam; ga.col_pos = p->d_col_pos; ga.chunk_sta = p->d_chunk_sta; ga.chunk_begin = p->d_chunk_begin;
+    ga.sta_list = p->d_sta_list; ga.sta_chunk0 = p->d_sta_chunk0; ga.rec = p->d_rec; ga.Jp = p->d_Jp; ga.Jc = p->d_Jc;
+    ga.Vinv = p->d_Vinv; ga.cam = p->d_cam; ga.Zc = p->d_Zc; ga.out_sc = p->d_part; ga.out_cc = p->d_part_cc;
+    ga.Ssc = p->d_Ssc; ga.corner = p->d_corner_gen;
+    launch_border_general(s, ga);
+    BA_TRY(p->allreduce(p->d_Ssc, (int64_t)ns * p->ncam, 0));
+    BA_TRY(p->allreduce(p->d_corner_gen, (int64_t)p->ncam * p->ncam, 0));
+    launch_border_general_corner(s, p->ncam, p->d_corner_gen, p->d_diagfull + ns, p->d_Scc);
   } else {
-    // general case: one pass of the implicit operator per camera column
+    // fallback: one pass of the implicit operator per camera column
     for (int k = 0; k < p->ncam; ++k) {
       BA_TRY(probe_column(p, (int64_t)ns + k, p->d_q));
       launch_store_border_col(s, p->S, p->ncam, k, p->d_q, p->d_Ssc, p->d_Scc);

@@ -151,6 +151,18 @@ void launch_border_station(hipStream_t s, const StationArgs &sa, const double *J
 void launch_border_fold(hipStream_t s, int S, int ncam, int n_chunks, const int *sta_chunk0, const double *part, int stride,
                         double *Ssc);
 void launch_border_corner(hipStream_t s, int ncam, const double *corner, const double *camdiag, double *Scc);
+// general explicit border: any number of cameras and free camera parameters
+struct GenBorderArgs {
+  int P, S, ncam, ncmax, n_chunks;
+  const int *pt_start, *obs_sta, *obs_pt, *sta_cam, *col_cam, *col_pos, *chunk_sta, *chunk_begin, *sta_list, *sta_chunk0;
+  const double *rec, *Jp, *Jc, *Vinv;
+  const CamRec *cam;
+  double *Zc;              // [P x ncam x 3]
+  double *out_sc, *out_cc; // per chunk: [6 x ncam], [ncmax x ncam]
+  double *Ssc, *corner;    // [6S x ncam], raw corner [ncam x ncam] (before the sum over ranks)
+};
+void launch_border_general(hipStream_t s, const GenBorderArgs &a);
+void launch_border_general_corner(hipStream_t s, int ncam, const double *corner, const double *camdiag, double *Scc);
 int cg2_blocks_spmv(int S);
 int cg2_blocks_vec(int S);
 void launch_cg2_init(hipStream_t s, const BsrCgArgs &a, double rtol);

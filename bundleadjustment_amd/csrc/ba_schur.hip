@@ -197,6 +197,129 @@ __global__ void k_border_corner(int ncam, const double *__restrict__ corner, con
 }
 
 // ------------------------------------------------------------------------------------------
+// explicit border, general case (several cameras, or more than NCB free parameters)
+// ------------------------------------------------------------------------------------------
+// Z_j = V_j^-1 B_j^T with B_j = sum_{e in j} Jc_e^T Jp_e over all ncam camera columns (an observation
+// only touches the columns of its own camera).  One wave per point, one lane per column.
+__global__ void __launch_bounds__(256)
+k_border_Z(GenBorderArgs a) {
+  const int jj = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (jj >= a.P) return;
+  const int e0 = a.pt_start[jj], e1 = a.pt_start[jj + 1];
+  const double *vi = a.Vinv + 6 * (int64_t)jj;
+  const double Vi[6] = {vi[0], vi[1], vi[2], vi[3], vi[4], vi[5]};
+  for (int k = lane; k < a.ncam; k += 64) {
+    const int ck = a.col_cam[k], pos = a.col_pos[k];
+    double b0 = 0.0, b1 = 0.0, b2 = 0.0;
+    for (int e = e0; e < e1; ++e) {
+      if (a.sta_cam[a.obs_sta[e]] != ck) continue;
+      const double *jc = a.Jc + 2 * (int64_t)a.ncmax * e, *jp = a.Jp + 6 * (int64_t)e;
+      const double c0 = jc[pos], c1 = jc[a.ncmax + pos];
+      b0 += c0 * jp[0] + c1 * jp[3];
+      b1 += c0 * jp[1] + c1 * jp[4];
+      b2 += c0 * jp[2] + c1 * jp[5];
+    }
+    double *z = a.Zc + ((int64_t)jj * a.ncam + k) * 3;
+    sym3_mul(Vi, b0, b1, b2, z[0], z[1], z[2]);
+  }
+}
+
+// Station sweep: per chunk, column k of  sum Js^T Jt  (6 values) and of  sum Jc^T Jt  (the nc rows of the
+// station's camera), Jt_e[:,k] = Jc_e[:,k] (own camera's columns only) - Jp_e Z_j[:,k].
+// Thread t: column (t mod ncw) of the current tile of columns, observations t / ncw, t / ncw + nsub, ...
+__global__ void __launch_bounds__(256)
+k_border_general(GenBorderArgs a) {
+  __shared__ double lds[256 * 7];
+  const int ch = blockIdx.x, sta = a.chunk_sta[ch];
+  const int b0 = a.chunk_begin[ch], b1 = a.chunk_begin[ch + 1];
+  const int c = a.sta_cam[sta], nc = a.cam[c].nc, off = a.cam[c].off;
+  for (int k0 = 0; k0 < a.ncam; k0 += 256) {
+    const int ncw = min(256, a.ncam - k0), nsub = 256 / ncw;
+    const int kk = threadIdx.x % ncw, sub = threadIdx.x / ncw, k = k0 + kk;
+    const bool on = sub < nsub;
+    const bool own = k >= off && k < off + nc;
+    double as[6] = {0, 0, 0, 0, 0, 0}, ac[BA_NCAMPAR];
+#pragma unroll
+    for (int r = 0; r < BA_NCAMPAR; ++r) ac[r] = 0.0;
+    if (on)
+      for (int q = b0 + sub; q < b1; q += nsub) {
+        const int e = a.sta_list[q], jj = a.obs_pt[e];
+        const double *rec = a.rec + (int64_t)BA_REC_STRIDE * e, *jp = a.Jp + 6 * (int64_t)e;
+        const double *jc = a.Jc + 2 * (int64_t)a.ncmax * e, *z = a.Zc + ((int64_t)jj * a.ncam + k) * 3;
+        double t0 = -(jp[0] * z[0] + jp[1] * z[1] + jp[2] * z[2]), t1 = -(jp[3] * z[0] + jp[4] * z[1] + jp[5] * z[2]);
+        if (own) {
+          t0 += jc[k - off];
+          t1 += jc[a.ncmax + k - off];
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) as[r] += rec[r] * t0 + rec[6 + r] * t1;
+#pragma unroll
+        for (int r = 0; r < BA_NCAMPAR; ++r)
+          if (r < nc) ac[r] += jc[r] * t0 + jc[a.ncmax + r] * t1;
+      }
+    // fold the nsub partial sums of each column through LDS, 7 values at a time
+    for (int pass = 0; pass < 4; ++pass) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 7; ++r) {
+        const int idx = 7 * pass + r;  // 0..5 station rows, 6..24 camera rows
+        double v = 0.0;
+        if (idx < 6) v = as[idx];
+        else if (idx - 6 < BA_NCAMPAR) v = ac[idx - 6];
+        lds[threadIdx.x * 7 + r] = on ? v : 0.0;
+      }
+      __syncthreads();
+      if (sub == 0) {
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+          const int idx = 7 * pass + r;
+          double t = 0.0;
+          for (int m = 0; m < nsub; ++m) t += lds[(m * ncw + kk) * 7 + r];
+          if (idx < 6) a.out_sc[((int64_t)ch * 6 + idx) * a.ncam + k] = t;
+          else if (idx - 6 < a.ncmax) a.out_cc[((int64_t)ch * a.ncmax + (idx - 6)) * a.ncam + k] = (idx - 6 < nc) ? t : 0.0;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Ssc[i][r][k] = sum over the chunks of station i (fixed order)
+__global__ void k_border_general_fold_sc(int S, int ncam, const int *__restrict__ sta_chunk0, const double *__restrict__ part,
+                                         double *__restrict__ Ssc) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= 6 * (int64_t)S * ncam) return;
+  const int i = (int)(t / (6 * ncam));
+  const int64_t rem = t - (int64_t)i * 6 * ncam;
+  double s = 0.0;
+  for (int ch = sta_chunk0[i]; ch < sta_chunk0[i + 1]; ++ch) s += part[(int64_t)ch * 6 * ncam + rem];
+  Ssc[t] = s;
+}
+
+// raw corner row (off_c + r), column k = sum over the chunks whose station carries camera c; one workgroup per row
+__global__ void __launch_bounds__(256)
+k_border_general_fold_cc(int n_chunks, int ncam, int ncmax, const int *__restrict__ chunk_sta, const int *__restrict__ sta_cam,
+                         const int *__restrict__ col_cam, const int *__restrict__ col_pos, const double *__restrict__ part,
+                         double *__restrict__ corner) {
+  const int row = blockIdx.x, c = col_cam[row], r = col_pos[row];
+  for (int k = threadIdx.x; k < ncam; k += blockDim.x) {
+    double s = 0.0;
+    for (int ch = 0; ch < n_chunks; ++ch)
+      if (sta_cam[chunk_sta[ch]] == c) s += part[((int64_t)ch * ncmax + r) * ncam + k];
+    corner[(int64_t)row * ncam + k] = s;
+  }
+}
+
+// Scc = symmetrised raw corner + prior and LM diagonal
+__global__ void k_border_general_corner(int ncam, const double *__restrict__ corner, const double *__restrict__ camdiag,
+                                        double *__restrict__ Scc) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ncam * ncam) return;
+  const int r = t / ncam, k = t % ncam;
+  Scc[t] = 0.5 * (corner[(int64_t)r * ncam + k] + corner[(int64_t)k * ncam + r]) + (r == k ? camdiag[r] : 0.0);
+}
+
+// ------------------------------------------------------------------------------------------
 // PCG on the explicit system
 // ------------------------------------------------------------------------------------------
 // scal: [0],[1] r.z (double-buffered by iteration parity), [2] initial r.z, [3] iterations done,
@@ -655,6 +778,17 @@ void launch_border_fold(hipStream_t s, int S, int ncam, int n_chunks, const int 
   (void)n_chunks;
   const int nb = nblk(6 * (int64_t)S * ncam, 256);
   if (nb > 0) hipLaunchKernelGGL(k_border_fold, dim3(nb), dim3(256), 0, s, S, ncam, sta_chunk0, part, stride, Ssc);
+}
+void launch_border_general(hipStream_t s, const GenBorderArgs &a) {
+  if (a.P > 0) hipLaunchKernelGGL(k_border_Z, dim3(nblk(a.P, 4)), dim3(256), 0, s, a);
+  if (a.n_chunks > 0) hipLaunchKernelGGL(k_border_general, dim3(a.n_chunks), dim3(256), 0, s, a);
+  const int nb = nblk(6 * (int64_t)a.S * a.ncam, 256);
+  if (nb > 0) hipLaunchKernelGGL(k_border_general_fold_sc, dim3(nb), dim3(256), 0, s, a.S, a.ncam, a.sta_chunk0, a.out_sc, a.Ssc);
+  hipLaunchKernelGGL(k_border_general_fold_cc, dim3(a.ncam), dim3(256), 0, s, a.n_chunks, a.ncam, a.ncmax, a.chunk_sta, a.sta_cam,
+                     a.col_cam, a.col_pos, a.out_cc, a.corner);
+}
+void launch_border_general_corner(hipStream_t s, int ncam, const double *corner, const double *camdiag, double *Scc) {
+  hipLaunchKernelGGL(k_border_general_corner, dim3(nblk((int64_t)ncam * ncam, 256)), dim3(256), 0, s, ncam, corner, camdiag, Scc);
 }
 void launch_border_corner(hipStream_t s, int ncam, const double *corner, const double *camdiag, double *Scc) {
   hipLaunchKernelGGL(k_border_corner, dim3(1), dim3(1), 0, s, ncam, corner, camdiag, Scc);
