@@ -97,7 +97,7 @@ struct ba_problem {
   double *d_scal = nullptr, *h_scal = nullptr;
   // device: reduced system
   double *d_g = nullptr, *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_p = nullptr, *d_q = nullptr;
-  double *d_Minv = nullptr, *d_Ssc = nullptr, *d_Scc = nullptr, *d_Lcc = nullptr, *d_cgscal = nullptr, *h_cgscal = nullptr;
+  double *d_Minv = nullptr, *d_Ssc = nullptr, *d_Scc = nullptr, *d_Lcc = nullptr, *d_Sccinv = nullptr, *d_cgscal = nullptr, *h_cgscal = nullptr;
   double *d_Sdense = nullptr;
   // explicit block-sparse reduced system (null / 0 when the network is too dense for it)
   bool explicit_ok = false;
@@ -473,6 +473,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   BA_TRY(p->dalloc(&p->d_Ssc, 6 * (size_t)S * p->ncam));
   BA_TRY(p->dalloc(&p->d_Scc, (size_t)p->ncam * p->ncam));
   BA_TRY(p->dalloc(&p->d_Lcc, (size_t)p->ncam * p->ncam));
+  BA_TRY(p->dalloc(&p->d_Sccinv, (size_t)p->ncam * p->ncam));
   HIP_OK(hipMemsetAsync(p->d_flags, 0, 4 * sizeof(unsigned), p->stream));
   HIP_OK(hipMemsetAsync(p->d_scal, 0, SC_COUNT * sizeof(double), p->stream));
   HIP_OK(hipStreamSynchronize(p->stream));
@@ -692,6 +693,7 @@ int build_reduced(ba_problem *p, bool explicit_blocks) {
   }
   launch_copy(s, (int64_t)p->ncam * p->ncam, p->d_Scc, p->d_Lcc);
   launch_cholesky(s, p->d_Lcc, p->ncam, p->d_info);
+  launch_chol_inverse(s, p->d_Lcc, p->ncam, p->d_Sccinv);  // the block-sparse PCG applies the camera block as a product
   int info = 0;
   HIP_OK(hipMemcpyAsync(&info, p->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
@@ -705,7 +707,7 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
   hipStream_t s = p->stream;
   BsrCgArgs a{};
   a.S = p->S; a.ncam = p->ncam; a.rowptr = p->d_bsr_rowptr; a.col = p->d_bsr_col; a.val = p->d_bsr_val; a.Ssc = p->d_Ssc;
-  a.Scc = p->d_Scc; a.Lcc = p->d_Lcc; a.Minv = p->d_Minv; a.b = p->d_b; a.x = p->d_x; a.r = p->d_r; a.z = p->d_z; a.p = p->d_p;
+  a.Scc = p->d_Scc; a.Lcc = p->d_Sccinv; a.Minv = p->d_Minv; a.b = p->d_b; a.x = p->d_x; a.r = p->d_r; a.z = p->d_z; a.p = p->d_p;
   a.q = p->d_q; a.scal = p->d_cg2scal; a.part_pq = p->d_part_pq; a.part_qc = p->d_part_qc; a.part_rz = p->d_part_rz;
   // multilevel preconditioner: structure once (it needs the values of a first linearisation),
   // numbers after every change of the matrix
@@ -1390,7 +1392,7 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
   la.cam_partial = p->d_campart;
   BsrCgArgs ba{};
   ba.S = p->S; ba.ncam = p->ncam; ba.rowptr = p->d_bsr_rowptr; ba.col = p->d_bsr_col; ba.val = p->d_bsr_val; ba.Ssc = p->d_Ssc;
-  ba.Scc = p->d_Scc; ba.Lcc = p->d_Lcc; ba.Minv = p->d_Minv; ba.b = p->d_b; ba.x = p->d_x; ba.r = p->d_r; ba.z = p->d_z; ba.p = p->d_p;
+  ba.Scc = p->d_Scc; ba.Lcc = p->d_Sccinv; ba.Minv = p->d_Minv; ba.b = p->d_b; ba.x = p->d_x; ba.r = p->d_r; ba.z = p->d_z; ba.p = p->d_p;
   ba.q = p->d_q; ba.scal = p->d_cg2scal; ba.part_pq = p->d_part_pq; ba.part_qc = p->d_part_qc; ba.part_rz = p->d_part_rz;
   if ((which == 4 || which == 5 || which == 6) && !p->explicit_ok) return fail(BA_ERR_INVALID, "ba_time_kernel: the block-sparse system was not built for this network");
   // the PCG iteration is timed with the preconditioner the last solve used (multilevel once it has been built)

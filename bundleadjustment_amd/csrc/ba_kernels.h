@@ -133,7 +133,7 @@ void launch_resjac_dense(hipStream_t s, const CostArgs &a, double *r_out, double
 struct BsrCgArgs {
   int S, ncam;
   const int *rowptr, *col;
-  const double *val, *Ssc, *Scc, *Lcc, *Minv, *b;
+  const double *val, *Ssc, *Scc, *Lcc, *Minv, *b;  // Lcc: explicit INVERSE of the camera block of the preconditioner
   double *x, *r, *z, *p, *q, *scal, *part_pq, *part_qc, *part_rz;
   // camera coarse space of the multilevel preconditioner (null when not used): G [6S x ncam], an
   // approximation of S_ss^-1 S_sc; Lcc is then the INVERSE of Q^T S Q, Q = [-G; I]

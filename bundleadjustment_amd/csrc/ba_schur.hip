@@ -389,21 +389,6 @@ k_bsr_spmv(BsrCgArgs a, int parity) {
   }
 }
 
-#define CAM_STAGE 16  // camera blocks up to this order are staged in LDS by the vector kernel
-// camera part of z = M^-1 r with the dense Cholesky factor of the corner (one thread)
-__device__ void cam_precond(int n, const double *__restrict__ L, const double *__restrict__ rc, double *__restrict__ zc) {
-  for (int i = 0; i < n; ++i) {
-    double s = rc[i];
-    for (int k = 0; k < i; ++k) s -= L[i * n + k] * zc[k];
-    zc[i] = s / L[i * n + i];
-  }
-  for (int i = n - 1; i >= 0; --i) {
-    double s = zc[i];
-    for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * zc[k];
-    zc[i] = s / L[i * n + i];
-  }
-}
-
 // thread per station: z_i = Minv_i r_i; returns r_i . z_i
 __device__ __forceinline__ double station_precond(const double *__restrict__ Minv, const double *__restrict__ r,
                                                   double *__restrict__ z, int i) {
@@ -468,19 +453,22 @@ k_cg2_init(BsrCgArgs a) {
     for (int k = 0; k < 6; ++k) a.p[6 * (int64_t)i + k] = a.z[6 * (int64_t)i + k];
   }
   if (a.G) defl_partials(a, i);
-  if (blockIdx.x == 0 && threadIdx.x == 0 && a.ncam > 0) {
+  if (blockIdx.x == 0 && a.ncam > 0) {
+    // camera entries: x = 0, r = b and (without the coarse space) z = Scc^-1 r with the explicit inverse,
+    // one thread per row.  With the coarse space the camera part of z needs G^T r_s: the last kernel does it.
     const int64_t o = 6 * (int64_t)a.S;
-    for (int k = 0; k < a.ncam; ++k) {
+    for (int k = threadIdx.x; k < a.ncam; k += blockDim.x) {
       a.x[o + k] = 0.0;
       a.r[o + k] = a.b[o + k];
     }
-    if (!a.G) {  // with the coarse space the camera part of z needs G^T r_s: the last kernel does it
-      cam_precond(a.ncam, a.Lcc, a.r + o, a.z + o);
-      for (int k = 0; k < a.ncam; ++k) {
-        a.p[o + k] = a.z[o + k];
-        dot += a.r[o + k] * a.z[o + k];
+    if (!a.G)
+      for (int k = threadIdx.x; k < a.ncam; k += blockDim.x) {
+        double z = 0.0;
+        for (int m = 0; m < a.ncam; ++m) z += a.Lcc[k * a.ncam + m] * a.b[o + m];
+        a.z[o + k] = z;
+        a.p[o + k] = z;
+        dot += a.b[o + k] * z;
       }
-    }
   }
   const double t = block_sum(dot, lds);
   if (threadIdx.x == 0) a.part_rz[blockIdx.x] = t;
@@ -513,7 +501,7 @@ k_cg2_update1(BsrCgArgs a, int parity, int nblk_spmv) {
   __shared__ double pcs[80];   // camera part of p
   __shared__ double pq_s;
   __shared__ double fold4[4][8];
-  __shared__ double Ls[CAM_STAGE * CAM_STAGE], rcs[CAM_STAGE], zcs[CAM_STAGE];
+  __shared__ double rcs[80];
   if (a.scal[8 + parity] != 0.0) return;
   // Every workgroup folds the SpMV partials in the same order -> identical alpha everywhere.
   // Eight sums at a time: thread t takes sum (t & 7) and every 32nd partial from (t >> 3) on, so all
@@ -577,42 +565,23 @@ k_cg2_update1(BsrCgArgs a, int parity, int nblk_spmv) {
   }
   if (a.G) defl_partials(a, i);
   if (blockIdx.x == gridDim.x - 1) {
-    // the last workgroup is the least loaded one: it also carries the camera entries.  A small
-    // camera block is staged in LDS first: the substitution is one thread's chain of dependent loads.
-    const bool staged = a.ncam > 0 && a.ncam <= CAM_STAGE;
-    if (a.G) {
-      // camera coarse space: only x and r here, the camera part of z follows in the last kernel
-      if (threadIdx.x < a.ncam) {
-        a.x[o + threadIdx.x] += alpha * pcs[threadIdx.x];
-        a.r[o + threadIdx.x] -= alpha * red[1 + threadIdx.x];
-      }
-      if (threadIdx.x == 0) a.scal[4] = pq;
-    } else if (staged) {
-      for (int k = threadIdx.x; k < a.ncam * a.ncam; k += blockDim.x) Ls[k] = a.Lcc[k];
-      if (threadIdx.x < a.ncam) {
-        a.x[o + threadIdx.x] += alpha * pcs[threadIdx.x];
-        rcs[threadIdx.x] = a.r[o + threadIdx.x] - alpha * red[1 + threadIdx.x];
-      }
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        cam_precond(a.ncam, Ls, rcs, zcs);
-        for (int k = 0; k < a.ncam; ++k) dot += rcs[k] * zcs[k];
-        a.scal[4] = pq;
-      }
-      __syncthreads();
-      if (threadIdx.x < a.ncam) {
-        a.r[o + threadIdx.x] = rcs[threadIdx.x];
-        a.z[o + threadIdx.x] = zcs[threadIdx.x];
-      }
-    } else if (threadIdx.x == 0) {
-      for (int k = 0; k < a.ncam; ++k) {
-        a.x[o + k] += alpha * pcs[k];
-        a.r[o + k] -= alpha * red[1 + k];
-      }
-      if (a.ncam > 0) cam_precond(a.ncam, a.Lcc, a.r + o, a.z + o);
-      for (int k = 0; k < a.ncam; ++k) dot += a.r[o + k] * a.z[o + k];
-      a.scal[4] = pq;
+    // the last workgroup is the least loaded one: it also carries the camera entries (ncam <= 80).
+    // z_c = Scc^-1 r_c with the explicit inverse, one thread per row; with the camera coarse space only
+    // x and r here, the camera part of z follows in the last kernel.
+    if (threadIdx.x < a.ncam) {
+      a.x[o + threadIdx.x] += alpha * pcs[threadIdx.x];
+      const double rk = a.r[o + threadIdx.x] - alpha * red[1 + threadIdx.x];
+      a.r[o + threadIdx.x] = rk;
+      rcs[threadIdx.x] = rk;
     }
+    __syncthreads();
+    if (!a.G && threadIdx.x < a.ncam) {
+      double z = 0.0;
+      for (int m = 0; m < a.ncam; ++m) z += a.Lcc[threadIdx.x * a.ncam + m] * rcs[m];
+      a.z[o + threadIdx.x] = z;
+      dot += rcs[threadIdx.x] * z;
+    }
+    if (threadIdx.x == 0) a.scal[4] = pq;
   }
   const double t = block_sum(dot, lds);
   if (threadIdx.x == 0) a.part_rz[blockIdx.x] = t;
