@@ -328,7 +328,7 @@ __global__ void k_border_general_corner(int ncam, const double *__restrict__ cor
 //       so no workgroup ever sees a scalar change under it.
 // q = S p for station rows (one wave per row) with per-workgroup partials of p.q and of the
 // camera rows Ssc^T p.
-#define SPMV_WAVES 16
+#define SPMV_WAVES 8
 __global__ void __launch_bounds__(64 * SPMV_WAVES)
 k_bsr_spmv(BsrCgArgs a, int parity) {
   __shared__ double lds_pq[SPMV_WAVES];
@@ -341,13 +341,32 @@ k_bsr_spmv(BsrCgArgs a, int parity) {
   const double *pcam = a.p + 6 * (int64_t)a.S;
   for (int i = blockIdx.x * SPMV_WAVES + w; i < a.S; i += gridDim.x * SPMV_WAVES) {
     double s = 0.0;
-    if (r < 6) {
-      for (int b = a.rowptr[i] + g; b < a.rowptr[i + 1]; b += 8) {
-        const double2 *B = reinterpret_cast<const double2 *>(a.val + 36 * (int64_t)b + 6 * r);
-        const double2 *pc = reinterpret_cast<const double2 *>(a.p + 6 * (int64_t)a.col[b]);
-        const double2 b0 = B[0], b1 = B[1], b2 = B[2], p0 = pc[0], p1 = pc[1], p2 = pc[2];
-        s += b0.x * p0.x + b0.y * p0.y + b1.x * p1.x + b1.y * p1.y + b2.x * p2.x + b2.y * p2.y;
+    // 16 blocks per pass (2 per group of 8 lanes).  Their column indices come from one coalesced load
+    // and are handed round by shuffles, so that every value and vector load of the pass is issued
+    // before the first one is waited for: the row costs three memory latencies, not one per block.
+    const int rb = a.rowptr[i], re = a.rowptr[i + 1];
+    const int rr = r < 6 ? r : 0;
+    for (int base = rb; base < re; base += 16) {
+      const int nb = min(16, re - base);
+      const int mycol = lane < nb ? a.col[base + lane] : 0;
+      double2 bv[2][3], pv[2][3];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int bi = g + 8 * u;
+        const int cb = __shfl(mycol, bi, 64);
+        const bool on = bi < nb && r < 6;
+        const double2 *B = reinterpret_cast<const double2 *>(a.val + 36 * (int64_t)(base + (on ? bi : 0)) + 6 * rr);
+        const double2 *pc = reinterpret_cast<const double2 *>(a.p + 6 * (int64_t)cb);
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+          bv[u][h] = on ? B[h] : make_double2(0.0, 0.0);
+          pv[u][h] = on ? pc[h] : make_double2(0.0, 0.0);
+        }
       }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int h = 0; h < 3; ++h) s += bv[u][h].x * pv[u][h].x + bv[u][h].y * pv[u][h].y;
     }
     s += __shfl_xor(s, 8, 64);
     s += __shfl_xor(s, 16, 64);
@@ -515,15 +534,18 @@ k_cg2_update1(BsrCgArgs a, int parity, int nblk_spmv) {
     if (qn < 1 + a.ncam) {
       const double *src = (qn == 0) ? a.part_pq : a.part_qc + (qn - 1);
       const int64_t st = (qn == 0) ? 1 : a.ncam;
-      // at most 512 partials (cg2_blocks_spmv): 16 independent loads per thread, summed in a fixed tree
-      double v[16];
+      // at most 1024 partials (cg2_blocks_spmv): 32 independent loads per thread, summed in a fixed tree
+      double v[32];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < 32; ++j) {
         const int m = (threadIdx.x >> 3) + 32 * j;
         v[j] = (m < nblk_spmv) ? src[st * m] : 0.0;
       }
-      s = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
-          (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+#pragma unroll
+      for (int w2 = 16; w2 >= 1; w2 >>= 1)
+#pragma unroll
+        for (int j = 0; j < w2; ++j) v[j] += v[j + w2];
+      s = v[0];
     }
     s += __shfl_xor(s, 8, 64);
     s += __shfl_xor(s, 16, 64);
@@ -763,7 +785,7 @@ void launch_border_corner(hipStream_t s, int ncam, const double *corner, const d
   hipLaunchKernelGGL(k_border_corner, dim3(1), dim3(1), 0, s, ncam, corner, camdiag, Scc);
 }
 int cg2_blocks_spmv(int S) {
-  // two 16-wave workgroups fit a compute unit: no more than one resident round of them
+  // one resident round of workgroups; also bounds the partials the vector kernel folds (32 loads per thread)
   const int nb = nblk(S, SPMV_WAVES);
   return nb > 512 ? 512 : nb;
 }
