@@ -17,14 +17,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _make_net():
+def _make_net(n_cam=1):
     from bundleadjustment_amd import host
     # few points per station pair, so that the two shards see different sets of station pairs
-    return host.synth(n_cam=1, n_sta=120, n_pts=500, rays_per_point=4, seed=77, ap_free_mask=host.AP_K1K2P1P2,
+    return host.synth(n_cam=n_cam, n_sta=120, n_pts=500, rays_per_point=4, seed=77, ap_free_mask=host.AP_K1K2P1P2,
                       control_every=8).net
 
 
-def _worker(rank, world, port, ls, out):
+def _worker(rank, world, port, ls, n_cam, out):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -32,7 +32,7 @@ def _worker(rank, world, port, ls, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from bundleadjustment_amd import sharding, solver
-    net = _make_net()
+    net = _make_net(n_cam)
     shard, sl = sharding.shard_network(net, rank, world)
 
     def reduce_fn(buf, op):
@@ -54,22 +54,23 @@ def _worker(rank, world, port, ls, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("ls", [0, 1, 2])
-def test_two_ranks_match_oracle(ls):
+# one camera: the fused single-camera border and the camera coarse space; three cameras: the general border
+@pytest.mark.parametrize("ls,n_cam", [(0, 1), (1, 1), (2, 1), (0, 3), (1, 3)])
+def test_two_ranks_match_oracle(ls, n_cam):
     from oracle import py_oracle as po
     from bundleadjustment_amd import capi
     from util import assert_solve_parity
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ls, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ls, n_cam, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = q.get(timeout=240)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    net = _make_net()
+    net = _make_net(n_cam)
     opt = capi.default_options(linear_solver=ls)
     o = po.solve(net, opt, po.SCHUR_DENSE)
     # the summary sizes of a shard count its own points only: compare costs, steps and parameters
