@@ -341,36 +341,32 @@ k_bsr_spmv(BsrCgArgs a, int parity) {
   const double *pcam = a.p + 6 * (int64_t)a.S;
   for (int i = blockIdx.x * SPMV_WAVES + w; i < a.S; i += gridDim.x * SPMV_WAVES) {
     double s = 0.0;
-    // 16 blocks per pass (2 per group of 8 lanes).  Their column indices come from one coalesced load
-    // and are handed round by shuffles, so that every value and vector load of the pass is issued
-    // before the first one is waited for: the row costs three memory latencies, not one per block.
+    // The row's blocks are contiguous in memory (288 B each).  Lanes 0..53 read them as one stream,
+    // 16 B per lane: lane l holds piece l % 18 of block l / 18 of each triple, i.e. always the same
+    // block row (l % 18) / 3 and column pair 2 * (l % 3).  Four triples (12 blocks) per pass; their
+    // column indices come from one coalesced load and shuffles, so all loads of a pass are independent.
     const int rb = a.rowptr[i], re = a.rowptr[i + 1];
-    const int rr = r < 6 ? r : 0;
-    for (int base = rb; base < re; base += 16) {
-      const int nb = min(16, re - base);
+    const int tri = lane / 18, piece = lane - 18 * tri;  // tri == 3 for the idle lanes 54..63
+    const int cpair = 2 * (piece % 3);
+    for (int base = rb; base < re; base += 12) {
+      const int nb = min(12, re - base);
       const int mycol = lane < nb ? a.col[base + lane] : 0;
-      double2 bv[2][3], pv[2][3];
+      double2 bv[4], pv[4];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int bi = g + 8 * u;
-        const int cb = __shfl(mycol, bi, 64);
-        const bool on = bi < nb && r < 6;
-        const double2 *B = reinterpret_cast<const double2 *>(a.val + 36 * (int64_t)(base + (on ? bi : 0)) + 6 * rr);
-        const double2 *pc = reinterpret_cast<const double2 *>(a.p + 6 * (int64_t)cb);
-#pragma unroll
-        for (int h = 0; h < 3; ++h) {
-          bv[u][h] = on ? B[h] : make_double2(0.0, 0.0);
-          pv[u][h] = on ? pc[h] : make_double2(0.0, 0.0);
-        }
+      for (int u = 0; u < 4; ++u) {
+        const int bi = 3 * u + tri;
+        const int cb = __shfl(mycol, bi < 12 ? bi : 0, 64);
+        const bool on = tri < 3 && bi < nb;
+        bv[u] = on ? *reinterpret_cast<const double2 *>(a.val + 36 * (int64_t)(base + bi) + 2 * piece) : make_double2(0.0, 0.0);
+        pv[u] = on ? *reinterpret_cast<const double2 *>(a.p + 6 * (int64_t)cb + cpair) : make_double2(0.0, 0.0);
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int h = 0; h < 3; ++h) s += bv[u][h].x * pv[u][h].x + bv[u][h].y * pv[u][h].y;
+      for (int u = 0; u < 4; ++u) s += bv[u].x * pv[u].x + bv[u].y * pv[u].y;
     }
-    s += __shfl_xor(s, 8, 64);
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
+    // block row r: pieces 3r..3r+2 of the three triples -> lanes 3r + {0,1,2} + {0,18,36}
+    s += __shfl_down(s, 1, 64) + __shfl_down(s, 2, 64);   // valid where piece % 3 == 0
+    s += __shfl_down(s, 18, 64) + __shfl_down(s, 36, 64);  // valid for lanes 0,3,..,15
+    s = __shfl(s, 3 * (lane < 6 ? lane : 0), 64);          // lanes 0..5: rows 0..5
     if (lane < 6) {
       const double *row = a.Ssc + (6 * (int64_t)i + lane) * a.ncam;
       for (int k = 0; k < a.ncam; ++k) s += row[k] * pcam[k];
