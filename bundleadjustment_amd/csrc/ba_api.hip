@@ -1425,10 +1425,12 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
         else launch_cg2_iteration(s, ba, 0);
         break;
       case 6: launch_bsr_spmv(s, ba, 0); break;
+      case 7: launch_linearize(s, la, 1); break;
+      case 8: launch_linearize(s, la, 2); break;
       default: break;
     }
   };
-  if (which < 0 || which > 6) return fail(BA_ERR_INVALID, "ba_time_kernel: unknown kernel %d", which);
+  if (which < 0 || which > 8) return fail(BA_ERR_INVALID, "ba_time_kernel: unknown kernel %d", which);
   run();  // warm-up
   HIP_OK(hipEventRecord(e0, s));
   for (int k = 0; k < repeats; ++k) run();

@@ -94,7 +94,7 @@ struct CgArgs {
 
 void launch_station_prep(hipStream_t s, int S, const double *eop, const double *scale_sta, const int *sta_cam, double *sta);
 int linearize_blocks(int P);
-void launch_linearize(hipStream_t s, const LinArgs &a);
+void launch_linearize(hipStream_t s, const LinArgs &a, int part = 3);
 int lin_ncb();
 int elim_stride();
 int obs_rows_blocks(int64_t N);

@@ -1227,15 +1227,16 @@ int obs_rows_blocks(int64_t N) {
   const int b = nblk((N + 63) / 64, 4);
   return b < 1 ? 1 : (b > 4096 ? 4096 : b);
 }
-void launch_linearize(hipStream_t s, const LinArgs &a) {
+// part: 1 = per-point kernel, 2 = per-observation kernel, 3 = both (a linearisation)
+void launch_linearize(hipStream_t s, const LinArgs &a, int part) {
   if (a.P <= 0) return;
   const dim3 gp(nblk(a.P, 256)), go(obs_rows_blocks(a.N)), b(256);
   if (a.Jt) {
-    hipLaunchKernelGGL(k_point_elim<true>, gp, b, 0, s, a);
-    hipLaunchKernelGGL(k_obs_rows<true>, go, b, 0, s, a);
+    if (part & 1) hipLaunchKernelGGL(k_point_elim<true>, gp, b, 0, s, a);
+    if (part & 2) hipLaunchKernelGGL(k_obs_rows<true>, go, b, 0, s, a);
   } else {
-    hipLaunchKernelGGL(k_point_elim<false>, gp, b, 0, s, a);
-    hipLaunchKernelGGL(k_obs_rows<false>, go, b, 0, s, a);
+    if (part & 1) hipLaunchKernelGGL(k_point_elim<false>, gp, b, 0, s, a);
+    if (part & 2) hipLaunchKernelGGL(k_obs_rows<false>, go, b, 0, s, a);
   }
 }
 int elim_stride() { return ELIM_STRIDE; }

@@ -240,13 +240,15 @@ int ba_residual_jacobian(ba_problem *p, double *r, double *J);
  * Times `repeats` launches of one kernel at the resident parameters with HIP events on the
  * solver's stream and returns the mean seconds per launch.  Used for the Jacobian obs/s figure
  * and the roofline line of the benchmark.  which:
- *   0  fused residual + Jacobian + point elimination (one lane per point)
+ *   0  residual + Jacobian + point elimination: the two kernels 7 and 8 back to back
  *   1  point half of the reduced operator  S p   (matrix-free PCG inner loop)
  *   2  station half of the reduced operator      (PCG inner loop)
  *   3  residual-only cost evaluation at a candidate point
  *   4  assembly of the off-diagonal 6x6 blocks of the reduced matrix
- *   5  one PCG iteration on the block-sparse reduced system (SpMV + two vector kernels)
+ *   5  one PCG iteration on the block-sparse reduced system (SpMV, vector kernel, preconditioner kernels)
  *   6  the block-sparse matrix-vector product of that iteration alone
+ *   7  per-point kernel of 0: first evaluation, V, its gradient, the camera coupling, V^-1
+ *   8  per-observation kernel of 0: second evaluation, all per-observation rows written once
  * No counterpart in the reference (its timers are wall-clock prints, src/main.cpp:3027, 4703).
  */
 int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *seconds_per_launch);
