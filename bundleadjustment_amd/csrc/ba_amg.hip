@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <vector>
 
+#include "ba_cg_device.h"
 #include "ba_device.h"
 #include "ba_kernels.h"
 
@@ -162,7 +163,9 @@ __device__ __forceinline__ double coarse_jacobi(const double *__restrict__ D, do
 // rc[c] = sum over the blocks of column c of P^T v ; result (per r = lane & 7 < 6) in every group of
 // 8 lanes of the wave.  The indices of up to 64 blocks are fetched with one coalesced load and
 // handed round by shuffles, so that all value loads of a pass are independent of each other.
-__device__ __forceinline__ double restrict_column(const AmgTransfer &t, int c, const double *__restrict__ v, int lane) {
+// With q != null the vector is v - alpha q, formed on the fly.
+__device__ __forceinline__ double restrict_column(const AmgTransfer &t, int c, const double *__restrict__ v, int lane,
+                                                  const double *__restrict__ q = nullptr, double alpha = 0.0) {
   const int g = lane >> 3, r = lane & 7, rr = r < 6 ? r : 0;
   const int k0 = t.Pt_ptr[c], k1 = t.Pt_ptr[c + 1];
   double s = 0.0;
@@ -182,6 +185,11 @@ __device__ __forceinline__ double restrict_column(const AmgTransfer &t, int c, c
         for (int m = 0; m < 6; ++m) {
           pv[u][m] = on ? P[6 * m] : 0.0;
           vv[u][m] = on ? vi[m] : 0.0;
+        }
+        if (q) {
+          const double *qi = q + 6 * (int64_t)row;
+#pragma unroll
+          for (int m = 0; m < 6; ++m) vv[u][m] -= on ? alpha * qi[m] : 0.0;
         }
       }
 #pragma unroll
@@ -215,6 +223,36 @@ k_amg_restrict(AmgTransfer t, const double *__restrict__ v, double *__restrict__
   }
   const double tot = block_sum(dot, lds);
   if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// Second kernel of a multilevel PCG iteration: the vector update and the first restriction in one
+// launch.  Workgroups [0, nbv) update x, r, z (thread per station); the others restrict the NEW residual
+// r_in - alpha q, formed on the fly, so they need not wait for the first group.  The residual is double
+// buffered by iteration parity because the two groups run concurrently.
+__global__ void __launch_bounds__(256)
+k_amg_update1_restrict(BsrCgArgs a, AmgTransfer t, int parity, int nblk_spmv, int nbv, double *__restrict__ part) {
+  __shared__ double lds[4];
+  if (a.scal[8 + parity] != 0.0) return;
+  const double *rin = parity ? a.r2 : a.r;
+  double *rout = parity ? a.r : a.r2;
+  const bool vec = (int)blockIdx.x < nbv;
+  const double alpha = cg2_update1_body(a, parity, nblk_spmv, rin, rout, vec ? (int)blockIdx.x : -1, nbv);
+  if (vec) return;
+  const int cb = blockIdx.x - nbv;
+  const int c = cb * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, r = lane & 7;
+  double dot = 0.0;
+  if (c < t.nc) {
+    const double s = restrict_column(t, c, rin, lane, a.q, alpha);
+    double y;
+    const double d = coarse_jacobi(t.Dinv_c + 36 * (int64_t)c, s, lane, r, &y);
+    if (lane < 6) {
+      t.rc[6 * (int64_t)c + lane] = s;
+      t.y[6 * (int64_t)c + lane] = y;
+      dot = d;
+    }
+  }
+  const double tot = block_sum(dot, lds);
+  if (threadIdx.x == 0) part[cb] = tot;
 }
 
 // (P yc)[i][r] for the 8 lanes of a group (r = lane & 7 < 6): column indices of up to 8 blocks come
@@ -293,7 +331,7 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restr
   const double tot = block_sum(s, lds);  // has the barriers that publish Ls and gr4
   if (threadIdx.x == 0) tot_s = tot;
   if (defl && threadIdx.x < cg.ncam)  // t_c = r_c - G^T r_s
-    tcs[threadIdx.x] = cg.r[o + threadIdx.x] - ((gr4[0][threadIdx.x] + gr4[1][threadIdx.x]) + (gr4[2][threadIdx.x] + gr4[3][threadIdx.x]));
+    tcs[threadIdx.x] = ((mode == 1 && !parity) ? cg.r2 : cg.r)[o + threadIdx.x] - ((gr4[0][threadIdx.x] + gr4[1][threadIdx.x]) + (gr4[2][threadIdx.x] + gr4[3][threadIdx.x]));
   __syncthreads();
   if (defl && threadIdx.x < cg.ncam) {  // z_c = (Q^T S Q)^-1 t_c with the explicit inverse
     double zc = 0.0;
@@ -700,11 +738,16 @@ static AmgApplyArgs apply_args(const Amg *a) {
 
 // preconditioner part of one PCG iteration: after the vector kernel has left r, z = D0^-1 r and
 // the partials of r.z, finish z, the scalars and p.  mode 0 right after the start-up kernel.
-static void amg_finish_iteration(hipStream_t s, const BsrCgArgs &cg, const Amg *a, int parity, int mode, double rtol) {
+// first_done: the restriction into level 1 has already run (fused into the vector kernel)
+static void amg_finish_iteration(hipStream_t s, const BsrCgArgs &cg, const Amg *a, int parity, int mode, double rtol, int first_done) {
   const AmgApplyArgs aa = apply_args(a);
   int off = 0;
   for (int l = 0; l < aa.n_transfers; ++l) {
     const int nb = nblk(aa.t[l].nc, 4);
+    if (l == 0 && first_done) {
+      off += nb;
+      continue;
+    }
     hipLaunchKernelGGL(k_amg_restrict, dim3(nb), dim3(256), 0, s, aa.t[l], l == 0 ? cg.r : aa.t[l - 1].rc, aa.part + off);
     off += nb;
   }
@@ -716,12 +759,20 @@ static void amg_finish_iteration(hipStream_t s, const BsrCgArgs &cg, const Amg *
 
 void launch_amg_cg_init(hipStream_t s, const BsrCgArgs &cg, const Amg *a, double rtol) {
   launch_cg2_start(s, cg);
-  amg_finish_iteration(s, cg, a, 0, 0, rtol);
+  amg_finish_iteration(s, cg, a, 0, 0, rtol, 0);
 }
 
 void launch_amg_cg_iteration(hipStream_t s, const BsrCgArgs &cg, const Amg *a, int parity) {
-  launch_cg2_spmv_update1(s, cg, parity);
-  amg_finish_iteration(s, cg, a, parity, 1, 0.0);
+  const AmgApplyArgs aa = apply_args(a);
+  if (aa.n_transfers == 0 || !cg.r2) {
+    launch_cg2_spmv_update1(s, cg, parity);
+    amg_finish_iteration(s, cg, a, parity, 1, 0.0, 0);
+    return;
+  }
+  launch_bsr_spmv(s, cg, parity);
+  const int nbv = cg2_blocks_vec(cg.S), nbr = nblk(aa.t[0].nc, 4);
+  hipLaunchKernelGGL(k_amg_update1_restrict, dim3(nbv + nbr), dim3(256), 0, s, cg, aa.t[0], parity, cg2_blocks_spmv(cg.S), nbv, aa.part);
+  amg_finish_iteration(s, cg, a, parity, 1, 0.0, 1);
 }
 
 }  // namespace ba

@@ -115,7 +115,7 @@ struct ba_problem {
   ba::Amg *amg = nullptr;             // multilevel preconditioner (built at the first PCG solve)
   // camera coarse space of that preconditioner: G ~ S_ss^-1 S_sc, computed once per problem
   double *d_G = nullptr, *d_GT = nullptr, *d_SG = nullptr, *d_defl_part = nullptr, *d_E = nullptr, *d_Lcc_defl = nullptr, *d_part_gr = nullptr;
-  double *d_defl_b = nullptr;
+  double *d_defl_b = nullptr, *d_r2 = nullptr;
   bool have_G = false;
   // general explicit border (several cameras or many free camera parameters); null -> one probe per camera column
   double *d_Zc = nullptr, *d_part_cc = nullptr, *d_corner_gen = nullptr;
@@ -469,6 +469,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   BA_TRY(p->dalloc(&p->d_g, nr)); BA_TRY(p->dalloc(&p->d_b, nr)); BA_TRY(p->dalloc(&p->d_x, nr));
   BA_TRY(p->dalloc(&p->d_r, nr)); BA_TRY(p->dalloc(&p->d_z, nr)); BA_TRY(p->dalloc(&p->d_p, nr));
   BA_TRY(p->dalloc(&p->d_q, nr));
+  BA_TRY(p->dalloc(&p->d_r2, nr));
   BA_TRY(p->dalloc(&p->d_Minv, 36 * (size_t)S));
   BA_TRY(p->dalloc(&p->d_Ssc, 6 * (size_t)S * p->ncam));
   BA_TRY(p->dalloc(&p->d_Scc, (size_t)p->ncam * p->ncam));
@@ -709,6 +710,7 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
   a.S = p->S; a.ncam = p->ncam; a.rowptr = p->d_bsr_rowptr; a.col = p->d_bsr_col; a.val = p->d_bsr_val; a.Ssc = p->d_Ssc;
   a.Scc = p->d_Scc; a.Lcc = p->d_Sccinv; a.Minv = p->d_Minv; a.b = p->d_b; a.x = p->d_x; a.r = p->d_r; a.z = p->d_z; a.p = p->d_p;
   a.q = p->d_q; a.scal = p->d_cg2scal; a.part_pq = p->d_part_pq; a.part_qc = p->d_part_qc; a.part_rz = p->d_part_rz;
+  a.r2 = p->d_r2;
   // multilevel preconditioner: structure once (it needs the values of a first linearisation),
   // numbers after every change of the matrix
   bool use_amg = opt->preconditioner == 0 && p->S > 1;
@@ -1394,6 +1396,7 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
   ba.S = p->S; ba.ncam = p->ncam; ba.rowptr = p->d_bsr_rowptr; ba.col = p->d_bsr_col; ba.val = p->d_bsr_val; ba.Ssc = p->d_Ssc;
   ba.Scc = p->d_Scc; ba.Lcc = p->d_Sccinv; ba.Minv = p->d_Minv; ba.b = p->d_b; ba.x = p->d_x; ba.r = p->d_r; ba.z = p->d_z; ba.p = p->d_p;
   ba.q = p->d_q; ba.scal = p->d_cg2scal; ba.part_pq = p->d_part_pq; ba.part_qc = p->d_part_qc; ba.part_rz = p->d_part_rz;
+  ba.r2 = p->d_r2;
   if ((which == 4 || which == 5 || which == 6) && !p->explicit_ok) return fail(BA_ERR_INVALID, "ba_time_kernel: the block-sparse system was not built for this network");
   // the PCG iteration is timed with the preconditioner the last solve used (multilevel once it has been built)
   const bool with_amg = p->amg && amg_levels(p->amg) >= 2;

@@ -135,6 +135,7 @@ struct BsrCgArgs {
   const int *rowptr, *col;
   const double *val, *Ssc, *Scc, *Lcc, *Minv, *b;  // Lcc: explicit INVERSE of the camera block of the preconditioner
   double *x, *r, *z, *p, *q, *scal, *part_pq, *part_qc, *part_rz;
+  double *r2;  // second residual buffer of the multilevel iteration (iteration it reads r or r2 by parity, writes the other)
   // camera coarse space of the multilevel preconditioner (null when not used): G [6S x ncam], an
   // approximation of S_ss^-1 S_sc; Lcc is then the INVERSE of Q^T S Q, Q = [-G; I]
   const double *G, *GT;  // by rows and by columns
