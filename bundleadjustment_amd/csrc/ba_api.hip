@@ -65,6 +65,7 @@ struct ba_problem {
   int N = 0, S = 0, P = 0, C = 0;
   int ncam = 0, ncmax = 0, nr = 0, n_chunks = 0;
   double huber_a = 1.0;
+  int model = 0;  // projection of the image rows, 0..7
   hipStream_t stream = nullptr;
   std::vector<void *> allocs;
   // host copies
@@ -168,7 +169,8 @@ namespace {
 int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   const int N = d->n_obs, S = d->n_sta, P = d->n_pts, C = d->n_cam;
   if (N < 0 || S < 0 || P < 0 || C < 0) return fail(BA_ERR_INVALID, "negative dimension");
-  if (in->model != 0) return fail(BA_ERR_UNSUPPORTED, "projection model %d is not implemented (0 = collinearity)", in->model);
+  if (in->model < 0 || in->model > 7)
+    return fail(BA_ERR_UNSUPPORTED, "projection model %d is not implemented (0 collinearity, 1 stereographic, 2..5 fisheye, 6 orthographic, 7 omnidirectional)", in->model);
   if (N > 0 && (!in->obs_pt || !in->obs_sta || !in->obs_x || !in->obs_y || !in->obs_sx || !in->obs_sy || !in->obs_cx || !in->obs_cy))
     return fail(BA_ERR_INVALID, "null observation array");
   if ((S > 0 && !in->sta_cam) || (P > 0 && (!in->pt_prior || !in->pt_sigma)) ||
@@ -176,6 +178,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
     return fail(BA_ERR_INVALID, "null station / point / camera array");
   p->N = N; p->S = S; p->P = P; p->C = C;
   p->huber_a = in->huber_a;
+  p->model = in->model;
   for (int n = 0; n < N; ++n) {
     if (in->obs_pt[n] < 0 || in->obs_pt[n] >= P) return fail(BA_ERR_INVALID, "observation %d: point index %d out of range [0,%d)", n, in->obs_pt[n], P);
     if (in->obs_sta[n] < 0 || in->obs_sta[n] >= S) return fail(BA_ERR_INVALID, "observation %d: station index %d out of range [0,%d)", n, in->obs_sta[n], S);
@@ -556,7 +559,7 @@ int linearize(ba_problem *p, const LmState &st) {
   la.scale_pt = p->d_scale_pt; la.pt_prior = p->d_pt_prior; la.pt_isig = p->d_pt_isig; la.cam = p->d_cam;
   la.rec = p->d_rec; la.Jp = p->d_Jp; la.Jc = p->d_Jc; la.Mo = p->d_Mo; la.Vinv = p->d_Vinv; la.g_pt = p->d_g_pt;
   la.colnorm_pt = p->d_colnorm_pt; la.diag_pt = p->d_diag_pt; la.cost_partial = p->d_partial; la.flags = p->d_flags;
-  la.huber_a = p->huber_a; la.lm_min = st.lm_min; la.lm_max = st.lm_max; la.radius = st.radius; la.reuse_diag = st.reuse_diag;
+  la.huber_a = p->huber_a; la.model = p->model; la.lm_min = st.lm_min; la.lm_max = st.lm_max; la.radius = st.radius; la.reuse_diag = st.reuse_diag;
   la.Y = (st.reduced == 2) ? p->d_Y : nullptr;
   la.Jt = p->d_Jt;
   la.cam_partial = p->d_campart;
@@ -921,7 +924,7 @@ int cost_at(ba_problem *p, const double *eop, const double *xyz, const CamRec *c
   hipStream_t s = p->stream;
   launch_station_prep(s, p->S, eop, p->d_scale_sta, p->d_sta_cam, sta_buf);
   CostArgs ca{};
-  ca.N = p->N; ca.obs = p->d_obs; ca.sta = sta_buf; ca.xyz = xyz; ca.obs_pt = p->d_obs_pt; ca.cam = cam; ca.huber_a = p->huber_a;
+  ca.N = p->N; ca.obs = p->d_obs; ca.sta = sta_buf; ca.xyz = xyz; ca.obs_pt = p->d_obs_pt; ca.cam = cam; ca.huber_a = p->huber_a; ca.model = p->model;
   ca.apply_loss = apply_loss; ca.res_out = res_out; ca.partial = p->d_partial;
   const int b1 = cost_blocks(p->N), b2 = cost_blocks(3 * (int64_t)p->P);
   launch_cost_obs(s, ca, b1);
@@ -1360,7 +1363,7 @@ int ba_residual_jacobian(ba_problem *p, double *r, double *J) {
   launch_station_prep(p->stream, p->S, p->d_eop, p->d_scale_sta, p->d_sta_cam, p->d_sta_c);
   CostArgs ca{};
   ca.N = p->N; ca.obs = p->d_obs; ca.sta = p->d_sta_c; ca.xyz = p->d_xyz; ca.obs_pt = p->d_obs_pt; ca.cam = p->d_cam;
-  ca.huber_a = p->huber_a;
+  ca.huber_a = p->huber_a; ca.model = p->model;
   launch_resjac_dense(p->stream, ca, d_r, d_J);
   int rc = p->check_kernels();
   if (!rc && hipStreamSynchronize(p->stream) != hipSuccess) rc = fail(BA_ERR_DEVICE, "residual/Jacobian kernel failed");
@@ -1388,7 +1391,7 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
   la.scale_pt = p->d_scale_pt; la.pt_prior = p->d_pt_prior; la.pt_isig = p->d_pt_isig; la.cam = p->d_cam;
   la.rec = p->d_rec; la.Jp = p->d_Jp; la.Jc = p->d_Jc; la.Mo = p->d_Mo; la.Vinv = p->d_Vinv; la.g_pt = p->d_g_pt;
   la.colnorm_pt = p->d_colnorm_pt; la.diag_pt = p->d_diag_pt; la.cost_partial = p->d_partial; la.flags = p->d_flags;
-  la.huber_a = p->huber_a; la.lm_min = st.lm_min; la.lm_max = st.lm_max; la.radius = st.radius; la.reuse_diag = 0;
+  la.huber_a = p->huber_a; la.model = p->model; la.lm_min = st.lm_min; la.lm_max = st.lm_max; la.radius = st.radius; la.reuse_diag = 0;
   la.Y = p->explicit_ok ? p->d_Y : nullptr;
   la.Jt = p->d_Jt;
   la.cam_partial = p->d_campart;
@@ -1412,7 +1415,7 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
   StationArgs sa = station_args(p, 7, 6);
   CostArgs ca{};
   ca.N = p->N; ca.obs = p->d_obs; ca.sta = p->d_sta; ca.xyz = p->d_xyz; ca.obs_pt = p->d_obs_pt; ca.cam = p->d_cam;
-  ca.huber_a = p->huber_a; ca.partial = p->d_partial;
+  ca.huber_a = p->huber_a; ca.model = p->model; ca.partial = p->d_partial;
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));

@@ -72,18 +72,79 @@ __device__ __forceinline__ CamIn load_cam(const CamRec *__restrict__ cam, int c)
 //   src/main.cpp:1322-1388 (collinearity) with the constant correction of :2096-2097.
 // R, C, sk, ck come from the station record; dcol[p][row] (p = 0..18: xp yp c a1 a2 k1 k2 k3 p1 p2
 // ep1..ep9) are the camera columns before selection of the free ones.
-template <bool JAC>
+// GEN = false is the collinearity projection x = -c Xc/Zc.  GEN = true takes `model` (uniform over a
+// launch) and covers the reference's other functors, whose projections all have the form
+// (x, y) = c h(rho, Zc) (Xc, Yc) with rho = sqrt(Xc^2 + Yc^2):
+//   1 collinearity stereographic  h = 2/(d - Zc), d = |(Xc,Yc,Zc)|            src/main.cpp:2161-2166
+//   2 fisheye equidistant         h = theta/rho, theta = atan2(rho, -Zc)      src/main.cpp:2255-2256
+//   3 fisheye equisolid angle     h = 2 sin(theta/2)/rho                      src/main.cpp:2341-2342
+//   4 fisheye orthographic        h = sin(theta)/rho                          src/main.cpp:2427-2428
+//   5 fisheye stereographic       h = 2 tan(theta/2)/rho                      src/main.cpp:2513-2514
+//   6 collinearity orthographic   h = 1                                       src/main.cpp:1441-1442
+//   7 omnidirectional             model 2 with (|Xc|, |Yc|) for (Xc, Yc)      src/main.cpp:2737-2738
+// (model 0 through this path gives h = -1/Zc).  hr = (dh/drho)/rho and hz = dh/dZc give
+// d(x,y)/d(Xc,Yc,Zc) = c [ h I + hr (Xc,Yc)(Xc,Yc)^T | hz (Xc,Yc) ].
+template <bool JAC, bool GEN = false>
 __device__ __forceinline__ void eval_obs(const ObsIn &o, const double *__restrict__ st, const double X, const double Y,
                                          const double Z, const CamIn &cm, double &r0, double &r1, double *Js /*12*/,
-                                         double *Jp /*6*/, double *dc0 /*19*/, double *dc1 /*19*/) {
+                                         double *Jp /*6*/, double *dc0 /*19*/, double *dc1 /*19*/, const int model = 0) {
   const double R0 = st[0], R1 = st[1], R2 = st[2], R3 = st[3], R4 = st[4], R5 = st[5], R6 = st[6], R7 = st[7], R8 = st[8];
   const double dX = X - st[9], dY = Y - st[10], dZ = Z - st[11];
   const double Xc = R0 * dX + R1 * dY + R2 * dZ;  // :1338-1340
   const double Yc = R3 * dX + R4 * dY + R5 * dZ;
   const double Zc = R6 * dX + R7 * dY + R8 * dZ;
-  const double iz = 1.0 / Zc;
-  const double x = -cm.c * Xc * iz;  // :1349-1350
-  const double y = -cm.c * Yc * iz;
+  double iz = 0.0, x, y;
+  double h = 0.0, hr = 0.0, hz = 0.0;
+  if (!GEN) {
+    iz = 1.0 / Zc;
+    x = -cm.c * Xc * iz;  // :1349-1350
+    y = -cm.c * Yc * iz;
+  } else {
+    const double rho2 = Xc * Xc + Yc * Yc;
+    if (model == 0) {
+      h = -1.0 / Zc;
+      hz = h * h;
+    } else if (model == 6) {
+      h = 1.0;
+    } else if (model == 1) {
+      const double d = sqrt(rho2 + Zc * Zc), ie = 1.0 / (d - Zc), id = 1.0 / d;
+      h = 2.0 * ie;
+      hz = h * id;
+      hr = rho2 > 0.0 ? -hz * ie : 0.0;
+    } else {
+      const double rho = sqrt(rho2), ir = 1.0 / rho, id2 = 1.0 / (rho2 + Zc * Zc);
+      const double th = atan2(rho, -Zc);
+      double f, fth;  // (x, y) = c f(theta) (Xc, Yc)/rho
+      if (model == 2 || model == 7) {
+        f = th;
+        fth = 1.0;
+      } else if (model == 3) {
+        double sh, ch;
+        sincos(0.5 * th, &sh, &ch);
+        f = 2.0 * sh;
+        fth = ch;
+      } else if (model == 4) {
+        double s1, c1;
+        sincos(th, &s1, &c1);
+        f = s1;
+        fth = c1;
+      } else {
+        double sh, ch;
+        sincos(0.5 * th, &sh, &ch);
+        f = 2.0 * sh / ch;
+        fth = 1.0 / (ch * ch);
+      }
+      h = f * ir;
+      hr = (fth * (-Zc * id2) - h) * ir * ir;  // d theta/d rho = -Zc/d^2
+      hz = fth * (rho * id2) * ir;             // d theta/d Zc  =  rho/d^2
+    }
+    x = cm.c * h * Xc;
+    y = cm.c * h * Yc;
+    if (model == 7) {
+      x = fabs(x);
+      y = fabs(y);
+    }
+  }
   const double xb = (o.x - cm.xp) / BA_APSCALE;  // :1357-1362
   const double yb = (o.y - cm.yp) / BA_APSCALE;
   const double rr = xb * xb + yb * yb;
@@ -100,19 +161,33 @@ __device__ __forceinline__ void eval_obs(const ObsIn &o, const double *__restric
   r1 = (y + cm.yp + ddy - o.cy - o.y) * isy;
   if (!JAC) return;
 
-  // d(x,y)/d(Xc,Yc,Zc)
-  const double a = -cm.c * iz, bx = -x * iz, by = -y * iz;
-  const double ax = a * isx, bxx = bx * isx, ay = a * isy, byy = by * isy;
-  // point block: d cam / d XYZ = R
-  Jp[0] = ax * R0 + bxx * R6; Jp[1] = ax * R1 + bxx * R7; Jp[2] = ax * R2 + bxx * R8;
-  Jp[3] = ay * R3 + byy * R6; Jp[4] = ay * R4 + byy * R7; Jp[5] = ay * R5 + byy * R8;
-  // station block: omega, phi, kappa, Xo, Yo, Zo
   const double sk = st[12], ck = st[13];
   const double woX = R1 * dZ - R2 * dY, woY = R4 * dZ - R5 * dY, woZ = R7 * dZ - R8 * dY;  // d cam / d omega
   const double wpX = -ck * Zc, wpY = sk * Zc, wpZ = ck * Xc - sk * Yc;                      // d cam / d phi
-  Js[0] = ax * woX + bxx * woZ;  Js[6] = ay * woY + byy * woZ;
-  Js[1] = ax * wpX + bxx * wpZ;  Js[7] = ay * wpY + byy * wpZ;
-  Js[2] = ax * Yc;               Js[8] = -ay * Xc;                                         // d cam / d kappa = (Yc,-Xc,0)
+  if (!GEN) {
+    // d(x,y)/d(Xc,Yc,Zc)
+    const double a = -cm.c * iz, bx = -x * iz, by = -y * iz;
+    const double ax = a * isx, bxx = bx * isx, ay = a * isy, byy = by * isy;
+    // point block: d cam / d XYZ = R
+    Jp[0] = ax * R0 + bxx * R6; Jp[1] = ax * R1 + bxx * R7; Jp[2] = ax * R2 + bxx * R8;
+    Jp[3] = ay * R3 + byy * R6; Jp[4] = ay * R4 + byy * R7; Jp[5] = ay * R5 + byy * R8;
+    // station block: omega, phi, kappa, Xo, Yo, Zo
+    Js[0] = ax * woX + bxx * woZ;  Js[6] = ay * woY + byy * woZ;
+    Js[1] = ax * wpX + bxx * wpZ;  Js[7] = ay * wpY + byy * wpZ;
+    Js[2] = ax * Yc;               Js[8] = -ay * Xc;                                         // d cam / d kappa = (Yc,-Xc,0)
+  } else {
+    // model 7: the rows of x and y take the signs of Xc and Yc
+    const double cx = (model == 7 && Xc < 0.0) ? -cm.c * isx : cm.c * isx;
+    const double cy = (model == 7 && Yc < 0.0) ? -cm.c * isy : cm.c * isy;
+    const double hxy = hr * Xc * Yc;
+    const double ax = cx * (h + hr * Xc * Xc), bx = cx * hxy, gx = cx * hz * Xc;  // row of x wrt (Xc, Yc, Zc)
+    const double ay = cy * hxy, by = cy * (h + hr * Yc * Yc), gy = cy * hz * Yc;  // row of y
+    Jp[0] = ax * R0 + bx * R3 + gx * R6; Jp[1] = ax * R1 + bx * R4 + gx * R7; Jp[2] = ax * R2 + bx * R5 + gx * R8;
+    Jp[3] = ay * R0 + by * R3 + gy * R6; Jp[4] = ay * R1 + by * R4 + gy * R7; Jp[5] = ay * R2 + by * R5 + gy * R8;
+    Js[0] = ax * woX + bx * woY + gx * woZ;  Js[6] = ay * woX + by * woY + gy * woZ;
+    Js[1] = ax * wpX + bx * wpY + gx * wpZ;  Js[7] = ay * wpX + by * wpY + gy * wpZ;
+    Js[2] = ax * Yc - bx * Xc;               Js[8] = ay * Yc - by * Xc;
+  }
   Js[3] = -Jp[0]; Js[4] = -Jp[1]; Js[5] = -Jp[2];
   Js[9] = -Jp[3]; Js[10] = -Jp[4]; Js[11] = -Jp[5];
   // camera block
@@ -127,7 +202,12 @@ __device__ __forceinline__ void eval_obs(const ObsIn &o, const double *__restric
   const double is = 1.0 / BA_APSCALE;
   dc0[0] = (1.0 - dxx * is) * isx;  dc1[0] = (-dyx * is) * isy;        // xp
   dc0[1] = (-dxy * is) * isx;       dc1[1] = (1.0 - dyy * is) * isy;   // yp
-  dc0[2] = -Xc * iz * isx;          dc1[2] = -Yc * iz * isy;           // c
+  if (!GEN) {
+    dc0[2] = -Xc * iz * isx;        dc1[2] = -Yc * iz * isy;           // c
+  } else {
+    dc0[2] = h * (model == 7 ? fabs(Xc) : Xc) * isx;
+    dc1[2] = h * (model == 7 ? fabs(Yc) : Yc) * isy;
+  }
   const double xs = xb * isx, ys = yb * isy;
   dc0[3] = xs;                      dc1[3] = 0.0;                      // a1
   dc0[4] = yb * isx;                dc1[4] = 0.0;                      // a2

@@ -28,6 +28,7 @@ struct LinArgs {
   unsigned *flags;
   double huber_a, lm_min, lm_max, radius;
   int reuse_diag;
+  int model;  // projection, 0..7 (ba_inputs.model)
 };
 
 struct PointArgs {
@@ -72,6 +73,7 @@ struct CostArgs {
   const CamRec *cam;
   double huber_a;
   int apply_loss;
+  int model;
   double *res_out;  // file order, may be null
   double *partial;
 };

@@ -58,7 +58,7 @@ __global__ void k_station_prep(int S, const double *__restrict__ eop, const doub
 #define LIN_NCB 8
 #define ELIM_STRIDE 40  // per point: u = V^-1 g (3) | L, V^-1 = L L^T (6) | pad (7) | Z = V^-1 B^T (LIN_NCB x 3)
 
-template <bool CAM1>
+template <bool CAM1, bool GEN>
 __global__ void __launch_bounds__(256)
 k_point_elim(LinArgs a) {
   __shared__ double lds[8];
@@ -79,7 +79,7 @@ k_point_elim(LinArgs a) {
       const int c = __double2loint(st[20]);
       const CamIn cm = load_cam(a.cam, c);
       double r0, r1, Js[12], Jp[6], dc0[BA_NCAMPAR], dc1[BA_NCAMPAR];
-      eval_obs<true>(o, st, X, Y, Z, cm, r0, r1, Js, Jp, dc0, dc1);
+      eval_obs<true, GEN>(o, st, X, Y, Z, cm, r0, r1, Js, Jp, dc0, dc1, a.model);
       double sc;
       cost += 0.5 * huber_rho(a.huber_a, r0 * r0 + r1 * r1, sc);
       r0 *= sc;
@@ -188,7 +188,7 @@ __device__ __forceinline__ void tile_store(double *buf, const double (&v)[R], do
 }
 
 #define ROWS_LDS(CAM1) (64 * ((CAM1) ? 25 : 2 * BA_NCAMPAR + 1))
-template <bool CAM1>
+template <bool CAM1, bool GEN>
 __global__ void __launch_bounds__(256)
 k_obs_rows(LinArgs a) {
   __shared__ double lds[4][ROWS_LDS(CAM1)];
@@ -212,7 +212,7 @@ k_obs_rows(LinArgs a) {
     const double X = a.xyz[3 * (int64_t)jj], Y = a.xyz[3 * (int64_t)jj + 1], Z = a.xyz[3 * (int64_t)jj + 2];
     const double s0 = a.scale_pt[3 * (int64_t)jj], s1 = a.scale_pt[3 * (int64_t)jj + 1], s2 = a.scale_pt[3 * (int64_t)jj + 2];
     double r0, r1, Js[12], Jp[6], dc0[BA_NCAMPAR], dc1[BA_NCAMPAR];
-    eval_obs<true>(o, st, X, Y, Z, cm, r0, r1, Js, Jp, dc0, dc1);
+    eval_obs<true, GEN>(o, st, X, Y, Z, cm, r0, r1, Js, Jp, dc0, dc1, a.model);
     double sc;
     (void)huber_rho(a.huber_a, r0 * r0 + r1 * r1, sc);
     r0 *= sc;
@@ -719,6 +719,7 @@ __global__ void k_invert_blocks(int S, const double *__restrict__ src, const int
 // ------------------------------------------------------------------------------------------
 // cost at a candidate point (residuals only), src/main.cpp:1322-1388 + Huber
 // ------------------------------------------------------------------------------------------
+template <bool GEN>
 __global__ void __launch_bounds__(256)
 k_cost_obs(CostArgs a) {
   __shared__ double lds[8];
@@ -730,7 +731,7 @@ k_cost_obs(CostArgs a) {
     const int jj = a.obs_pt[e];
     const double *x = a.xyz + 3 * (int64_t)jj;
     double r0, r1;
-    eval_obs<false>(o, st, x[0], x[1], x[2], cm, r0, r1, nullptr, nullptr, nullptr, nullptr);
+    eval_obs<false, GEN>(o, st, x[0], x[1], x[2], cm, r0, r1, nullptr, nullptr, nullptr, nullptr, a.model);
     double sc;
     const double rho = huber_rho(a.huber_a, r0 * r0 + r1 * r1, sc);
     cost += 0.5 * rho;
@@ -1089,6 +1090,7 @@ __global__ void k_unit(int64_t n, double *__restrict__ v, int64_t k) {
 
 // Per-observation residuals and dense 2x28 Jacobians in file order (no loss, no scaling):
 // the counterpart of AutoDiffCostFunction<collinearity,2,6,3,3,16>::Evaluate, src/main.cpp:3845-3847.
+template <bool GEN>
 __global__ void __launch_bounds__(256)
 k_resjac_dense(CostArgs a, double *__restrict__ r_out, double *__restrict__ J_out) {
   const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1098,7 +1100,7 @@ k_resjac_dense(CostArgs a, double *__restrict__ r_out, double *__restrict__ J_ou
   const CamIn cm = load_cam(a.cam, __double2loint(st[20]));
   const double *x = a.xyz + 3 * (int64_t)a.obs_pt[e];
   double r0, r1, Js[12], Jp[6], dc0[BA_NCAMPAR], dc1[BA_NCAMPAR];
-  eval_obs<true>(o, st, x[0], x[1], x[2], cm, r0, r1, Js, Jp, dc0, dc1);
+  eval_obs<true, GEN>(o, st, x[0], x[1], x[2], cm, r0, r1, Js, Jp, dc0, dc1, a.model);
   if (r_out) {
     r_out[2 * (int64_t)o.row] = r0;
     r_out[2 * (int64_t)o.row + 1] = r1;
@@ -1231,13 +1233,17 @@ int obs_rows_blocks(int64_t N) {
 void launch_linearize(hipStream_t s, const LinArgs &a, int part) {
   if (a.P <= 0) return;
   const dim3 gp(nblk(a.P, 256)), go(obs_rows_blocks(a.N)), b(256);
+  const bool gen = a.model != 0;
+  void (*elim)(LinArgs), (*rows)(LinArgs);
   if (a.Jt) {
-    if (part & 1) hipLaunchKernelGGL(k_point_elim<true>, gp, b, 0, s, a);
-    if (part & 2) hipLaunchKernelGGL(k_obs_rows<true>, go, b, 0, s, a);
+    elim = gen ? k_point_elim<true, true> : k_point_elim<true, false>;
+    rows = gen ? k_obs_rows<true, true> : k_obs_rows<true, false>;
   } else {
-    if (part & 1) hipLaunchKernelGGL(k_point_elim<false>, gp, b, 0, s, a);
-    if (part & 2) hipLaunchKernelGGL(k_obs_rows<false>, go, b, 0, s, a);
+    elim = gen ? k_point_elim<false, true> : k_point_elim<false, false>;
+    rows = gen ? k_obs_rows<false, true> : k_obs_rows<false, false>;
   }
+  if (part & 1) hipLaunchKernelGGL(elim, gp, b, 0, s, a);
+  if (part & 2) hipLaunchKernelGGL(rows, go, b, 0, s, a);
 }
 int elim_stride() { return ELIM_STRIDE; }
 int lin_ncb() { return LIN_NCB; }
@@ -1302,7 +1308,8 @@ int cost_blocks(int64_t n) {
   return b < 1 ? 1 : (b > 4096 ? 4096 : b);
 }
 void launch_cost_obs(hipStream_t s, const CostArgs &a, int blocks) {
-  hipLaunchKernelGGL(k_cost_obs, dim3(blocks), dim3(256), 0, s, a);
+  void (*k)(CostArgs) = a.model ? k_cost_obs<true> : k_cost_obs<false>;
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, s, a);
 }
 void launch_cost_prior(hipStream_t s, int P, const double *xyz, const double *prior, const double *isig, const int *pt_file,
                        double *res_out, double *partial, int blocks) {
@@ -1344,7 +1351,8 @@ void launch_unit(hipStream_t s, int64_t n, double *v, int64_t k) {
   if (n > 0) hipLaunchKernelGGL(k_unit, dim3(nblk(n, 256)), dim3(256), 0, s, n, v, k);
 }
 void launch_resjac_dense(hipStream_t s, const CostArgs &a, double *r_out, double *J_out) {
-  if (a.N > 0) hipLaunchKernelGGL(k_resjac_dense, dim3(nblk(a.N, 256)), dim3(256), 0, s, a, r_out, J_out);
+  void (*k)(CostArgs, double *, double *) = a.model ? k_resjac_dense<true> : k_resjac_dense<false>;
+  if (a.N > 0) hipLaunchKernelGGL(k, dim3(nblk(a.N, 256)), dim3(256), 0, s, a, r_out, J_out);
 }
 
 }  // namespace ba

@@ -17,7 +17,7 @@ class SynthConfig(C.Structure):
         ("seed", C.c_uint64), ("ap_free_mask", C.c_uint16), ("iop_free_mask", C.c_uint8),
         ("empirical_terms", C.c_uint8), ("noise_sigma", C.c_double), ("outlier_fraction", C.c_double),
         ("control_sigma", C.c_double), ("free_sigma", C.c_double), ("control_every", C.c_int32),
-        ("perfect_start", C.c_int32),
+        ("perfect_start", C.c_int32), ("model", C.c_int32),
     ]
 
 
@@ -141,6 +141,11 @@ class HostNetwork:
 
     def set_free(self, ap_free_mask, iop_free_mask=7):
         _check(lib().ba_net_set_free(self._h, ap_free_mask, iop_free_mask))
+        self.net = self._export()
+
+    def set_model(self, model):
+        """Projection of the image rows: 0 collinearity, 1 collinearity stereographic, 2..5 the fisheye functors."""
+        _check(lib().ba_net_set_model(self._h, int(model)))
         self.net = self._export()
 
     def set_parameters(self, eop, xyz, iop, ap):

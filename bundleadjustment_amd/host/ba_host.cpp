@@ -32,6 +32,7 @@ const double kApScale = 1000.0;                                       // src/mai
 }  // namespace
 
 struct ba_network {
+  int32_t model = 0;  // projection functor, 0..7
   // .pho (src/main.cpp:3058-3059)
   std::vector<int32_t> imageTarget, imageStation;
   std::vector<double> imageX, imageY, imageXStdDev, imageYStdDev, imageXCorr, imageYCorr;
@@ -241,6 +242,29 @@ void distortion(const double *ap, double xb, double yb, double &dx, double &dy) 
   dy = yb * G + ap[6] * (rr + 2.0 * yb * yb) + 2.0 * ap[5] * xb * yb;
 }
 
+// image coordinates of a point at (Xc, Yc, Zc) in the camera frame, before principal point and distortion:
+// src/main.cpp:1349-1350, :2161-2166, :2255-2256, :2341-2342, :2427-2428, :2513-2514, :1441-1442, :2737-2738
+void project(int model, double c, double Xc, double Yc, double Zc, double &x, double &y) {
+  double h;
+  if (model == 0) {
+    h = -1.0 / Zc;
+  } else if (model == 1) {
+    h = 2.0 / (std::sqrt(Xc * Xc + Yc * Yc + Zc * Zc) - Zc);
+  } else if (model == 6) {
+    h = 1.0;
+  } else {
+    const double rho = std::sqrt(Xc * Xc + Yc * Yc), th = std::atan2(rho, -Zc);
+    const double f = (model == 2 || model == 7) ? th : model == 3 ? 2.0 * std::sin(0.5 * th) : model == 4 ? std::sin(th) : 2.0 * std::tan(0.5 * th);
+    h = f / rho;
+  }
+  x = c * h * Xc;
+  y = c * h * Yc;
+  if (model == 7) {
+    x = std::fabs(x);
+    y = std::fabs(y);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -287,15 +311,18 @@ void ba_synth_default(ba_synth_config *c) {
   c->free_sigma = 1.0e4;
   c->control_every = 64;
   c->perfect_start = 0;
+  c->model = 0;
 }
 
 int ba_net_synth(const ba_synth_config *cfg, ba_network **out) {
   if (!cfg || !out) return fail(BA_ERR_INVALID, "ba_net_synth: null argument");
   const int32_t C = cfg->n_cam, S = cfg->n_sta, P = cfg->n_pts;
   if (C < 1 || S < 1 || P < 1 || cfg->rays_per_point < 1) return fail(BA_ERR_INVALID, "ba_net_synth: sizes must be positive");
+  if (cfg->model < 0 || cfg->model > 7) return fail(BA_ERR_INVALID, "ba_net_synth: projection model %d out of range 0..7", cfg->model);
   const int32_t K = std::min(cfg->rays_per_point, S);
   if (static_cast<int64_t>(P) * K > 2000000000LL) return fail(BA_ERR_INVALID, "ba_net_synth: too many observations");
   ba_network *n = new ba_network();
+  n->model = cfg->model;
   Rng rng(cfg->seed);
 
   // cameras: image units are pixels, sensor about +-2000 px
@@ -308,7 +335,7 @@ int ba_net_synth(const ba_synth_config *cfg, ba_network **out) {
     n->iopXMax.push_back(2000.0); n->iopYMax.push_back(2000.0);
     n->tIOP[3 * c] = rng.uni(-5, 5);
     n->tIOP[3 * c + 1] = rng.uni(-5, 5);
-    n->tIOP[3 * c + 2] = 3000.0;
+    n->tIOP[3 * c + 2] = cfg->model == 6 ? 0.3 : 3000.0;  // orthographic: image = c x object coordinates
     double *a = &n->tAP[16 * static_cast<size_t>(c)];
     a[0] = 1e-2; a[1] = 1e-2; a[2] = 0.5; a[3] = -0.02; a[4] = 5e-4; a[5] = 0.05; a[6] = 0.05;
     if (cfg->empirical_terms) { a[7] = 1e-5; a[10] = 1e-8; }
@@ -395,7 +422,8 @@ int ba_net_synth(const ba_synth_config *cfg, ba_network **out) {
         const double dX = p[0] - e[3], dY = p[1] - e[4], dZ = p[2] - e[5];
         const double Xc = r[0] * dX + r[1] * dY + r[2] * dZ, Yc = r[3] * dX + r[4] * dY + r[5] * dZ;
         const double Zc = r[6] * dX + r[7] * dY + r[8] * dZ;
-        const double x = -io[2] * Xc / Zc, y = -io[2] * Yc / Zc;
+        double x, y;
+        project(cfg->model, io[2], Xc, Yc, Zc, x, y);
         // the correction is a function of the observed coordinate: solve x_obs = x + xp + dx(x_obs)
         double xo = x + io[0], yo = y + io[1];
         for (int it = 0; it < 5; ++it) {
@@ -434,7 +462,8 @@ int ba_net_synth(const ba_synth_config *cfg, ba_network **out) {
     for (size_t q = 0; q < n->XYZ.size(); ++q) n->XYZ[q] += 5.0 * rng.normal();
     for (int32_t c = 0; c < C; ++c)
       for (int k = 0; k < 3; ++k)
-        if (cfg->iop_free_mask & (1u << k)) n->IOP[3 * static_cast<size_t>(c) + k] += rng.normal();
+        if (cfg->iop_free_mask & (1u << k))
+          n->IOP[3 * static_cast<size_t>(c) + k] += (k == 2 && cfg->model == 6 ? 1e-4 : 1.0) * rng.normal();
   }
   n->xyzStdDev.resize(3 * static_cast<size_t>(P));
   const int32_t every = cfg->control_every > 0 ? cfg->control_every : 64;
@@ -454,6 +483,12 @@ int ba_net_synth(const ba_synth_config *cfg, ba_network **out) {
 }
 
 void ba_net_free(ba_network *net) { delete net; }
+
+int ba_net_set_model(ba_network *n, int32_t model) {
+  if (!n || model < 0 || model > 7) return fail(BA_ERR_INVALID, "ba_net_set_model: model must be 0..7");
+  n->model = model;
+  return 0;
+}
 
 int ba_net_dims(const ba_network *n, ba_dims *d) {
   if (!n || !d) return fail(BA_ERR_INVALID, "ba_net_dims: null argument");
@@ -477,7 +512,7 @@ int ba_net_inputs(ba_network *n, ba_inputs *in) {
   in->ap_free_mask = n->apFree.data();
   in->iop_free_mask = n->iopFree.data();
   in->huber_a = 1.0;  // src/main.cpp:3810
-  in->model = 0;
+  in->model = n->model;
   return 0;
 }
 

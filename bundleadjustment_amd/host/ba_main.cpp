@@ -15,10 +15,13 @@
 static void usage() {
   fprintf(stderr,
           "usage: ba_main <file.pho> <file.eop> <file.iop> <file.xyz> [--out DIR] [--free-ap MASK] [--free-iop MASK]\n"
-          "               [--solver dense|pcg] [--pcg-rtol X] [--max-iter N] [--covariance]\n"
+          "               [--solver dense|pcg] [--pcg-rtol X] [--max-iter N] [--covariance] [--model M]\n"
           "       ba_main --synth C S P RAYS [same options]\n"
           "  MASK: bit k of --free-ap frees AP[k] (a1 a2 k1 k2 k3 p1 p2 ep1..ep9); default 0x4 = k1 only,\n"
           "        the reference's choice (src/main.cpp:4487-4504).  --free-iop: bits xp yp c, default 7.\n"
+          "  --model: projection functor, 0 collinearity (default), 1 collinearity stereographic, 2 fisheye equidistant,\n"
+          "        3 equisolid angle, 4 orthographic, 5 stereographic, 6 collinearity orthographic, 7 omnidirectional\n"
+          "        (src/main.cpp:3845-3918, :4016, :4186-4250).\n"
           "  --covariance: standard deviations of all parameters in the result files (the reference's COMPUTECX\n"
           "        branch, src/main.cpp:5261); small networks only.\n");
 }
@@ -28,6 +31,7 @@ int main(int argc, char **argv) {
   std::string out = ".";
   unsigned ap_mask = 0x4, iop_mask = 7;
   bool synth = false, covariance = false;
+  int model = 0;
   ba_options opt;
   ba_default_options(&opt);
   for (int i = 1; i < argc; ++i) {
@@ -41,6 +45,7 @@ int main(int argc, char **argv) {
     else if (a == "--max-iter") opt.max_num_iterations = atoi(next());
     else if (a == "--synth") synth = true;
     else if (a == "--covariance") covariance = true;
+    else if (a == "--model") model = atoi(next());
     else pos.push_back(a);
   }
   ba_network *net = nullptr;
@@ -51,6 +56,7 @@ int main(int argc, char **argv) {
     cfg.n_cam = atoi(pos[0].c_str()); cfg.n_sta = atoi(pos[1].c_str()); cfg.n_pts = atoi(pos[2].c_str());
     cfg.rays_per_point = atoi(pos[3].c_str());
     cfg.ap_free_mask = (uint16_t)ap_mask; cfg.iop_free_mask = (uint8_t)iop_mask;
+    cfg.model = model;
     if (ba_net_synth(&cfg, &net)) { fprintf(stderr, "error: %s\n", ba_host_last_error()); return 1; }
   } else {
     if (pos.size() != 4) { usage(); return 2; }
@@ -60,6 +66,7 @@ int main(int argc, char **argv) {
     }
     ba_net_set_free(net, (uint16_t)ap_mask, (uint8_t)iop_mask);
   }
+  if (ba_net_set_model(net, model)) { fprintf(stderr, "error: %s\n", ba_host_last_error()); return 1; }
   ba_dims d;
   ba_inputs in;
   ba_net_dims(net, &d);

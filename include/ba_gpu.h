@@ -93,7 +93,11 @@ typedef struct {
   const uint16_t *ap_free_mask; /* [n_cam] bit k set -> AP[k] is estimated; 0 -> block constant */
   const uint8_t *iop_free_mask; /* [n_cam] bits 0..2 -> xp,yp,c estimated; 0 -> block constant  */
   double huber_a;               /* 1.0 in the reference; <= 0 disables the robust loss          */
-  int32_t model;                /* 0 = collinearity; other projection models are reserved       */
+  int32_t model;                /* projection functor of the image rows (src/main.cpp:3845-3918, :4186-4250):
+                                 * 0 collinearity :1315/:2033, 1 collinearity stereographic :1500/:2133,
+                                 * 2 fisheye equidistant :1596/:2226, 3 equisolid angle :1680/:2312,
+                                 * 4 fisheye orthographic :1765/:2398, 5 fisheye stereographic :1850/:2484,
+                                 * 6 collinearity orthographic :1412, 7 omnidirectional :2700 */
 } ba_inputs;
 
 /*

@@ -47,6 +47,7 @@ typedef struct {
   double free_sigma;           /* prior sigma of every other point, mm        */
   int32_t control_every;       /* every n-th point is a control point         */
   int32_t perfect_start;       /* 1: initial values = truth (for debugging)   */
+  int32_t model;               /* projection the image points are made with, 0..7 (ba_inputs.model) */
 } ba_synth_config;
 
 void ba_synth_default(ba_synth_config *cfg);
@@ -69,6 +70,10 @@ const double *ba_net_truth_ap(const ba_network *net);
 /* File ids, [n_obs] target / station of each .pho row, [n_sta], [n_pts], [n_cam]. */
 const int32_t *ba_net_ids(const ba_network *net, int which /*0 pho target,1 pho station,2 eop station,3 eop camera,4 xyz target,5 iop camera*/);
 int ba_net_set_free(ba_network *net, uint16_t ap_free_mask, uint8_t iop_free_mask);
+/* Projection handed on by ba_net_inputs (the functor chosen at src/main.cpp:3845-3918, :4186-4250): 0 collinearity,
+ * 1 collinearity stereographic, 2..5 fisheye equidistant / equisolid-angle / orthographic / stereographic,
+ * 6 collinearity orthographic (:1412), 7 omnidirectional (:2700). */
+int ba_net_set_model(ba_network *net, int32_t model);
 
 /* First-match id lookup with a hash map: out[n] = first i with ids[i] == keys[n].
  * Returns BA_ERR_INVALID and sets out[n] = n_ids for every key that is absent. */

@@ -44,6 +44,19 @@ static double now_s(void) {
  * both rr^7 and rr^8); the Jacobian is the hand derivative of exactly these expressions. */
 void bao_collinearity(const double *EOP, const double *XYZ, const double *IOP, const double *AP,
                       const double *obs, double *residual, double *J) {
+  bao_projection(0, EOP, XYZ, IOP, AP, obs, residual, J);
+}
+
+/* The same cost model with the projection of one of the reference's other functors (their
+ * "MachineLearnedSimple" forms, which reduce to the plain ones when the correction is zero):
+ *   0 collinearity :2033-2120 (:1315-1401)      1 collinearityStereographic :2133-2225
+ *   2 fisheyeEquidistant :2226-2311              3 fisheyeEquisolidAngle :2312-2397
+ *   4 fisheyeOrthographic :2398-2483             5 fisheyeStereographic :2484-2571
+ *   6 collinearityOrthographic :1412-1490         7 omniCollinearity :2700-2790
+ * They differ in the two projection lines only: (x, y) = c h(rho, Zs) (Xs, Ys), rho = sqrt(Xs^2 + Ys^2);
+ * model 7 is model 2 with (|Xs|, |Ys|) in place of (Xs, Ys). */
+void bao_projection(int model, const double *EOP, const double *XYZ, const double *IOP, const double *AP,
+                    const double *obs, double *residual, double *J) {
   const double x_ = obs[0], y_ = obs[1], xStdDev_ = obs[2], yStdDev_ = obs[3];
   const double xMLP_ = obs[4], yMLP_ = obs[5];
 
@@ -68,9 +81,58 @@ void bao_collinearity(const double *EOP, const double *XYZ, const double *IOP, c
   const double YTemp = r21 * dX + r22 * dY + r23 * dZ;
   const double ZTemp = r31 * dX + r32 * dY + r33 * dZ;
 
-  /* :1349-1350 */
-  const double x = -IOP[2] * XTemp / ZTemp;
-  const double y = -IOP[2] * YTemp / ZTemp;
+  double x, y;
+  double h = 0.0, hr = 0.0, hz = 0.0; /* h, (dh/drho)/rho, dh/dZs for the Jacobian of models 1..7 */
+  if (model == 0) {
+    /* :1349-1350 */
+    x = -IOP[2] * XTemp / ZTemp;
+    y = -IOP[2] * YTemp / ZTemp;
+  } else if (model == 1) {
+    /* :2161-2166 */
+    const double d = sqrt(XTemp * XTemp + YTemp * YTemp + ZTemp * ZTemp);
+    x = (2.0 * IOP[2]) / (d - ZTemp) * XTemp;
+    y = (2.0 * IOP[2]) / (d - ZTemp) * YTemp;
+    const double rho2 = XTemp * XTemp + YTemp * YTemp, e = d - ZTemp;
+    h = 2.0 / e;
+    hr = rho2 > 0.0 ? -2.0 / (d * e * e) : 0.0;
+    hz = 2.0 / (d * e);
+  } else if (model == 6) {
+    /* :1441-1442 */
+    x = IOP[2] * XTemp;
+    y = IOP[2] * YTemp;
+    h = 1.0;
+  } else {
+    const double rho = sqrt(XTemp * XTemp + YTemp * YTemp);
+    const double th = atan2(rho, -ZTemp);
+    const double d2 = rho * rho + ZTemp * ZTemp;
+    const double th_r = -ZTemp / d2, th_z = rho / d2; /* d theta / d rho, d theta / d Zs */
+    double f, fth; /* (x, y) = c f(theta) (Xs, Ys) / rho */
+    if (model == 2) { /* :2255-2256 */
+      x = IOP[2] * XTemp * atan2(sqrt(XTemp * XTemp + YTemp * YTemp), -ZTemp) / sqrt(XTemp * XTemp + YTemp * YTemp);
+      y = IOP[2] * YTemp * atan2(sqrt(XTemp * XTemp + YTemp * YTemp), -ZTemp) / sqrt(XTemp * XTemp + YTemp * YTemp);
+      f = th; fth = 1.0;
+    } else if (model == 3) { /* :2341-2342 */
+      x = 2.0 * IOP[2] * XTemp * sin(0.5 * atan2(sqrt(XTemp * XTemp + YTemp * YTemp), -ZTemp)) / sqrt(XTemp * XTemp + YTemp * YTemp);
+      y = 2.0 * IOP[2] * YTemp * sin(0.5 * atan2(sqrt(XTemp * XTemp + YTemp * YTemp), -ZTemp)) / sqrt(XTemp * XTemp + YTemp * YTemp);
+      f = 2.0 * sin(0.5 * th); fth = cos(0.5 * th);
+    } else if (model == 4) { /* :2427-2428 */
+      x = IOP[2] * XTemp * sin(atan2(sqrt(XTemp * XTemp + YTemp * YTemp), -ZTemp)) / sqrt(XTemp * XTemp + YTemp * YTemp);
+      y = IOP[2] * YTemp * sin(atan2(sqrt(XTemp * XTemp + YTemp * YTemp), -ZTemp)) / sqrt(XTemp * XTemp + YTemp * YTemp);
+      f = sin(th); fth = cos(th);
+    } else if (model == 7) { /* :2737-2738 */
+      x = IOP[2] * atan2(sqrt(XTemp * XTemp + YTemp * YTemp), -ZTemp) / sqrt((YTemp / XTemp) * (YTemp / XTemp) + 1.0);
+      y = IOP[2] * atan2(sqrt(XTemp * XTemp + YTemp * YTemp), -ZTemp) / sqrt((XTemp / YTemp) * (XTemp / YTemp) + 1.0);
+      f = th; fth = 1.0;
+    } else { /* 5, :2513-2514 */
+      x = 2.0 * IOP[2] * XTemp * tan(0.5 * atan2(sqrt(XTemp * XTemp + YTemp * YTemp), -ZTemp)) / sqrt(XTemp * XTemp + YTemp * YTemp);
+      y = 2.0 * IOP[2] * YTemp * tan(0.5 * atan2(sqrt(XTemp * XTemp + YTemp * YTemp), -ZTemp)) / sqrt(XTemp * XTemp + YTemp * YTemp);
+      const double ch = cos(0.5 * th);
+      f = 2.0 * tan(0.5 * th); fth = 1.0 / (ch * ch);
+    }
+    h = f / rho;
+    hr = (fth * th_r / rho - f / (rho * rho)) / rho;
+    hz = fth * th_z / rho;
+  }
 
   /* :1357-1362 */
   const double x_bar = (x_ - IOP[0]) / APSCALE;
@@ -136,8 +198,20 @@ void bao_collinearity(const double *EOP, const double *XYZ, const double *IOP, c
   const double c = IOP[2];
   for (int q = 0; q < 9; ++q) {
     const double dXc = dcam[q][0], dYc = dcam[q][1], dZc = dcam[q][2];
-    const double dx = -c * (dXc * ZTemp - XTemp * dZc) / (ZTemp * ZTemp);
-    const double dy = -c * (dYc * ZTemp - YTemp * dZc) / (ZTemp * ZTemp);
+    double dx, dy;
+    if (model == 0) {
+      dx = -c * (dXc * ZTemp - XTemp * dZc) / (ZTemp * ZTemp);
+      dy = -c * (dYc * ZTemp - YTemp * dZc) / (ZTemp * ZTemp);
+    } else {
+      /* d(x,y)/d(Xs,Ys,Zs) = c [ h I + hr (Xs,Ys)(Xs,Ys)^T | hz (Xs,Ys) ] */
+      const double t = hr * (XTemp * dXc + YTemp * dYc) + hz * dZc;
+      dx = c * (h * dXc + XTemp * t);
+      dy = c * (h * dYc + YTemp * t);
+      if (model == 7) { /* x = c h |Xs|, y = c h |Ys| */
+        if (XTemp < 0.0) dx = -dx;
+        if (YTemp < 0.0) dy = -dy;
+      }
+    }
     J0[q] = dx / xStdDev_;
     J1[q] = dy / yStdDev_;
   }
@@ -159,10 +233,10 @@ void bao_collinearity(const double *EOP, const double *XYZ, const double *IOP, c
   /* IOP: xp, yp (through x_bar,y_bar = (obs - xp)/APSCALE and the +IOP term), c */
   J0[9] = (1.0 - ddx_dxb / APSCALE) / xStdDev_;
   J0[10] = (-ddx_dyb / APSCALE) / xStdDev_;
-  J0[11] = (-XTemp / ZTemp) / xStdDev_;
+  J0[11] = (model == 0 ? -XTemp / ZTemp : h * (model == 7 ? fabs(XTemp) : XTemp)) / xStdDev_;
   J1[9] = (-ddy_dxb / APSCALE) / yStdDev_;
   J1[10] = (1.0 - ddy_dyb / APSCALE) / yStdDev_;
-  J1[11] = (-YTemp / ZTemp) / yStdDev_;
+  J1[11] = (model == 0 ? -YTemp / ZTemp : h * (model == 7 ? fabs(YTemp) : YTemp)) / yStdDev_;
 
   /* AP: a1 a2 k1 k2 k3 p1 p2 ep1..ep9 */
   const double pw[16] = {0, 0, rr, rr2, rr3, 0, 0, rr4, rr5, rr6, rr7 + rr8, rr9, rr10, rr11, rr12, rr13};
@@ -260,7 +334,7 @@ static int prob_init(prob_t *q, const ba_dims *d, const ba_inputs *in, int need_
   q->in = in;
   const int N = q->N, S = q->S, P = q->P, C = q->C;
   if (N < 0 || S < 0 || P < 0 || C < 0) FAIL(BA_ERR_INVALID, "negative dimension");
-  if (in->model != 0) FAIL(BA_ERR_UNSUPPORTED, "model %d not implemented", in->model);
+  if (in->model < 0 || in->model > 7) FAIL(BA_ERR_UNSUPPORTED, "model %d not implemented", in->model);
   for (int n = 0; n < N; ++n) {
     if (in->obs_pt[n] < 0 || in->obs_pt[n] >= P) FAIL(BA_ERR_INVALID, "obs %d: point index %d out of range", n, in->obs_pt[n]);
     if (in->obs_sta[n] < 0 || in->obs_sta[n] >= S) FAIL(BA_ERR_INVALID, "obs %d: station index %d out of range", n, in->obs_sta[n]);
@@ -338,7 +412,7 @@ static double eval_cost(const prob_t *q, const double *eop, const double *xyz, c
     const int i = in->obs_sta[n], j = in->obs_pt[n], c = in->sta_cam[i];
     const double obs[6] = {in->obs_x[n], in->obs_y[n], in->obs_sx[n], in->obs_sy[n], in->obs_cx[n], in->obs_cy[n]};
     double r[2], rho[3];
-    bao_collinearity(eop + 6 * i, xyz + 3 * j, iop + 3 * c, ap + 16 * c, obs, r, NULL);
+    bao_projection(in->model, eop + 6 * i, xyz + 3 * j, iop + 3 * c, ap + 16 * c, obs, r, NULL);
     huber(in->huber_a, r[0] * r[0] + r[1] * r[1], rho);
     cost += 0.5 * rho[0];
     if (residuals) {
@@ -376,7 +450,7 @@ static void linearize(prob_t *q, const double *eop, const double *xyz, const dou
     const int i = in->obs_sta[n], j = in->obs_pt[n], c = in->sta_cam[i];
     const double obs[6] = {in->obs_x[n], in->obs_y[n], in->obs_sx[n], in->obs_sy[n], in->obs_cx[n], in->obs_cy[n]};
     double r[2], J[56], rho[3];
-    bao_collinearity(eop + 6 * i, xyz + 3 * j, iop + 3 * c, ap + 16 * c, obs, r, J);
+    bao_projection(in->model, eop + 6 * i, xyz + 3 * j, iop + 3 * c, ap + 16 * c, obs, r, J);
     huber(in->huber_a, r[0] * r[0] + r[1] * r[1], rho);
     cost += 0.5 * rho[0];
     const double sc = sqrt(rho[1]);
@@ -905,7 +979,7 @@ int bao_residual_jacobian_all(const ba_dims *d, const ba_inputs *in, const doubl
     if (c < 0 || c >= d->n_cam) FAIL(BA_ERR_INVALID, "station %d: camera out of range", i);
     const double obs[6] = {in->obs_x[n], in->obs_y[n], in->obs_sx[n], in->obs_sy[n], in->obs_cx[n], in->obs_cy[n]};
     double rr[2], JJ[56];
-    bao_collinearity(eop + 6 * i, xyz + 3 * j, iop + 3 * c, ap + 16 * c, obs, rr, J ? JJ : NULL);
+    bao_projection(in->model, eop + 6 * i, xyz + 3 * j, iop + 3 * c, ap + 16 * c, obs, rr, J ? JJ : NULL);
     if (r) { r[2 * (size_t)n] = rr[0]; r[2 * (size_t)n + 1] = rr[1]; }
     if (J) memcpy(J + 56 * (size_t)n, JJ, sizeof JJ);
   }

@@ -38,6 +38,11 @@ enum bao_mode {
  * J (may be NULL) is row-major 2x28: EOP 6 | XYZ 3 | IOP 3 | AP 16. */
 void bao_collinearity(const double *eop, const double *xyz, const double *iop, const double *ap,
                       const double *obs, double *r, double *J);
+/* the same with the projection of another of the reference's functors: model 0 collinearity, 1 collinearity
+ * stereographic, 2..5 fisheye equidistant / equisolid-angle / orthographic / stereographic (src/main.cpp:2133-2571),
+ * 6 collinearity orthographic (:1412-1490), 7 omnidirectional (:2700-2790) */
+void bao_projection(int model, const double *eop, const double *xyz, const double *iop, const double *ap,
+                      const double *obs, double *r, double *J);
 
 /* src/main.cpp:1057-1085.  J is diag(1/sigma). */
 void bao_constrain_point(const double *p, const double *p0, const double *sigma, double *r);

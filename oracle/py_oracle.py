@@ -60,6 +60,15 @@ def collinearity(eop, xyz, iop, ap, obs, jac=True):
     return r, J
 
 
+def projection(model, eop, xyz, iop, ap, obs, jac=True):
+    """Residual and 2x28 Jacobian of one observation under projection model 0..5."""
+    eop, xyz, iop, ap, obs = (np.ascontiguousarray(a, dtype=np.float64) for a in (eop, xyz, iop, ap, obs))
+    r = np.zeros(2)
+    J = np.zeros((2, 28)) if jac else None
+    lib().bao_projection(int(model), _dp(eop), _dp(xyz), _dp(iop), _dp(ap), _dp(obs), _dp(r), _dp(J) if jac else None)
+    return r, J
+
+
 def index_first_match(ids, keys):
     ids = np.ascontiguousarray(ids, dtype=np.int32)
     keys = np.ascontiguousarray(keys, dtype=np.int32)
@@ -151,6 +160,24 @@ def ref_collinearity_jacobian(eop, xyz, iop, ap, obs, h=1e-30):
     eop, xyz, iop, ap, obs = (np.ascontiguousarray(a, dtype=np.float64) for a in (eop, xyz, iop, ap, obs))
     J = np.zeros((2, 28))
     L.ref_collinearity_mls_jacobian(_dp(eop), _dp(xyz), _dp(iop), _dp(ap), _dp(obs), C.c_double(h), _dp(J))
+    return J
+
+
+def ref_projection(model, eop, xyz, iop, ap, obs):
+    L = ref_lib()
+    eop, xyz, iop, ap, obs = (np.ascontiguousarray(a, dtype=np.float64) for a in (eop, xyz, iop, ap, obs))
+    r = np.zeros(2)
+    if L.ref_projection(int(model), _dp(eop), _dp(xyz), _dp(iop), _dp(ap), _dp(obs), _dp(r)) != 0:
+        raise ValueError(f"no reference functor for model {model}")
+    return r
+
+
+def ref_projection_jacobian(model, eop, xyz, iop, ap, obs, h=1e-30):
+    L = ref_lib()
+    eop, xyz, iop, ap, obs = (np.ascontiguousarray(a, dtype=np.float64) for a in (eop, xyz, iop, ap, obs))
+    J = np.zeros((2, 28))
+    if L.ref_projection_jacobian(int(model), _dp(eop), _dp(xyz), _dp(iop), _dp(ap), _dp(obs), C.c_double(h), _dp(J)) != 0:
+        raise ValueError(f"no reference functor for model {model}")
     return J
 
 

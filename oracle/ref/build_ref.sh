@@ -14,10 +14,24 @@ sed -n '55p'         "$SRC" > "$TMP/slice_apscale.inc"
 sed -n '1057,1085p'  "$SRC" > "$TMP/slice_constrainPoint.inc"
 sed -n '1315,1401p'  "$SRC" > "$TMP/slice_collinearity.inc"
 sed -n '2033,2120p'  "$SRC" > "$TMP/slice_collinearityMLS.inc"
+sed -n '2133,2214p'  "$SRC" > "$TMP/slice_stereographicMLS.inc"
+sed -n '2226,2301p'  "$SRC" > "$TMP/slice_equidistantMLS.inc"
+sed -n '2312,2387p'  "$SRC" > "$TMP/slice_equisolidMLS.inc"
+sed -n '2398,2473p'  "$SRC" > "$TMP/slice_orthographicMLS.inc"
+sed -n '2484,2562p'  "$SRC" > "$TMP/slice_fisheyeStereoMLS.inc"
+sed -n '1412,1490p'  "$SRC" > "$TMP/slice_orthographic.inc"
+sed -n '2700,2790p'  "$SRC" > "$TMP/slice_omniMLS.inc"
 grep -q 'define APSCALE'                         "$TMP/slice_apscale.inc"
 grep -q 'struct constrainPoint'                  "$TMP/slice_constrainPoint.inc"
 grep -q 'struct collinearity {'                  "$TMP/slice_collinearity.inc"
 grep -q 'struct collinearityMachineLearnedSimple' "$TMP/slice_collinearityMLS.inc"
+grep -q 'struct collinearityStereographicMachineLearnedSimple' "$TMP/slice_stereographicMLS.inc"
+grep -q 'struct fisheyeEquidistantMachineLearnedSimple'        "$TMP/slice_equidistantMLS.inc"
+grep -q 'struct fisheyeEquisolidAngleMachineLearnedSimple'     "$TMP/slice_equisolidMLS.inc"
+grep -q 'struct fisheyeOrthographicMachineLearnedSimple'       "$TMP/slice_orthographicMLS.inc"
+grep -q 'struct fisheyeStereographicMachineLearnedSimple'      "$TMP/slice_fisheyeStereoMLS.inc"
+grep -q 'struct collinearityOrthographic {'                    "$TMP/slice_orthographic.inc"
+grep -q 'struct omniCollinearityMachineLearnedSimple'          "$TMP/slice_omniMLS.inc"
 mkdir -p "$OUT"
 # -ffp-contract=off: keep the reference's expression order, no fused multiply-add
 g++ -O2 -std=c++14 -ffp-contract=off -fPIC -shared -I"$TMP" "$HERE/ref_wrap.cpp" -o "$OUT/libba_ref.so"

@@ -2,23 +2,70 @@
 //
 // TEST INFRASTRUCTURE ONLY.  The functor bodies are not in this file and not in this
 // repository: build_ref.sh cuts them, at build time, out of /root/reference/src/main.cpp
-// (struct collinearity :1315-1401, struct collinearityMachineLearnedSimple :2033-2120,
-// struct constrainPoint :1057-1085, and the APSCALE define :55) into a temporary directory
+// (struct collinearity :1315-1401, struct collinearityMachineLearnedSimple :2033-2120, the five
+// other projection functors of :2133-2562, struct collinearityOrthographic :1412-1490, struct
+// omniCollinearityMachineLearnedSimple :2700-2790, struct constrainPoint :1057-1085, and the APSCALE
+// define :55) into a temporary directory
 // that is on the include path only while this file compiles.  The functors are templates
 // over the scalar type, so they are instantiated here with
 //   T = double                 -> the reference's residuals, bit for bit;
 //   T = std::complex<double>   -> complex-step derivatives d r / d p = Im r(p + i h) / h,
 //                                 exact to rounding for these analytic expressions.
-// Only standard-library types are used; nothing stands in for Ceres.
+// Only standard-library types are used; nothing stands in for Ceres.  The fisheye functors call
+// atan2, which the standard library does not define for complex arguments: the overload below
+// is its first-order continuation (value of the real parts, imaginary part from the gradient),
+// which is all a complex step of size 1e-30 can see.
 #include <cmath>
 #include <complex>
+
+inline std::complex<double> atan2(const std::complex<double> &y, const std::complex<double> &x) {
+  const double yr = y.real(), xr = x.real();
+  return std::complex<double>(std::atan2(yr, xr), (xr * y.imag() - yr * x.imag()) / (xr * xr + yr * yr));
+}
 
 #include "slice_apscale.inc"
 #include "slice_constrainPoint.inc"
 #include "slice_collinearity.inc"
 #include "slice_collinearityMLS.inc"
+#include "slice_stereographicMLS.inc"
+#include "slice_equidistantMLS.inc"
+#include "slice_equisolidMLS.inc"
+#include "slice_orthographicMLS.inc"
+#include "slice_fisheyeStereoMLS.inc"
+#include "slice_orthographic.inc"
+#include "slice_omniMLS.inc"
 
 typedef std::complex<double> cplx;
+
+// collinearityOrthographic has no correction arguments (src/main.cpp:1414): give it the 8-argument face of the others
+struct orthographicNoCorrection : collinearityOrthographic {
+  orthographicNoCorrection(double x, double y, double sx, double sy, double xp, double yp, double, double)
+      : collinearityOrthographic(x, y, sx, sy, xp, yp) {}
+};
+
+template <class F>
+static void eval_functor(const double *eop, const double *xyz, const double *iop, const double *ap,
+                         const double *obs, double *r) {
+  F f(obs[0], obs[1], obs[2], obs[3], iop[0], iop[1], obs[4], obs[5]);
+  f(eop, xyz, iop, ap, r);
+}
+
+template <class F>
+static void jacobian_functor(const double *eop, const double *xyz, const double *iop, const double *ap,
+                             const double *obs, double h, double *J) {
+  F f(obs[0], obs[1], obs[2], obs[3], iop[0], iop[1], obs[4], obs[5]);
+  cplx p[28], r[2];
+  for (int col = 0; col < 28; ++col) {
+    for (int k = 0; k < 6; ++k) p[k] = eop[k];
+    for (int k = 0; k < 3; ++k) p[6 + k] = xyz[k];
+    for (int k = 0; k < 3; ++k) p[9 + k] = iop[k];
+    for (int k = 0; k < 16; ++k) p[12 + k] = ap[k];
+    p[col] += cplx(0.0, h);
+    f(p, p + 6, p + 9, p + 12, r);
+    J[col] = r[0].imag() / h;
+    J[28 + col] = r[1].imag() / h;
+  }
+}
 
 extern "C" {
 
@@ -52,6 +99,39 @@ void ref_collinearity_mls_jacobian(const double *eop, const double *xyz, const d
     J[col] = r[0].imag() / h;
     J[28 + col] = r[1].imag() / h;
   }
+}
+
+// model: 0 collinearity, 1 collinearity stereographic, 2..5 fisheye equidistant, equisolid-angle,
+// orthographic, stereographic (the "MachineLearnedSimple" functors), 6 collinearityOrthographic (ignores the
+// corrections obs[4], obs[5]), 7 omniCollinearityMachineLearnedSimple.  Returns -1 for another model.
+int ref_projection(int model, const double *eop, const double *xyz, const double *iop, const double *ap,
+                   const double *obs, double *r) {
+  switch (model) {
+    case 0: eval_functor<collinearityMachineLearnedSimple>(eop, xyz, iop, ap, obs, r); return 0;
+    case 1: eval_functor<collinearityStereographicMachineLearnedSimple>(eop, xyz, iop, ap, obs, r); return 0;
+    case 2: eval_functor<fisheyeEquidistantMachineLearnedSimple>(eop, xyz, iop, ap, obs, r); return 0;
+    case 3: eval_functor<fisheyeEquisolidAngleMachineLearnedSimple>(eop, xyz, iop, ap, obs, r); return 0;
+    case 4: eval_functor<fisheyeOrthographicMachineLearnedSimple>(eop, xyz, iop, ap, obs, r); return 0;
+    case 5: eval_functor<fisheyeStereographicMachineLearnedSimple>(eop, xyz, iop, ap, obs, r); return 0;
+    case 6: eval_functor<orthographicNoCorrection>(eop, xyz, iop, ap, obs, r); return 0;
+    case 7: eval_functor<omniCollinearityMachineLearnedSimple>(eop, xyz, iop, ap, obs, r); return 0;
+  }
+  return -1;
+}
+
+int ref_projection_jacobian(int model, const double *eop, const double *xyz, const double *iop,
+                            const double *ap, const double *obs, double h, double *J) {
+  switch (model) {
+    case 0: jacobian_functor<collinearityMachineLearnedSimple>(eop, xyz, iop, ap, obs, h, J); return 0;
+    case 1: jacobian_functor<collinearityStereographicMachineLearnedSimple>(eop, xyz, iop, ap, obs, h, J); return 0;
+    case 2: jacobian_functor<fisheyeEquidistantMachineLearnedSimple>(eop, xyz, iop, ap, obs, h, J); return 0;
+    case 3: jacobian_functor<fisheyeEquisolidAngleMachineLearnedSimple>(eop, xyz, iop, ap, obs, h, J); return 0;
+    case 4: jacobian_functor<fisheyeOrthographicMachineLearnedSimple>(eop, xyz, iop, ap, obs, h, J); return 0;
+    case 5: jacobian_functor<fisheyeStereographicMachineLearnedSimple>(eop, xyz, iop, ap, obs, h, J); return 0;
+    case 6: jacobian_functor<orthographicNoCorrection>(eop, xyz, iop, ap, obs, h, J); return 0;
+    case 7: jacobian_functor<omniCollinearityMachineLearnedSimple>(eop, xyz, iop, ap, obs, h, J); return 0;
+  }
+  return -1;
 }
 
 void ref_constrain_point(const double *p, const double *p0, const double *sigma, double *r) {

@@ -31,3 +31,10 @@ def gpu_available():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+@pytest.fixture(scope="session")
+def projection_golden():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "projection_golden.json")) as f:
+        return json.load(f)

@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/collinearity_golden.json from the reference's own cost functors.
+"""Generates tests/golden/collinearity_golden.json and tests/golden/projection_golden.json from the
+reference's own cost functors.
 
 Run in the build container, where /root/reference is mounted and `make -C oracle` has built
 oracle/_ref/libba_ref.so out of src/main.cpp:1315-1401, :2033-2120, :1057-1085 (see
 oracle/ref/build_ref.sh).  The fixture holds numbers only: inputs, the residuals of both
 functors evaluated in double, and the 2x28 Jacobian obtained by complex-step differentiation
 of the reference functor (std::complex<double> instantiation, h = 1e-30).
+
+projection_golden.json holds the same for the seven other projection functors (src/main.cpp:2133-2562:
+collinearity stereographic and the four fisheye models; :1412-1490 collinearity orthographic; :2700-2790
+omnidirectional), at off-axis angles up to 69 degrees.
 
     python tests/golden/make_golden.py
 """
@@ -64,6 +69,76 @@ def make_case(rng, ap_kind, resid_kind, with_corr):
     return eop, xyz, iop, ap, obs
 
 
+MODEL_NAMES = {1: "collinearityStereographicMachineLearnedSimple :2133-2214",
+               2: "fisheyeEquidistantMachineLearnedSimple :2226-2301",
+               3: "fisheyeEquisolidAngleMachineLearnedSimple :2312-2387",
+               4: "fisheyeOrthographicMachineLearnedSimple :2398-2473",
+               5: "fisheyeStereographicMachineLearnedSimple :2484-2562",
+               6: "collinearityOrthographic :1412-1490 (no correction arguments)",
+               7: "omniCollinearityMachineLearnedSimple :2700-2790"}
+
+
+def make_projection_case(rng, model, ap_kind, resid_kind, with_corr):
+    eop = np.array([rng.uniform(-0.4, 0.4), rng.uniform(-0.4, 0.4), rng.uniform(-np.pi, np.pi),
+                    rng.uniform(-5e3, 5e3), rng.uniform(-5e3, 5e3), rng.uniform(8e3, 12e3)])
+    R = rot(*eop[:3])
+    depth, off_axis, azimuth = rng.uniform(8e3, 12e3), rng.uniform(0.01, 1.2), rng.uniform(0, 2 * np.pi)
+    cam = np.array([depth * np.tan(off_axis) * np.cos(azimuth), depth * np.tan(off_axis) * np.sin(azimuth), -depth])
+    xyz = eop[3:] + R.T @ cam
+    # orthographic: image = c x object coordinates, so c is a scale of order 0.1
+    iop = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(0.05, 0.1) if model == 6 else rng.uniform(800, 1500)])
+    ap = np.zeros(16)
+    if ap_kind in ("brown", "all"):
+        ap[:7] = [rng.normal(0, 1e-2), rng.normal(0, 1e-2), rng.normal(0, 0.5), rng.normal(0, 2e-2),
+                  rng.normal(0, 5e-4), rng.normal(0, 5e-2), rng.normal(0, 5e-2)]
+    if ap_kind == "all":
+        ap[7:] = rng.normal(0, 1.0, 9) * 10.0 ** -np.arange(5, 14)
+    sx, sy = rng.uniform(0.2, 1.0, 2)
+    corr = rng.normal(0, 0.7, 2) if (with_corr and model != 6) else np.zeros(2)
+    obs = np.array([0.0, 0.0, sx, sy, corr[0], corr[1]])
+    for _ in range(12):
+        r = po.ref_projection(model, eop, xyz, iop, ap, obs)
+        obs[0] += r[0] * sx
+        obs[1] += r[1] * sy
+    if resid_kind == "small":
+        t, m = rng.uniform(0, 2 * np.pi), rng.uniform(0.05, 0.7)
+        obs[0] += m * np.cos(t) * sx
+        obs[1] += m * np.sin(t) * sy
+    else:
+        obs[0] += rng.choice([-1, 1]) * rng.uniform(2, 20) * sx
+        obs[1] += rng.choice([-1, 1]) * rng.uniform(2, 20) * sy
+    return eop, xyz, iop, ap, obs
+
+
+def main_projection():
+    rng = np.random.default_rng(SEED + 1)
+    cases = []
+    for model in sorted(MODEL_NAMES):
+        for ap_kind in ("zero", "brown", "all"):
+            for resid_kind in ("small", "large"):
+                for i in range(12):
+                    eop, xyz, iop, ap, obs = make_projection_case(rng, model, ap_kind, resid_kind, bool(i % 2))
+                    cases.append({
+                        "model": model, "ap_kind": ap_kind, "resid_kind": resid_kind,
+                        "eop": eop.tolist(), "xyz": xyz.tolist(), "iop": iop.tolist(), "ap": ap.tolist(),
+                        "obs": obs.tolist(),
+                        "r": po.ref_projection(model, eop, xyz, iop, ap, obs).tolist(),
+                        "J": po.ref_projection_jacobian(model, eop, xyz, iop, ap, obs).reshape(-1).tolist(),
+                    })
+    out = {
+        "generator": "tests/golden/make_golden.py",
+        "source": "reference functors src/main.cpp:2133-2562, 1412-1490, 2700-2790 compiled by oracle/ref/build_ref.sh",
+        "models": {str(k): v for k, v in MODEL_NAMES.items()},
+        "jacobian_method": "complex step, std::complex<double>, h=1e-30 (atan2 continued to first order)",
+        "seed": SEED + 1,
+        "cases": cases,
+    }
+    path = os.path.join(ROOT, "tests", "golden", "projection_golden.json")
+    with open(path, "w") as f:
+        json.dump(out, f)
+    print(f"wrote {path}: {len(cases)} cases")
+
+
 def main():
     if po.ref_lib() is None:
         sys.exit("oracle/_ref/libba_ref.so is missing: run `make -C oracle` where /root/reference exists")
@@ -109,3 +184,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    main_projection()

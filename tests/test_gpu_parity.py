@@ -168,8 +168,10 @@ def test_covariance_after_the_solve(which):
     elif which == "three_cameras":
         net = host.synth(n_cam=3, n_sta=12, n_pts=150, rays_per_point=6, ap_free_mask=host.AP_K1K2P1P2, seed=5).net
     else:
+        # every 8th point is a control point: with two of 80 the datum is so weak (station sigmas of kilometres)
+        # that the comparison measures the conditioning of the network, not the code
         net = host.synth(n_cam=1, n_sta=9, n_pts=80, rays_per_point=5, ap_free_mask=0, iop_free_mask=0, seed=7,
-                         outlier_fraction=0.1).net
+                         outlier_fraction=0.1, control_every=8).net
     with solver.Problem(net) as P:
         P.set_parameters()
         P.solve_resident(options(capi.SOLVER_DENSE_SCHUR))
@@ -290,7 +292,7 @@ def test_error_behaviour():
     with pytest.raises(solver.BaError, match="standard deviation"):
         solver.Problem(modified(net, obs_sx=np.zeros(net.n_obs)))
     with pytest.raises(solver.BaError, match="model"):
-        solver.Problem(capi.Network(**{k: getattr(net, k) for k in __import__("util").FIELDS}, model=3))
+        solver.Problem(capi.Network(**{k: getattr(net, k) for k in __import__("util").FIELDS}, model=8))
     with solver.Problem(net) as P:
         with pytest.raises(solver.BaError, match="ba_set_parameters"):
             P.solve_resident(options(capi.SOLVER_DENSE_SCHUR))

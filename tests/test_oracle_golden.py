@@ -66,3 +66,57 @@ def test_oracle_equals_reference_functor_on_fresh_inputs():
         Jr = po.ref_collinearity_jacobian(eop, xyz, iop, ap, obs)
         nz = Jr != 0
         assert np.max(np.abs(J[nz] - Jr[nz]) / np.abs(Jr[nz])) < 1e-10
+
+
+# ---- the other projection functors (src/main.cpp:2133-2562, :1412-1490, :2700-2790), models 1..7 of ba_inputs.model
+
+def test_projection_models_residuals_bit_exact(projection_golden):
+    seen = set()
+    for c in projection_golden["cases"]:
+        r, _ = po.projection(c["model"], c["eop"], c["xyz"], c["iop"], c["ap"], c["obs"], jac=False)
+        assert r.tolist() == c["r"], c["model"]
+        seen.add(c["model"])
+    assert seen == {1, 2, 3, 4, 5, 6, 7}
+
+
+def test_projection_models_jacobian_matches_complex_step(projection_golden):
+    worst = {}
+    for c in projection_golden["cases"]:
+        _, J = po.projection(c["model"], c["eop"], c["xyz"], c["iop"], c["ap"], c["obs"])
+        Jg = np.array(c["J"]).reshape(2, 28)
+        assert np.array_equal(Jg == 0.0, J == 0.0)
+        nz = Jg != 0.0
+        # relative to the largest entry of the same parameter block: the kappa column of a point near the axis
+        # is a difference of two products and carries their rounding
+        scale = np.empty_like(Jg)
+        for lo, hi in ((0, 3), (3, 6), (6, 9), (9, 12), (12, 28)):
+            scale[:, lo:hi] = np.max(np.abs(Jg[:, lo:hi]), axis=1, keepdims=True)
+        worst[c["model"]] = max(worst.get(c["model"], 0.0), np.max(np.abs(J[nz] - Jg[nz]) / scale[nz]))
+    assert max(worst.values()) < 1e-11, worst  # tolerance: analytic derivative vs complex step, fp64
+
+
+def test_model_zero_of_the_general_function_is_collinearity(golden):
+    for c in golden["collinearity"][:64]:
+        r, J = po.projection(0, c["eop"], c["xyz"], c["iop"], c["ap"], c["obs"])
+        r0, J0 = po.collinearity(c["eop"], c["xyz"], c["iop"], c["ap"], c["obs"])
+        assert r.tolist() == r0.tolist() and np.array_equal(J, J0)
+
+
+@pytest.mark.skipif(po.ref_lib() is None, reason="reference functors not built (no /root/reference here)")
+@pytest.mark.parametrize("model", [1, 2, 3, 4, 5, 6, 7])
+def test_projection_oracle_equals_reference_functor_on_fresh_inputs(model):
+    rng = np.random.default_rng(70 + model)
+    for _ in range(100):
+        eop = np.concatenate([rng.uniform(-0.5, 0.5, 2), rng.uniform(-3, 3, 1), rng.normal(0, 3e3, 2), [rng.uniform(8e3, 1.2e4)]])
+        xyz = rng.normal(0, 6e3, 3)
+        xyz[2] = rng.uniform(-1e3, 1e3)
+        iop = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(0.05, 0.1) if model == 6 else rng.uniform(800, 1500)])
+        ap = rng.normal(0, 1, 16) * 10.0 ** -np.concatenate([[2, 2, 0.5, 2, 3, 1.5, 1.5], np.arange(5, 14)])
+        obs = np.array([rng.uniform(-1e3, 1e3), rng.uniform(-1e3, 1e3), 0.5, 0.7, rng.normal(), rng.normal()])
+        if model == 6:
+            obs[4:] = 0.0  # collinearityOrthographic takes no corrections (src/main.cpp:1414)
+        r, J = po.projection(model, eop, xyz, iop, ap, obs)
+        assert r.tolist() == po.ref_projection(model, eop, xyz, iop, ap, obs).tolist()
+        Jr = po.ref_projection_jacobian(model, eop, xyz, iop, ap, obs)
+        nz = Jr != 0
+        assert np.max(np.abs(J[nz] - Jr[nz]) / np.abs(Jr[nz])) < 1e-9

@@ -18,7 +18,7 @@ def modified(net, **kw):
     d = {k: getattr(net, k) for k in FIELDS}
     d.update(kw)
     return capi.Network(huber_a=kw.pop("huber_a", net.huber_a) if "huber_a" in kw else net.huber_a,
-                        **{k: v for k, v in d.items() if k != "huber_a"})
+                        model=d.pop("model", net.model), **{k: v for k, v in d.items() if k != "huber_a"})
 
 
 def assert_solve_parity(gpu_out, ora_out, cost_rtol=RTOL, par_rtol=RTOL):
