@@ -336,7 +336,6 @@ k_bsr_spmv(BsrCgArgs a, int parity) {
   __shared__ double lds_qc[SPMV_WAVES][80];
   if (a.scal[8 + parity] != 0.0) return;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int g = lane >> 3, r = lane & 7;
   double pq = 0.0;
   double tcam0 = 0.0, tcam1 = 0.0;  // camera-row partials of this lane: columns lane and lane + 64
   const double *pcam = a.p + 6 * (int64_t)a.S;

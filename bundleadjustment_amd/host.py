@@ -21,6 +21,32 @@ class SynthConfig(C.Structure):
     ]
 
 
+class Stats(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("median", "mean", "stdev", "min", "max", "rmse")]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class Report(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("quadratic_error", "redundancy", "aposteriori_variance", "aposteriori_stddev",
+                                          "aic", "bic", "ic_n", "ic_k", "vtpv", "approx_dof", "vtpv_image")] + \
+               [("n_frames", C.c_int32), ("n_targets", C.c_int32)] + \
+               [(k, C.c_double) for k in ("res_x_mean", "res_x_min", "res_x_max", "res_y_mean", "res_y_min", "res_y_max",
+                                          "rmse_x", "rmse_y", "rmse_xy")] + \
+               [("bins", C.c_int32), ("bin_width", C.c_int64)]
+
+
+class BinStats(C.Structure):
+    _fields_ = [("count", C.c_int64), ("obs", Stats), ("res", Stats), ("dist", Stats)]
+
+
+class Qc(C.Structure):
+    _fields_ = [("n_truth", C.c_int32), ("n_estimated", C.c_int32), ("n_matches", C.c_int32),
+                ("mean", C.c_double * 3), ("min", C.c_double * 3), ("max", C.c_double * 3), ("rmse", C.c_double * 3),
+                ("rmse_average", C.c_double)]
+
+
 # AP bit positions: a1 a2 k1 k2 k3 p1 p2 ep1..ep9 (src/main.cpp:3588-3604)
 AP_BITS = {"a1": 0, "a2": 1, "k1": 2, "k2": 3, "k3": 4, "p1": 5, "p2": 6,
            **{f"ep{i}": 6 + i for i in range(1, 10)}}
@@ -75,6 +101,26 @@ def lib():
         L.ba_net_write_results.argtypes = [C.c_void_p, C.c_char_p, c_double_p]
         L.ba_net_set_variances.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]
         L.ba_net_num_ap_correction.argtypes = [C.c_void_p]
+        L.ba_net_set_model.argtypes = [C.c_void_p, C.c_int32]
+        for f in ("ba_stat_median", "ba_stat_stddev"):
+            getattr(L, f).restype = C.c_double
+            getattr(L, f).argtypes = [c_double_p, C.c_int64]
+        L.ba_stat_all.restype = None
+        L.ba_stat_all.argtypes = [c_double_p, C.c_int64, C.POINTER(Stats)]
+        for f in ("ba_aic", "ba_bic"):
+            getattr(L, f).restype = C.c_double
+            getattr(L, f).argtypes = [C.c_double] * 3
+        L.ba_incidence_angle.restype = C.c_double
+        L.ba_incidence_angle.argtypes = [c_double_p, c_double_p]
+        for f in ("ba_refraction_angle", "ba_radial_distance"):
+            getattr(L, f).restype = C.c_double
+            getattr(L, f).argtypes = [C.c_double, C.c_double, c_double_p, c_double_p]
+        L.ba_net_write_angles.argtypes = [C.c_void_p, C.c_char_p]
+        L.ba_net_report.argtypes = [C.c_void_p, C.POINTER(BaSummary), c_double_p, C.c_int64, C.c_int32, C.POINTER(Report),
+                                    C.POINTER(BinStats)]
+        L.ba_net_print_report.argtypes = [C.c_void_p, C.POINTER(Report), C.POINTER(BinStats), C.c_char_p]
+        L.ba_net_qc.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Qc)]
+        L.ba_net_print_qc.argtypes = [C.POINTER(Qc), C.c_char_p, C.c_char_p]
         L.ba_sigma0.restype = C.c_double
         L.ba_sigma0.argtypes = [C.POINTER(BaSummary), C.c_int32, C.c_int32, c_double_p]
         _lib = L
@@ -168,6 +214,36 @@ class HostNetwork:
         """Variances for the sigma columns of the result files (the output of Problem.covariance()); None = default."""
         arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (var_eop, var_xyz, var_iop, var_ap)]
         _check(lib().ba_net_set_variances(self._h, *[None if a is None else a.ctypes.data_as(c_double_p) for a in arrs]))
+
+    def write_angles(self, directory):
+        """angles.jck of src/main.cpp:4756-4782 from the parameters held by the network."""
+        _check(lib().ba_net_write_angles(self._h, directory.encode()))
+
+    def report(self, summary, residuals, bins=30, path=None, text=False):
+        """The post-solve figures of src/main.cpp:4905-5137, 6982-6984.  summary: BaSummary or its dict;
+        residuals: all rows of evaluate(apply_loss=True).  Returns (Report, [BinStats]); text=True also writes the
+        reference's console lines to `path` (None: stdout)."""
+        sm = summary
+        if isinstance(summary, dict):
+            sm = BaSummary()
+            for k, v in summary.items():
+                if hasattr(sm, k):
+                    setattr(sm, k, v)
+        r = np.ascontiguousarray(residuals, dtype=np.float64)
+        rep = Report()
+        bs = (BinStats * max(bins, 1))()
+        _check(lib().ba_net_report(self._h, C.byref(sm), r.ctypes.data_as(c_double_p), r.size, bins, C.byref(rep), bs))
+        if text:
+            _check(lib().ba_net_print_report(self._h, C.byref(rep), bs, None if path is None else path.encode()))
+        return rep, list(bs)[:bins]
+
+    def qc(self, truth_path, path=None, text=False):
+        """Object-space error against a truth .xyz file (src/main.cpp:7242-7346)."""
+        q = Qc()
+        _check(lib().ba_net_qc(self._h, truth_path.encode(), C.byref(q)))
+        if text:
+            _check(lib().ba_net_print_qc(C.byref(q), truth_path.encode(), None if path is None else path.encode()))
+        return q
 
     def num_ap_correction(self):
         return lib().ba_net_num_ap_correction(self._h)

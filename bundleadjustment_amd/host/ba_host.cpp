@@ -8,7 +8,11 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <numeric>
 #include <random>
+#include <sstream>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -688,6 +692,309 @@ int ba_net_write_results(const ba_network *n, const char *dir, const double *res
     }
     fclose(fout);
   }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// reporting: statistics helpers, angles.jck, the console report after the solve, QC against a truth file
+// ---------------------------------------------------------------------------------------------
+double ba_stat_median(const double *v, int64_t n) {  // calcMedian, src/main.cpp:791-808
+  if (!v || n <= 0) return 0.0;
+  std::vector<double> s(v, v + n);
+  std::sort(s.begin(), s.end());
+  const size_t size = s.size();
+  return (size % 2 == 0) ? (s[size / 2 - 1] + s[size / 2]) / 2 : s[size / 2];
+}
+
+double ba_stat_stddev(const double *v, int64_t n) {  // calcStdDev, src/main.cpp:811-823 (divides by n)
+  if (!v || n <= 0) return 0.0;
+  double sum = 0.0;
+  for (int64_t i = 0; i < n; ++i) sum += v[i];
+  const double mean = sum / n;
+  double sq = 0.0;
+  for (int64_t i = 0; i < n; ++i) sq += (v[i] - mean) * (v[i] - mean);
+  return std::sqrt(sq / n);
+}
+
+void ba_stat_all(const double *v, int64_t n, ba_stats *out) {  // calcStatistics, src/main.cpp:884-920
+  if (!out) return;
+  std::memset(out, 0, sizeof *out);
+  if (!v || n <= 0) return;
+  out->median = ba_stat_median(v, n);
+  double sum = 0.0;
+  for (int64_t i = 0; i < n; ++i) sum += v[i];
+  out->mean = sum / n;
+  out->stdev = ba_stat_stddev(v, n);
+  out->max = *std::max_element(v, v + n);
+  out->min = *std::min_element(v, v + n);
+  double r = 0.0;
+  for (int64_t i = 0; i < n; ++i) r += v[i] * v[i];
+  out->rmse = std::sqrt(r / double(n));
+}
+
+double ba_aic(double num_obs, double mse, double num_unk) { return num_obs * std::log(mse) + 2.0 * num_unk; }  // :1008-1012
+double ba_bic(double num_obs, double mse, double num_unk) { return num_obs * std::log(mse) + num_unk * std::log(num_obs); }  // :1015-1019
+
+double ba_incidence_angle(const double *eop, const double *xyz) {  // src/main.cpp:923-945
+  double R[9];
+  rotation(eop, R);
+  const double dX = xyz[0] - eop[3], dY = xyz[1] - eop[4], dZ = xyz[2] - eop[5];
+  const double Xs = R[0] * dX + R[1] * dY + R[2] * dZ, Ys = R[3] * dX + R[4] * dY + R[5] * dZ;
+  const double Zs = R[6] * dX + R[7] * dY + R[8] * dZ;
+  return std::atan2(std::sqrt(Xs * Xs + Ys * Ys), -Zs);
+}
+
+static void corrected_image_point(double x, double y, const double *iop, const double *ap, double &xc, double &yc) {
+  double dx, dy;  // src/main.cpp:950-963
+  distortion(ap, (x - iop[0]) / kApScale, (y - iop[1]) / kApScale, dx, dy);
+  xc = x - iop[0] - dx;
+  yc = y - iop[1] - dy;
+}
+
+double ba_refraction_angle(double x, double y, const double *iop, const double *ap) {  // src/main.cpp:947-966
+  double xc, yc;
+  corrected_image_point(x, y, iop, ap, xc, yc);
+  return std::atan2(std::sqrt(xc * xc + yc * yc), iop[2]);
+}
+
+double ba_radial_distance(double x, double y, const double *iop, const double *ap) {  // src/main.cpp:968-987
+  double xc, yc;
+  corrected_image_point(x, y, iop, ap, xc, yc);
+  return std::sqrt(xc * xc + yc * yc);
+}
+
+int ba_net_write_angles(const ba_network *n, const char *dir) {  // src/main.cpp:4756-4782
+  if (!n || !dir) return fail(BA_ERR_INVALID, "ba_net_write_angles: null argument");
+  FILE *fout = fopen((std::string(dir) + "/angles.jck").c_str(), "w");
+  if (!fout) return fail(BA_ERR_INVALID, "cannot write into %s", dir);
+  for (size_t i = 0; i < n->imageTarget.size(); ++i) {
+    const int32_t pose = n->indexPose[i], cam = n->staSensor[pose];
+    const double alpha = ba_incidence_angle(&n->EOP[6 * (size_t)pose], &n->XYZ[3 * (size_t)n->indexPoint[i]]);
+    const double beta = ba_refraction_angle(n->imageX[i], n->imageY[i], &n->IOP[3 * (size_t)cam], &n->AP[16 * (size_t)cam]);
+    fprintf(fout, "%i %i %i %.6lf %.6lf\n", n->imageTarget[i], n->imageStation[i], n->eopCamera[pose], beta * 180.0 / kPi,
+            alpha * 180.0 / kPi);
+  }
+  fclose(fout);
+  return 0;
+}
+
+int ba_net_report(const ba_network *n, const ba_summary *sm, const double *residuals, int64_t n_residuals, int32_t bins,
+                  ba_report *out, ba_bin_stats *bin_stats) {
+  if (!n || !sm || !residuals || !out) return fail(BA_ERR_INVALID, "ba_net_report: null argument");
+  const size_t N = n->imageX.size(), P = n->xyzTarget.size();
+  if (n_residuals < (int64_t)(2 * N)) return fail(BA_ERR_INVALID, "ba_net_report: %lld residuals for %zu image points", (long long)n_residuals, N);
+  if (bins < 0 || (bins > 0 && !bin_stats)) return fail(BA_ERR_INVALID, "ba_net_report: bins without an output array");
+  std::memset(out, 0, sizeof *out);
+  const int32_t nap = ba_net_num_ap_correction(n);
+  // ---- src/main.cpp:4905-4915
+  out->quadratic_error = 2 * sm->final_cost;
+  out->redundancy = sm->num_residuals_reduced - sm->num_parameters_reduced - 3 * (double)P + 7 + nap;
+  out->aposteriori_variance = 2 * sm->final_cost / out->redundancy;
+  out->aposteriori_stddev = std::sqrt(out->aposteriori_variance);
+  out->ic_n = (double)(sm->num_residuals_reduced - 3 * (int64_t)P);
+  out->ic_k = (double)(sm->num_parameters_reduced - nap);
+  out->aic = ba_aic(out->ic_n, 2 * sm->final_cost, out->ic_k);
+  out->bic = ba_bic(out->ic_n, 2 * sm->final_cost, out->ic_k);
+  // ---- :4919-4942; frames and targets are the distinct ids of the .pho file (:3097-3107)
+  std::vector<int32_t> frames(n->imageStation), targets(n->imageTarget);
+  std::sort(frames.begin(), frames.end());
+  frames.erase(std::unique(frames.begin(), frames.end()), frames.end());
+  std::sort(targets.begin(), targets.end());
+  targets.erase(std::unique(targets.begin(), targets.end()), targets.end());
+  out->n_frames = (int32_t)frames.size();
+  out->n_targets = (int32_t)targets.size();
+  double vtpv = 0.0;
+  for (int64_t i = 0; i < n_residuals; ++i) vtpv += residuals[i] * residuals[i];
+  out->vtpv = vtpv;
+  out->approx_dof = (double)(2 * (int64_t)N - 6 * (int64_t)frames.size() - 3 * (int64_t)targets.size() + 7);
+  double vi = 0.0;
+  for (size_t i = 0; i < 2 * N; ++i) vi += residuals[i] * residuals[i];
+  out->vtpv_image = vi;
+  // ---- :6952-6984 image residuals in image units, reprojection errors
+  double sx = 0.0, sy = 0.0, mx = 0.0, my = 0.0;
+  out->res_x_min = out->res_y_min = N ? 1e300 : 0.0;
+  out->res_x_max = out->res_y_max = N ? -1e300 : 0.0;
+  std::vector<double> vx(N), vy(N);
+  for (size_t i = 0; i < N; ++i) {
+    vx[i] = residuals[2 * i] * n->imageXStdDev[i];
+    vy[i] = residuals[2 * i + 1] * n->imageYStdDev[i];
+    sx += vx[i] * vx[i];
+    sy += vy[i] * vy[i];
+    mx += vx[i];
+    my += vy[i];
+    out->res_x_min = std::min(out->res_x_min, vx[i]); out->res_x_max = std::max(out->res_x_max, vx[i]);
+    out->res_y_min = std::min(out->res_y_min, vy[i]); out->res_y_max = std::max(out->res_y_max, vy[i]);
+  }
+  if (N) {
+    out->res_x_mean = mx / N;
+    out->res_y_mean = my / N;
+    out->rmse_x = std::sqrt(sx / N);
+    out->rmse_y = std::sqrt(sy / N);
+    out->rmse_xy = std::sqrt((sx + sy) / (2 * N));
+  }
+  // ---- :4960-5090 quantile bins over the corrected radial distance (stable order of equal distances, :990-1005)
+  out->bins = bins;
+  if (bins > 0) {
+    std::vector<double> dist(N);
+    for (size_t i = 0; i < N; ++i) {
+      const int32_t cam = n->staSensor[n->indexPose[i]];
+      dist[i] = ba_radial_distance(n->imageX[i], n->imageY[i], &n->IOP[3 * (size_t)cam], &n->AP[16 * (size_t)cam]);
+    }
+    std::vector<int> idx(N);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&dist](size_t a, size_t b) { return dist[a] < dist[b]; });
+    const int64_t width = (int64_t)std::ceil(double(N) / double(bins));
+    out->bin_width = width;
+    size_t l = 0;
+    std::vector<double> tImg, tRes, tDist;
+    for (int b = 0; b < bins; ++b) {
+      tImg.clear(); tRes.clear(); tDist.clear();
+      for (int64_t m = 0; m < width && l < N; ++m, ++l) {
+        tImg.push_back(n->imageX[idx[l]]);
+        tImg.push_back(n->imageY[idx[l]]);
+        tRes.push_back(vx[idx[l]]);
+        tRes.push_back(vy[idx[l]]);
+        tDist.push_back(dist[idx[l]]);
+      }
+      bin_stats[b].count = (int64_t)tDist.size();
+      ba_stat_all(tImg.data(), (int64_t)tImg.size(), &bin_stats[b].obs);
+      ba_stat_all(tRes.data(), (int64_t)tRes.size(), &bin_stats[b].res);
+      ba_stat_all(tDist.data(), (int64_t)tDist.size(), &bin_stats[b].dist);
+    }
+  }
+  return 0;
+}
+
+int ba_net_print_report(const ba_network *n, const ba_report *r, const ba_bin_stats *bs, const char *path) {
+  if (!n || !r) return fail(BA_ERR_INVALID, "ba_net_print_report: null argument");
+  std::ostringstream o;  // the reference prints with std::cout in its default format (6 significant digits)
+  const double dof = r->approx_dof;
+  o << "  Estimating A Posterior Variance Factor..." << std::endl;
+  o << "     *CERES GLOBAL A Posteriori Variance (using the robust weights): " << std::endl;  // src/main.cpp:4905-4915
+  o << "        *Ceres Quadratic Error: " << r->quadratic_error << std::endl;
+  o << "        *Ceres Redundancy: " << r->redundancy << std::endl;
+  o << "        *Ceres A Posteriori Variance: " << r->aposteriori_variance << std::endl;
+  o << "        *Ceres A Posteriori Std Dev: " << r->aposteriori_stddev << std::endl;
+  o << "        *AIC n: " << r->aic << ". n = " << (int64_t)r->ic_n << ", k = " << (int64_t)r->ic_k << std::endl;
+  o << "        *BIC n: " << r->bic << ". n = " << (int64_t)r->ic_n << ", k = " << (int64_t)r->ic_k << std::endl;
+  o << "     MANUAL GLOBAL A Posteriori Variance (assumes normal weights): " << std::endl;  // :4925-4931
+  o << "        vTPv: " << r->vtpv << std::endl;
+  o << "        Approximate dof (2*img - 6*EOP - 3*XYZ + 7datum): " << (int64_t)dof << std::endl;
+  o << "        vTPv/dof: " << r->vtpv / dof << std::endl;
+  o << "        sqrt(vTPv/dof): " << std::sqrt(r->vtpv / dof) << std::endl;
+  o << "        vTPv/ceresRedundancy: " << r->vtpv / r->redundancy << std::endl;
+  o << "        sqrt(vTPv/ceresRedundancy): " << std::sqrt(r->vtpv / r->redundancy) << std::endl;
+  o << "     Image A Posteriori Variance: " << std::endl;  // :4935-4940
+  o << "        vTPv: " << r->vtpv_image << std::endl;
+  o << "        Approx dof: " << (int64_t)dof << std::endl;
+  o << "        Approx a posteriori variance image (used for scaling Cx = apostVar*Qx): " << r->vtpv_image / dof << std::endl;
+  o << "        Approx a posteriori std dev image: " << std::sqrt(r->vtpv_image / dof) << std::endl;
+  if (r->bins > 0 && bs) {  // :4962-5137
+    o << "  Computing quantile residual statistics by dividing into " << r->bins << " bins..." << std::endl;
+    o << "    binWidth: " << r->bin_width << " points" << std::endl;
+    o << "    Min distanc: ";
+    for (int b = 0; b < r->bins; ++b) o << bs[b].dist.min << "\t";
+    o << std::endl;
+    o << "    Median dist: ";
+    for (int b = 0; b < r->bins; ++b) o << bs[b].dist.median << "\t";
+    o << std::endl;
+    o << "    Max distanc: ";
+    for (int b = 0; b < r->bins; ++b) o << bs[b].dist.max << "\t";
+    o << std::endl;
+    std::ios state(nullptr);
+    state.copyfmt(o);
+    o << std::setprecision(2) << std::fixed;
+    o << "    Mean residuals  : ";
+    for (int b = 0; b < r->bins; ++b) o << bs[b].res.mean << "\t";
+    o << std::endl;
+    o << "    StdDev residuals: ";
+    for (int b = 0; b < r->bins; ++b) o << bs[b].res.stdev << "\t";
+    o << std::endl;
+    o << "    RMSE residuals  : ";
+    for (int b = 0; b < r->bins; ++b) o << bs[b].res.rmse << "\t";
+    o << std::endl;
+    o.copyfmt(state);
+  }
+  // :6982-6984
+  o << "  Residual x mean (range): " << r->res_x_mean << " (" << r->res_x_min << " to " << r->res_x_max << ")" << std::endl;
+  o << "  Residual y mean (range): " << r->res_y_mean << " (" << r->res_y_min << " to " << r->res_y_max << ")" << std::endl;
+  o << "  Reprojection errors (RMSE in x, y, and average): " << r->rmse_x << ", " << r->rmse_y << " --> " << r->rmse_xy << std::endl;
+  const std::string text = o.str();
+  if (!path) {
+    fputs(text.c_str(), stdout);
+    return 0;
+  }
+  FILE *f = fopen(path, "w");
+  if (!f) return fail(BA_ERR_INVALID, "cannot write %s", path);
+  fputs(text.c_str(), f);
+  fclose(f);
+  return 0;
+}
+
+int ba_net_qc(const ba_network *n, const char *truth_path, ba_qc *out) {  // src/main.cpp:7242-7346
+  if (!n || !truth_path || !out) return fail(BA_ERR_INVALID, "ba_net_qc: null argument");
+  std::memset(out, 0, sizeof *out);
+  std::ifstream inp(truth_path);
+  if (!inp.is_open()) return fail(BA_ERR_INVALID, "cannot open %s", truth_path);
+  std::vector<double> id;  // the reference keeps the ids as doubles (:7249)
+  std::vector<double> xyz;
+  while (true) {  // seven columns per row; the row read at end of file is dropped again (:7251-7271)
+    int c0 = 0;
+    double c[6] = {0, 0, 0, 0, 0, 0};
+    inp >> c0 >> c[0] >> c[1] >> c[2] >> c[3] >> c[4] >> c[5];
+    id.push_back(c0);
+    xyz.insert(xyz.end(), c, c + 3);
+    if (inp.eof()) break;
+    if (inp.fail()) return fail(BA_ERR_INVALID, "%s: malformed token near record %zu", truth_path, id.size());
+  }
+  id.pop_back();
+  xyz.resize(xyz.size() - 3);
+  out->n_truth = (int32_t)id.size();
+  out->n_estimated = (int32_t)n->xyzTarget.size();
+  double mean[3] = {0, 0, 0}, rmse[3] = {0, 0, 0}, mn[3] = {1E10, 1E10, 1E10}, mx[3] = {-1E10, -1E10, -1E10};
+  std::unordered_map<int32_t, int32_t> first;  // first estimated point with an id, as the inner loop's break finds it
+  for (int32_t j = (int32_t)n->xyzTarget.size() - 1; j >= 0; --j) first[n->xyzTarget[j]] = j;
+  int matches = 0;
+  for (size_t i = 0; i < id.size(); ++i) {
+    const auto it = first.find((int32_t)id[i]);
+    if (it == first.end()) continue;
+    for (int k = 0; k < 3; ++k) {
+      const double diff = n->XYZ[3 * (size_t)it->second + k] - xyz[3 * i + k];
+      mean[k] += diff;
+      rmse[k] += std::pow(diff, 2.0);
+      if (diff < mn[k]) mn[k] = diff;
+      if (diff > mx[k]) mx[k] = diff;
+    }
+    ++matches;
+  }
+  out->n_matches = matches;
+  for (int k = 0; k < 3; ++k) {
+    out->mean[k] = mean[k] / matches;
+    out->min[k] = mn[k];
+    out->max[k] = mx[k];
+    out->rmse[k] = std::sqrt(rmse[k] / matches);
+  }
+  out->rmse_average = std::sqrt((out->rmse[0] * out->rmse[0] + out->rmse[1] * out->rmse[1] + out->rmse[2] * out->rmse[2]) / 3.0);
+  return 0;
+}
+
+int ba_net_print_qc(const ba_qc *q, const char *truth_path, const char *path) {  // src/main.cpp:7246, 7274-7344
+  if (!q) return fail(BA_ERR_INVALID, "ba_net_print_qc: null argument");
+  std::ostringstream o;
+  o << "  Ground truth filename: " << (truth_path ? truth_path : "") << std::endl;
+  o << "  Number of XYZ Ground Truth Read: " << q->n_truth << std::endl;
+  o << "  Number of XYZ estimated        : " << q->n_estimated << std::endl;
+  o << "  Number of matching points used : " << q->n_matches << std::endl;
+  const char *axis[3] = {"X", "Y", "Z"};
+  for (int k = 0; k < 3; ++k)
+    o << "    Mean " << axis[k] << " (range): " << q->mean[k] << " (" << q->min[k] << " to " << q->max[k] << ")" << std::endl;
+  o << "    Direct method - RMSE X, Y, Z, Average: " << q->rmse[0] << ", " << q->rmse[1] << ", " << q->rmse[2] << " --> "
+    << q->rmse_average << std::endl;
+  const std::string text = o.str();
+  FILE *f = path ? fopen(path, "w") : stdout;
+  if (!f) return fail(BA_ERR_INVALID, "cannot write %s", path);
+  fputs(text.c_str(), f);
+  if (path) fclose(f);
   return 0;
 }
 

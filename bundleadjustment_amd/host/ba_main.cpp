@@ -16,12 +16,16 @@ static void usage() {
   fprintf(stderr,
           "usage: ba_main <file.pho> <file.eop> <file.iop> <file.xyz> [--out DIR] [--free-ap MASK] [--free-iop MASK]\n"
           "               [--solver dense|pcg] [--pcg-rtol X] [--max-iter N] [--covariance] [--model M]\n"
+          "               [--bins B] [--truth file.xyz]\n"
           "       ba_main --synth C S P RAYS [same options]\n"
           "  MASK: bit k of --free-ap frees AP[k] (a1 a2 k1 k2 k3 p1 p2 ep1..ep9); default 0x4 = k1 only,\n"
           "        the reference's choice (src/main.cpp:4487-4504).  --free-iop: bits xp yp c, default 7.\n"
           "  --model: projection functor, 0 collinearity (default), 1 collinearity stereographic, 2 fisheye equidistant,\n"
           "        3 equisolid angle, 4 orthographic, 5 stereographic, 6 collinearity orthographic, 7 omnidirectional\n"
           "        (src/main.cpp:3845-3918, :4016, :4186-4250).\n"
+          "  --bins: quantile bins of the residual statistics printed after the solve (default 30 = the reference's\n"
+          "        QUANTILE_RESIDUALS_BINS, src/main.cpp:51; 0 leaves them out).  --truth: object-space QC against a file\n"
+          "        of rows \"id X Y Z sX sY sZ\" (src/main.cpp:7242-7346).\n"
           "  --covariance: standard deviations of all parameters in the result files (the reference's COMPUTECX\n"
           "        branch, src/main.cpp:5261); small networks only.\n");
 }
@@ -31,7 +35,8 @@ int main(int argc, char **argv) {
   std::string out = ".";
   unsigned ap_mask = 0x4, iop_mask = 7;
   bool synth = false, covariance = false;
-  int model = 0;
+  int model = 0, bins = 30;
+  std::string truth;
   ba_options opt;
   ba_default_options(&opt);
   for (int i = 1; i < argc; ++i) {
@@ -46,6 +51,8 @@ int main(int argc, char **argv) {
     else if (a == "--synth") synth = true;
     else if (a == "--covariance") covariance = true;
     else if (a == "--model") model = atoi(next());
+    else if (a == "--bins") bins = atoi(next());
+    else if (a == "--truth") truth = next();
     else pos.push_back(a);
   }
   ba_network *net = nullptr;
@@ -89,10 +96,6 @@ int main(int argc, char **argv) {
            rows[i].linear_iterations);
   printf("Initial cost %.6e  Final cost %.6e  Termination %s\n", sm.initial_cost, sm.final_cost,
          sm.termination == BA_CONVERGENCE ? "CONVERGENCE" : sm.termination == BA_NO_CONVERGENCE ? "NO_CONVERGENCE" : "FAILURE");
-  double red = 0;
-  const double s0 = ba_sigma0(&sm, d.n_pts, ba_net_num_ap_correction(net), &red);
-  printf("        *Ceres Quadratic Error: %g\n        *Ceres Redundancy: %g\n        *Ceres A Posteriori Variance: %g\n"
-         "        *Ceres A Posteriori Std Dev: %g\n", 2 * sm.final_cost, red, s0 * s0, s0);
   if (covariance) {
     std::vector<double> ve(6 * (size_t)d.n_sta + 1), vx(3 * (size_t)d.n_pts + 1), vi(3 * (size_t)d.n_cam + 1), va(16 * (size_t)d.n_cam + 1);
     if (ba_covariance(p, ve.data(), vx.data(), vi.data(), va.data())) {
@@ -107,7 +110,23 @@ int main(int argc, char **argv) {
     fprintf(stderr, "error: %s\n", ba_last_error());
     return 1;
   }
-  if (ba_net_write_results(net, out.c_str(), res.data())) { fprintf(stderr, "error: %s\n", ba_host_last_error()); return 1; }
+  // what the reference prints and writes after the solve: angles.jck (:4756-4782), the variance-factor, AIC/BIC and
+  // quantile lines (:4905-5137), the reprojection errors (:6982-6984), the result files, the QC against truth (:7242)
+  ba_report rep;
+  std::vector<ba_bin_stats> bin_stats(bins > 0 ? bins : 1);
+  if (ba_net_write_angles(net, out.c_str()) ||
+      ba_net_report(net, &sm, res.data(), (int64_t)res.size(), bins > 0 ? bins : 0, &rep, bin_stats.data()) ||
+      ba_net_print_report(net, &rep, bin_stats.data(), nullptr) || ba_net_write_results(net, out.c_str(), res.data())) {
+    fprintf(stderr, "error: %s\n", ba_host_last_error());
+    return 1;
+  }
+  if (!truth.empty()) {
+    ba_qc qc;
+    if (ba_net_qc(net, truth.c_str(), &qc) || ba_net_print_qc(&qc, truth.c_str(), nullptr)) {
+      fprintf(stderr, "error: %s\n", ba_host_last_error());
+      return 1;
+    }
+  }
   ba_destroy(p);
   ba_net_free(net);
   return 0;

@@ -99,6 +99,47 @@ int ba_net_set_variances(ba_network *net, const double *var_eop, const double *v
 double ba_sigma0(const ba_summary *summary, int32_t n_pts, int32_t num_ap_correction, double *redundancy);
 int32_t ba_net_num_ap_correction(const ba_network *net);
 
+/* ---- reporting (src/main.cpp:791-1019 helpers; :4756-4782, :4905-5137, :6982-6984, :7242-7346 their use) ---- */
+typedef struct { double median, mean, stdev, min, max, rmse; } ba_stats;
+double ba_stat_median(const double *v, int64_t n);              /* calcMedian :791                    */
+double ba_stat_stddev(const double *v, int64_t n);              /* calcStdDev :811 (divides by n)     */
+void ba_stat_all(const double *v, int64_t n, ba_stats *out);    /* calcStatistics :884; zeros if n==0 */
+double ba_aic(double num_obs, double mse, double num_unk);      /* calculateAIC :1008                 */
+double ba_bic(double num_obs, double mse, double num_unk);      /* calculateBIC :1015                 */
+double ba_incidence_angle(const double *eop, const double *xyz);                         /* :923, radians */
+double ba_refraction_angle(double x, double y, const double *iop, const double *ap);     /* :947, radians */
+double ba_radial_distance(double x, double y, const double *iop, const double *ap);      /* :968          */
+
+/* angles.jck: target, station, camera, refraction and incidence angle in degrees per image point (:4756-4782). */
+int ba_net_write_angles(const ba_network *net, const char *dir);
+
+typedef struct {
+  double quadratic_error, redundancy, aposteriori_variance, aposteriori_stddev; /* :4906-4912 */
+  double aic, bic, ic_n, ic_k;                                                    /* :4914-4915 */
+  double vtpv, approx_dof, vtpv_image;                                            /* :4919-4940 */
+  int32_t n_frames, n_targets;                                                    /* distinct ids of the .pho file, :3097-3107 */
+  double res_x_mean, res_x_min, res_x_max, res_y_mean, res_y_min, res_y_max;      /* :6982-6983 */
+  double rmse_x, rmse_y, rmse_xy;                                                 /* :6984      */
+  int32_t bins;                                                                   /* QUANTILE_RESIDUALS_BINS :51 */
+  int64_t bin_width;                                                              /* :4984      */
+} ba_report;
+typedef struct { int64_t count; ba_stats obs, res, dist; } ba_bin_stats;          /* one quantile bin, :4987-5062 */
+
+/* The figures the reference prints after the solve.  residuals = all rows of ba_evaluate(..., apply_loss=1, ...)
+ * (image rows first); bins = 0 skips the quantile statistics, else bin_stats holds `bins` entries. */
+int ba_net_report(const ba_network *net, const ba_summary *summary, const double *residuals, int64_t n_residuals,
+                  int32_t bins, ba_report *out, ba_bin_stats *bin_stats);
+/* The same as text, line for line as the reference's std::cout (path NULL: stdout). */
+int ba_net_print_report(const ba_network *net, const ba_report *report, const ba_bin_stats *bin_stats, const char *path);
+
+typedef struct {
+  int32_t n_truth, n_estimated, n_matches;
+  double mean[3], min[3], max[3], rmse[3], rmse_average;
+} ba_qc;
+/* Object-space error against a truth file of rows "id X Y Z sX sY sZ", matched by id (:7242-7346). */
+int ba_net_qc(const ba_network *net, const char *truth_path, ba_qc *out);
+int ba_net_print_qc(const ba_qc *qc, const char *truth_path, const char *path);
+
 const char *ba_host_last_error(void);
 
 #ifdef __cplusplus

@@ -181,6 +181,40 @@ def ref_projection_jacobian(model, eop, xyz, iop, ap, obs, h=1e-30):
     return J
 
 
+def ref_statistics(v):
+    """median, mean, stdev, min, max, RMSE of the reference's calcStatistics (src/main.cpp:884)."""
+    L = ref_lib()
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    out = np.zeros(6)
+    L.ref_statistics(_dp(v), len(v), _dp(out))
+    return out
+
+
+def ref_sort_index(v):
+    L = ref_lib()
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    out = np.zeros(len(v), dtype=np.int32)
+    L.ref_sort_index(_dp(v), len(v), out.ctypes.data_as(c_int32_p))
+    return out
+
+
+def ref_scalar(name, *args):
+    """ref_median / ref_stddev (array, n) and ref_aic / ref_bic / ref_incidence_angle / ref_refraction_angle /
+    ref_radial_distance with their C arguments; arrays as numpy float64."""
+    L = ref_lib()
+    fn = getattr(L, name)
+    fn.restype = C.c_double
+    conv = []
+    for a in args:
+        if isinstance(a, np.ndarray):
+            conv.append(_dp(np.ascontiguousarray(a, dtype=np.float64)))
+        elif isinstance(a, int):
+            conv.append(C.c_int(a))
+        else:
+            conv.append(C.c_double(a))
+    return fn(*conv)
+
+
 def ref_constrain_point(p, p0, sigma):
     L = ref_lib()
     p, p0, sigma = (np.ascontiguousarray(a, dtype=np.float64) for a in (p, p0, sigma))

@@ -21,6 +21,9 @@ sed -n '2398,2473p'  "$SRC" > "$TMP/slice_orthographicMLS.inc"
 sed -n '2484,2562p'  "$SRC" > "$TMP/slice_fisheyeStereoMLS.inc"
 sed -n '1412,1490p'  "$SRC" > "$TMP/slice_orthographic.inc"
 sed -n '2700,2790p'  "$SRC" > "$TMP/slice_omniMLS.inc"
+sed -n '39p'         "$SRC" > "$TMP/slice_pi.inc"
+sed -n '791,823p'    "$SRC" > "$TMP/slice_stats1.inc"
+sed -n '884,1019p'   "$SRC" > "$TMP/slice_stats2.inc"
 grep -q 'define APSCALE'                         "$TMP/slice_apscale.inc"
 grep -q 'struct constrainPoint'                  "$TMP/slice_constrainPoint.inc"
 grep -q 'struct collinearity {'                  "$TMP/slice_collinearity.inc"
@@ -32,6 +35,9 @@ grep -q 'struct fisheyeOrthographicMachineLearnedSimple'       "$TMP/slice_ortho
 grep -q 'struct fisheyeStereographicMachineLearnedSimple'      "$TMP/slice_fisheyeStereoMLS.inc"
 grep -q 'struct collinearityOrthographic {'                    "$TMP/slice_orthographic.inc"
 grep -q 'struct omniCollinearityMachineLearnedSimple'          "$TMP/slice_omniMLS.inc"
+grep -q 'define PI'                                            "$TMP/slice_pi.inc"
+grep -q 'double calcMedian'                                    "$TMP/slice_stats1.inc"
+grep -q 'double calculateBIC'                                  "$TMP/slice_stats2.inc"
 mkdir -p "$OUT"
 # -ffp-contract=off: keep the reference's expression order, no fused multiply-add
 g++ -O2 -std=c++14 -ffp-contract=off -fPIC -shared -I"$TMP" "$HERE/ref_wrap.cpp" -o "$OUT/libba_ref.so"

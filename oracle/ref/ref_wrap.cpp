@@ -4,7 +4,9 @@
 // repository: build_ref.sh cuts them, at build time, out of /root/reference/src/main.cpp
 // (struct collinearity :1315-1401, struct collinearityMachineLearnedSimple :2033-2120, the five
 // other projection functors of :2133-2562, struct collinearityOrthographic :1412-1490, struct
-// omniCollinearityMachineLearnedSimple :2700-2790, struct constrainPoint :1057-1085, and the APSCALE
+// omniCollinearityMachineLearnedSimple :2700-2790, the statistics and angle helpers :791-823 and
+// :884-1019 (calcMedian, calcStdDev, calcStatistics, incidenceAngle, refractionAngle, radialDistance,
+// sort_index, calculateAIC, calculateBIC), struct constrainPoint :1057-1085, and the APSCALE
 // define :55) into a temporary directory
 // that is on the include path only while this file compiles.  The functors are templates
 // over the scalar type, so they are instantiated here with
@@ -15,8 +17,13 @@
 // atan2, which the standard library does not define for complex arguments: the overload below
 // is its first-order continuation (value of the real parts, imaginary part from the gradient),
 // which is all a complex step of size 1e-30 can see.
+#include <algorithm>
 #include <cmath>
 #include <complex>
+#include <cstdlib>
+#include <functional>
+#include <numeric>
+#include <vector>
 
 inline std::complex<double> atan2(const std::complex<double> &y, const std::complex<double> &x) {
   const double yr = y.real(), xr = x.real();
@@ -34,6 +41,9 @@ inline std::complex<double> atan2(const std::complex<double> &y, const std::comp
 #include "slice_fisheyeStereoMLS.inc"
 #include "slice_orthographic.inc"
 #include "slice_omniMLS.inc"
+#include "slice_pi.inc"
+#include "slice_stats1.inc"
+#include "slice_stats2.inc"
 
 typedef std::complex<double> cplx;
 
@@ -133,6 +143,23 @@ int ref_projection_jacobian(int model, const double *eop, const double *xyz, con
   }
   return -1;
 }
+
+// out = median, mean, stdev, min, max, RMSE (calcStatistics with six outputs, src/main.cpp:884)
+void ref_statistics(const double *v, int n, double *out) {
+  std::vector<double> s(v, v + n);
+  calcStatistics(s, out[0], out[1], out[2], out[3], out[4], out[5]);
+}
+double ref_median(const double *v, int n) { return calcMedian(std::vector<double>(v, v + n)); }
+double ref_stddev(const double *v, int n) { return calcStdDev(std::vector<double>(v, v + n)); }
+void ref_sort_index(const double *v, int n, int *out) {
+  const std::vector<int> idx = sort_index(std::vector<double>(v, v + n));
+  for (int i = 0; i < n; ++i) out[i] = idx[i];
+}
+double ref_aic(double n, double mse, double k) { return calculateAIC(n, mse, k); }
+double ref_bic(double n, double mse, double k) { return calculateBIC(n, mse, k); }
+double ref_incidence_angle(const double *eop, const double *xyz) { return incidenceAngle(eop, xyz); }
+double ref_refraction_angle(double x, double y, const double *iop, const double *ap) { return refractionAngle(x, y, iop, ap); }
+double ref_radial_distance(double x, double y, const double *iop, const double *ap) { return radialDistance(x, y, iop, ap); }
 
 void ref_constrain_point(const double *p, const double *p0, const double *sigma, double *r) {
   constrainPoint f(p0[0], p0[1], p0[2], sigma[0], sigma[1], sigma[2]);

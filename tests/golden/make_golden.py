@@ -12,6 +12,9 @@ projection_golden.json holds the same for the seven other projection functors (s
 collinearity stereographic and the four fisheye models; :1412-1490 collinearity orthographic; :2700-2790
 omnidirectional), at off-axis angles up to 69 degrees.
 
+reporting_golden.json holds inputs and outputs of the reference's statistics and angle helpers
+(src/main.cpp:791-823, 884-1019).
+
     python tests/golden/make_golden.py
 """
 import json
@@ -139,6 +142,38 @@ def main_projection():
     print(f"wrote {path}: {len(cases)} cases")
 
 
+def main_reporting():
+    """Inputs and outputs of the reference's statistics and angle helpers (src/main.cpp:791-823, 884-1019)."""
+    rng = np.random.default_rng(SEED + 2)
+    stats = []
+    for n in (1, 2, 3, 10, 11, 64, 257):
+        for kind in ("normal", "ties"):
+            v = rng.normal(1.5, 3.0, n)
+            if kind == "ties":
+                v = np.round(v)
+            stats.append({"v": v.tolist(), "stats": po.ref_statistics(v).tolist(),  # median mean stdev min max rmse
+                          "median": po.ref_scalar("ref_median", v, int(n)), "stddev": po.ref_scalar("ref_stddev", v, int(n)),
+                          "sort_index": po.ref_sort_index(v).tolist()})
+    angles = []
+    for i in range(40):
+        eop, xyz, iop, ap, obs = make_projection_case(rng, 2, ("zero", "brown", "all")[i % 3], "small", False)
+        angles.append({"eop": eop.tolist(), "xyz": xyz.tolist(), "iop": iop.tolist(), "ap": ap.tolist(), "x": obs[0], "y": obs[1],
+                       "incidence": po.ref_scalar("ref_incidence_angle", eop, xyz),
+                       "refraction": po.ref_scalar("ref_refraction_angle", float(obs[0]), float(obs[1]), iop, ap),
+                       "radial": po.ref_scalar("ref_radial_distance", float(obs[0]), float(obs[1]), iop, ap)})
+    ic = []
+    for _ in range(8):
+        n, mse, k = float(rng.integers(100, 10 ** 7)), float(rng.uniform(0.1, 1e6)), float(rng.integers(7, 10 ** 5))
+        ic.append({"n": n, "mse": mse, "k": k, "aic": po.ref_scalar("ref_aic", n, mse, k), "bic": po.ref_scalar("ref_bic", n, mse, k)})
+    out = {"generator": "tests/golden/make_golden.py",
+           "source": "reference helpers src/main.cpp:791-823, 884-1019 compiled by oracle/ref/build_ref.sh",
+           "seed": SEED + 2, "statistics": stats, "angles": angles, "information_criteria": ic}
+    path = os.path.join(ROOT, "tests", "golden", "reporting_golden.json")
+    with open(path, "w") as f:
+        json.dump(out, f)
+    print(f"wrote {path}: {len(stats)} statistics, {len(angles)} angle and {len(ic)} AIC/BIC cases")
+
+
 def main():
     if po.ref_lib() is None:
         sys.exit("oracle/_ref/libba_ref.so is missing: run `make -C oracle` where /root/reference exists")
@@ -185,3 +220,4 @@ def main():
 if __name__ == "__main__":
     main()
     main_projection()
+    main_reporting()

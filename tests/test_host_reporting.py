@@ -1,0 +1,180 @@
+"""Host-side reporting (src/main.cpp:791-1019 helpers; angles.jck :4756-4782; console report :4905-5137, :6982-6984;
+QC against a truth file :7242-7346): the library against golden vectors made from the reference's own helper
+functions (tests/golden/make_golden.py) and against a numpy restatement of the report."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from bundleadjustment_amd import capi, host
+from oracle import py_oracle as po
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dp = host.c_double_p
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(ROOT, "tests", "golden", "reporting_golden.json")) as f:
+        return json.load(f)
+
+
+def _p(a):
+    return np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(dp)
+
+
+def test_statistics_helpers_vs_reference(golden):
+    L = host.lib()
+    for c in golden["statistics"]:
+        v = np.array(c["v"])
+        st = host.Stats()
+        L.ba_stat_all(_p(v), len(v), C.byref(st))
+        got = [st.median, st.mean, st.stdev, st.min, st.max, st.rmse]
+        assert got[0] == c["stats"][0] and got[3] == c["stats"][3] and got[4] == c["stats"][4]  # order statistics: exact
+        assert np.allclose(got, c["stats"], rtol=1e-14, atol=1e-15)
+        assert L.ba_stat_median(_p(v), len(v)) == c["median"]
+        assert L.ba_stat_stddev(_p(v), len(v)) == pytest.approx(c["stddev"], rel=1e-14, abs=1e-15)
+    st = host.Stats()
+    L.ba_stat_all(None, 0, C.byref(st))  # empty input gives zeros (:859, :893)
+    assert st.as_dict() == dict(median=0, mean=0, stdev=0, min=0, max=0, rmse=0)
+
+
+def test_angle_helpers_and_information_criteria_vs_reference(golden):
+    L = host.lib()
+    for c in golden["angles"]:
+        assert L.ba_incidence_angle(_p(c["eop"]), _p(c["xyz"])) == pytest.approx(c["incidence"], rel=1e-13)
+        assert L.ba_refraction_angle(c["x"], c["y"], _p(c["iop"]), _p(c["ap"])) == pytest.approx(c["refraction"], rel=1e-13)
+        assert L.ba_radial_distance(c["x"], c["y"], _p(c["iop"]), _p(c["ap"])) == pytest.approx(c["radial"], rel=1e-13)
+    for c in golden["information_criteria"]:
+        assert L.ba_aic(c["n"], c["mse"], c["k"]) == pytest.approx(c["aic"], rel=1e-15)
+        assert L.ba_bic(c["n"], c["mse"], c["k"]) == pytest.approx(c["bic"], rel=1e-15)
+
+
+@pytest.fixture(scope="module")
+def solved():
+    hn = host.synth(n_cam=2, n_sta=12, n_pts=120, rays_per_point=6, seed=21, ap_free_mask=host.AP_K1K2P1P2)
+    net = hn.net
+    opt = capi.default_options()
+    eop, xyz, iop, ap, sm, rows = po.solve(net, opt, po.SCHUR_DENSE)
+    hn.set_parameters(eop, xyz, iop, ap)
+    cost, res = po.evaluate(net, eop, xyz, iop, ap, apply_loss=True)
+    return hn, net, (eop, xyz, iop, ap), sm, res
+
+
+def test_report_vs_numpy(solved):
+    hn, net, (eop, xyz, iop, ap), sm, res = solved
+    bins = 7
+    rep, bs = hn.report(sm, res, bins=bins)
+    N, P = net.n_obs, net.n_pts
+    nap = hn.num_ap_correction()
+    red = sm["num_residuals_reduced"] - sm["num_parameters_reduced"] - 3 * P + 7 + nap   # :4907
+    assert rep.quadratic_error == 2 * sm["final_cost"] and rep.redundancy == red
+    assert rep.aposteriori_variance == pytest.approx(2 * sm["final_cost"] / red, rel=1e-15)
+    assert rep.aposteriori_stddev == pytest.approx(np.sqrt(2 * sm["final_cost"] / red), rel=1e-15)
+    n_ic, k_ic = sm["num_residuals_reduced"] - 3 * P, sm["num_parameters_reduced"] - nap
+    assert (rep.ic_n, rep.ic_k) == (n_ic, k_ic)
+    assert rep.aic == pytest.approx(n_ic * np.log(2 * sm["final_cost"]) + 2 * k_ic, rel=1e-14)       # :1010
+    assert rep.bic == pytest.approx(n_ic * np.log(2 * sm["final_cost"]) + k_ic * np.log(n_ic), rel=1e-14)
+    assert rep.vtpv == pytest.approx(float(res @ res), rel=1e-13)
+    assert rep.vtpv_image == pytest.approx(float(res[:2 * N] @ res[:2 * N]), rel=1e-13)
+    frames, targets = len(set(hn.ids("pho_station"))), len(set(hn.ids("pho_target")))
+    assert (rep.n_frames, rep.n_targets) == (frames, targets)
+    assert rep.approx_dof == 2 * N - 6 * frames - 3 * targets + 7
+    vx, vy = res[0:2 * N:2] * net.obs_sx, res[1:2 * N:2] * net.obs_sy
+    assert rep.rmse_x == pytest.approx(np.sqrt(np.mean(vx ** 2)), rel=1e-13)
+    assert rep.rmse_xy == pytest.approx(np.sqrt((np.sum(vx ** 2) + np.sum(vy ** 2)) / (2 * N)), rel=1e-13)
+    assert (rep.res_x_min, rep.res_x_max, rep.res_y_min, rep.res_y_max) == (vx.min(), vx.max(), vy.min(), vy.max())
+    assert rep.res_y_mean == pytest.approx(vy.mean(), rel=1e-12, abs=1e-15)
+    # quantile bins over the corrected radial distance (:4964-5062)
+    L = host.lib()
+    cam = net.sta_cam[net.obs_sta]
+    dist = np.array([L.ba_radial_distance(net.obs_x[i], net.obs_y[i], _p(iop[cam[i]]), _p(ap[cam[i]])) for i in range(N)])
+    order = np.argsort(dist, kind="stable")
+    width = int(np.ceil(N / bins))
+    assert rep.bin_width == width and rep.bins == bins and len(bs) == bins
+    for b in range(bins):
+        sel = order[b * width:(b + 1) * width]
+        assert bs[b].count == len(sel)
+        r = np.column_stack([vx[sel], vy[sel]]).ravel()
+        assert bs[b].res.mean == pytest.approx(r.mean(), rel=1e-12, abs=1e-15)
+        assert bs[b].res.stdev == pytest.approx(r.std(), rel=1e-12)
+        assert bs[b].res.rmse == pytest.approx(np.sqrt(np.mean(r ** 2)), rel=1e-12)
+        assert bs[b].dist.min == dist[sel].min() and bs[b].dist.max == dist[sel].max()
+        assert bs[b].dist.median == pytest.approx(np.median(dist[sel]), rel=1e-15)
+        o = np.column_stack([net.obs_x[sel], net.obs_y[sel]]).ravel()
+        assert bs[b].obs.median == pytest.approx(np.median(o), rel=1e-15)
+    assert sum(b.count for b in bs) == N
+
+
+def test_report_text_lines(solved, tmp_path):
+    hn, net, _, sm, res = solved
+    path = str(tmp_path / "report.txt")
+    rep, bs = hn.report(sm, res, bins=5, path=path, text=True)
+    lines = open(path).read().split("\n")
+    assert lines[0] == "  Estimating A Posterior Variance Factor..."
+    assert lines[1] == "     *CERES GLOBAL A Posteriori Variance (using the robust weights): "
+    assert lines[2] == "        *Ceres Quadratic Error: %g" % rep.quadratic_error      # std::cout default = %g, 6 digits
+    assert lines[3] == "        *Ceres Redundancy: %g" % rep.redundancy
+    assert lines[6] == "        *AIC n: %g. n = %d, k = %d" % (rep.aic, rep.ic_n, rep.ic_k)
+    assert lines[8] == "     MANUAL GLOBAL A Posteriori Variance (assumes normal weights): "
+    assert lines[10] == "        Approximate dof (2*img - 6*EOP - 3*XYZ + 7datum): %d" % rep.approx_dof
+    q = lines.index("  Computing quantile residual statistics by dividing into 5 bins...")
+    assert lines[q + 1] == "    binWidth: %d points" % rep.bin_width
+    assert lines[q + 2] == "    Min distanc: " + "".join("%g\t" % b.dist.min for b in bs)
+    assert lines[q + 5] == "    Mean residuals  : " + "".join("%.2f\t" % b.res.mean for b in bs)     # fixed, 2 decimals (:5119)
+    assert lines[q + 7] == "    RMSE residuals  : " + "".join("%.2f\t" % b.res.rmse for b in bs)
+    assert lines[q + 8] == "  Residual x mean (range): %g (%g to %g)" % (rep.res_x_mean, rep.res_x_min, rep.res_x_max)
+    assert lines[q + 10] == "  Reprojection errors (RMSE in x, y, and average): %g, %g --> %g" % (rep.rmse_x, rep.rmse_y, rep.rmse_xy)
+    # without bins the block is left out, as with QUANTILE_RESIDUALS_BINS 0 (:4960)
+    hn.report(sm, res, bins=0, path=path, text=True)
+    assert "quantile" not in open(path).read()
+
+
+def test_angles_file(solved, tmp_path):
+    hn, net, (eop, xyz, iop, ap), _, _ = solved
+    hn.write_angles(str(tmp_path))
+    rows = [l.split() for l in open(tmp_path / "angles.jck").read().strip().split("\n")]
+    assert len(rows) == net.n_obs and all(len(r) == 5 for r in rows)
+    L = host.lib()
+    tgt, sta, cam_ids = hn.ids("pho_target"), hn.ids("pho_station"), hn.ids("eop_camera")
+    for i in (0, 1, net.n_obs // 2, net.n_obs - 1):
+        s, c = net.obs_sta[i], net.sta_cam[net.obs_sta[i]]
+        assert [int(rows[i][0]), int(rows[i][1]), int(rows[i][2])] == [tgt[i], sta[i], cam_ids[s]]
+        beta = L.ba_refraction_angle(net.obs_x[i], net.obs_y[i], _p(iop[c]), _p(ap[c])) * 180.0 / np.pi
+        alpha = L.ba_incidence_angle(_p(eop[s]), _p(xyz[net.obs_pt[i]])) * 180.0 / np.pi
+        assert rows[i][3] == "%.6f" % beta and rows[i][4] == "%.6f" % alpha    # "%.6lf %.6lf" (:4779)
+    # for a collinear camera the two angles agree up to the residual: incidence = refraction at the truth
+    a = np.array([[float(r[3]), float(r[4])] for r in rows])
+    assert np.median(np.abs(a[:, 0] - a[:, 1])) < 0.05
+
+
+def test_qc_against_truth_file(solved, tmp_path):
+    hn, net, (eop, xyz, iop, ap), _, _ = solved
+    ids = hn.ids("xyz_target")
+    truth = net.truth["xyz"]
+    path = str(tmp_path / "truth.xyz")
+    keep = np.arange(net.n_pts)[::2][::-1]  # a subset, in another order (:7245 "DOES NOT assume ... same order")
+    with open(path, "w") as f:
+        for j in keep:
+            f.write("%d %.9f %.9f %.9f 1.0 1.0 1.0\n" % (ids[j], *truth[j]))
+        f.write("999999 0 0 0 1 1 1\n")  # an id the adjustment does not have
+    q = hn.qc(path, path=str(tmp_path / "qc.txt"), text=True)
+    assert (q.n_truth, q.n_estimated, q.n_matches) == (len(keep) + 1, net.n_pts, len(keep))
+    tr = np.array([[float("%.9f" % v) for v in truth[j]] for j in keep])
+    d = xyz[keep] - tr
+    assert np.allclose(list(q.mean), d.mean(axis=0), rtol=1e-10, atol=1e-12)
+    assert np.allclose(list(q.rmse), np.sqrt((d ** 2).mean(axis=0)), rtol=1e-12)
+    assert list(q.min) == d.min(axis=0).tolist() and list(q.max) == d.max(axis=0).tolist()
+    assert q.rmse_average == pytest.approx(np.sqrt(np.mean(np.array(list(q.rmse)) ** 2)), rel=1e-14)
+    text = open(tmp_path / "qc.txt").read().split("\n")
+    assert text[1] == "  Number of XYZ Ground Truth Read: %d" % q.n_truth
+    assert text[4].startswith("    Mean X (range): ")
+    assert text[7] == "    Direct method - RMSE X, Y, Z, Average: %g, %g, %g --> %g" % (*q.rmse, q.rmse_average)
+    # a last row without a newline is dropped, as every reader of the reference does (:7266-7271)
+    with open(path, "w") as f:
+        f.write("%d 0 0 0 1 1 1\n%d 0 0 0 1 1 1" % (ids[0], ids[1]))
+    assert hn.qc(path).n_truth == 1
+    with pytest.raises(RuntimeError, match="cannot open"):
+        hn.qc(str(tmp_path / "missing.xyz"))
