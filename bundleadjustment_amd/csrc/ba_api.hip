@@ -1062,6 +1062,29 @@ int ba_set_parameters(ba_problem *p, const double *eop, const double *xyz, const
   return set_parameters(p, eop, xyz, iop, ap, false);
 }
 
+int ba_set_corrections(ba_problem *p, const double *obs_cx, const double *obs_cy) {
+  if (!p) return fail(BA_ERR_INVALID, "ba_set_corrections: null problem");
+  if (p->N > 0 && (!obs_cx || !obs_cy)) return fail(BA_ERR_INVALID, "ba_set_corrections: null array");
+  if (p->N == 0) return 0;
+  for (int n = 0; n < p->N; ++n)
+    if (!std::isfinite(obs_cx[n]) || !std::isfinite(obs_cy[n]))
+      return fail(BA_ERR_INVALID, "ba_set_corrections: observation %d has a correction that is not finite", n);
+  double *d_c = nullptr;
+  const size_t bytes = (size_t)p->N * sizeof(double);
+  if (hipMalloc((void **)&d_c, 2 * bytes) != hipSuccess) return fail(BA_ERR_DEVICE, "ba_set_corrections: hipMalloc of %zu bytes failed", 2 * bytes);
+  int rc = 0;
+  if (hipMemcpyAsync(d_c, obs_cx, bytes, hipMemcpyHostToDevice, p->stream) != hipSuccess ||
+      hipMemcpyAsync(d_c + p->N, obs_cy, bytes, hipMemcpyHostToDevice, p->stream) != hipSuccess)
+    rc = fail(BA_ERR_DEVICE, "ba_set_corrections: upload failed");
+  if (!rc) {
+    launch_set_corrections(p->stream, p->N, p->d_obs, d_c, d_c + p->N);
+    rc = p->check_kernels();
+  }
+  if (hipStreamSynchronize(p->stream) != hipSuccess && !rc) rc = fail(BA_ERR_DEVICE, "ba_set_corrections: kernel failed");
+  (void)hipFree(d_c);
+  return rc;
+}
+
 int ba_get_parameters(ba_problem *p, double *eop, double *xyz, double *iop, double *ap) {
   if (!p) return fail(BA_ERR_INVALID, "ba_get_parameters: null problem");
   if (!p->have_params) return fail(BA_ERR_INVALID, "ba_get_parameters: no parameters were set");

@@ -128,6 +128,7 @@ void launch_camera_mcc(hipStream_t s, int C, const CamRec *cam, const double *y_
 void launch_cg_init(hipStream_t s, const CgArgs &a);
 void launch_cg_step(hipStream_t s, const CgArgs &a);
 void launch_copy(hipStream_t s, int64_t n, const double *src, double *dst);
+void launch_set_corrections(hipStream_t s, int64_t N, double *obs, const double *cx, const double *cy);
 void launch_unit(hipStream_t s, int64_t n, double *v, int64_t k);
 void launch_resjac_dense(hipStream_t s, const CostArgs &a, double *r_out, double *J_out);
 

@@ -1078,6 +1078,16 @@ k_cg_step(CgArgs a) {
   }
 }
 
+// new constant corrections (file order) into the observation records (point-sorted order)
+__global__ void k_set_corrections(int64_t N, double *__restrict__ obs, const double *__restrict__ cx, const double *__restrict__ cy) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  double *o = obs + e * BA_OBS_STRIDE;
+  const int row = __double2hiint(o[6]);
+  o[4] = cx[row];
+  o[5] = cy[row];
+}
+
 // copy helpers ------------------------------------------------------------------------------
 __global__ void k_copy(int64_t n, const double *__restrict__ src, double *__restrict__ dst) {
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1344,6 +1354,9 @@ void launch_camera_mcc(hipStream_t s, int C, const CamRec *cam, const double *y_
 }
 void launch_cg_init(hipStream_t s, const CgArgs &a) { hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(1024), 0, s, a); }
 void launch_cg_step(hipStream_t s, const CgArgs &a) { hipLaunchKernelGGL(k_cg_step, dim3(1), dim3(1024), 0, s, a); }
+void launch_set_corrections(hipStream_t s, int64_t N, double *obs, const double *cx, const double *cy) {
+  if (N > 0) hipLaunchKernelGGL(k_set_corrections, dim3(nblk(N, 256)), dim3(256), 0, s, N, obs, cx, cy);
+}
 void launch_copy(hipStream_t s, int64_t n, const double *src, double *dst) {
   if (n > 0) hipLaunchKernelGGL(k_copy, dim3(nblk(n, 256)), dim3(256), 0, s, n, src, dst);
 }

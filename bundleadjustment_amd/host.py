@@ -121,6 +121,9 @@ def lib():
         L.ba_net_print_report.argtypes = [C.c_void_p, C.POINTER(Report), C.POINTER(BinStats), C.c_char_p]
         L.ba_net_qc.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Qc)]
         L.ba_net_print_qc.argtypes = [C.POINTER(Qc), C.c_char_p, C.c_char_p]
+        L.ba_net_set_corrections.argtypes = [C.c_void_p, c_double_p, c_double_p]
+        L.ba_read_ml_cost.argtypes = [C.c_char_p, c_double_p, c_double_p, c_double_p]
+        L.ba_append_costs.argtypes = [C.c_char_p, C.c_int32] + [C.c_double] * 6 + [c_double_p]
         L.ba_sigma0.restype = C.c_double
         L.ba_sigma0.argtypes = [C.POINTER(BaSummary), C.c_int32, C.c_int32, c_double_p]
         _lib = L
@@ -192,6 +195,14 @@ class HostNetwork:
     def set_model(self, model):
         """Projection of the image rows: 0 collinearity, 1 collinearity stereographic, 2..5 the fisheye functors."""
         _check(lib().ba_net_set_model(self._h, int(model)))
+        self.net = self._export()
+
+    def set_corrections(self, obs_cx, obs_cy):
+        """New image corrections (columns 7-8 of temp.pho) from the regression step of the outer loop."""
+        cx, cy = (np.ascontiguousarray(a, dtype=np.float64) for a in (obs_cx, obs_cy))
+        if cx.shape != (self.dims.n_obs,) or cy.shape != (self.dims.n_obs,):
+            raise ValueError("one correction per observation")
+        _check(lib().ba_net_set_corrections(self._h, cx.ctypes.data_as(c_double_p), cy.ctypes.data_as(c_double_p)))
         self.net = self._export()
 
     def set_parameters(self, eop, xyz, iop, ap):
@@ -282,6 +293,21 @@ def synth_config(name, scale=1.0, **kw):
         cfg["n_pts"] = max(16, int(round(cfg["n_pts"] * scale)))
     cfg.update(kw)
     return synth(**cfg)
+
+
+def read_ml_cost(path):
+    """(cost, redundancy, [three hyper-parameters]) from the first row of kNNCost.jck (src/main.cpp:7562-7590)."""
+    c, r, h = np.zeros(1), np.zeros(1), np.zeros(3)
+    _check(lib().ba_read_ml_cost(path.encode(), c.ctypes.data_as(c_double_p), r.ctypes.data_as(c_double_p), h.ctypes.data_as(c_double_p)))
+    return c[0], r[0], h
+
+
+def append_costs(directory, iteration, lsq_cost, lsq_redundancy, ml_cost, ml_redundancy, reprojection_2d, reconstruction_3d,
+                 hyper=None):
+    """costs.jck / hyperparameters.jck, one line per outer iteration (src/main.cpp:7594-7613)."""
+    h = None if hyper is None else np.ascontiguousarray(hyper, dtype=np.float64)
+    _check(lib().ba_append_costs(directory.encode(), int(iteration), lsq_cost, lsq_redundancy, ml_cost, ml_redundancy,
+                                 reprojection_2d, reconstruction_3d, None if h is None else h.ctypes.data_as(c_double_p)))
 
 
 def read_network(pho, eop, iop, xyz):

@@ -978,6 +978,53 @@ int ba_net_qc(const ba_network *n, const char *truth_path, ba_qc *out) {  // src
   return 0;
 }
 
+// ---- hand-over to and from the regression step of the outer loop (src/main.cpp:3040-3056, :7544-7613)
+int ba_net_set_corrections(ba_network *n, const double *cx, const double *cy) {
+  if (!n || (!n->imageX.empty() && (!cx || !cy))) return fail(BA_ERR_INVALID, "ba_net_set_corrections: null argument");
+  std::copy(cx, cx + n->imageX.size(), n->imageXCorr.begin());  // columns 7-8 of temp.pho (:3130)
+  std::copy(cy, cy + n->imageY.size(), n->imageYCorr.begin());
+  return 0;
+}
+
+int ba_read_ml_cost(const char *path, double *cost, double *redundancy, double *hyper) {  // :7562-7590
+  if (!path || !cost || !redundancy || !hyper) return fail(BA_ERR_INVALID, "ba_read_ml_cost: null argument");
+  std::ifstream inp(path);
+  if (!inp.is_open()) return fail(BA_ERR_INVALID, "cannot open %s", path);
+  std::vector<double> rows;
+  while (true) {  // five columns per row; the row read at end of file is dropped again
+    double c[5] = {0, 0, 0, 0, 0};
+    inp >> c[0] >> c[1] >> c[2] >> c[3] >> c[4];
+    rows.insert(rows.end(), c, c + 5);
+    if (inp.eof()) break;
+    if (inp.fail()) return fail(BA_ERR_INVALID, "%s: malformed token", path);
+  }
+  rows.resize(rows.size() - 5);
+  if (rows.empty()) return fail(BA_ERR_INVALID, "%s: no complete row (the reference would read past the end, :7592)", path);
+  *cost = rows[0];
+  *redundancy = rows[1];
+  hyper[0] = rows[2]; hyper[1] = rows[3]; hyper[2] = rows[4];
+  return 0;
+}
+
+int ba_append_costs(const char *dir, int32_t iteration, double lsq_cost, double lsq_redundancy, double ml_cost,
+                    double ml_redundancy, double reprojection_2d, double reconstruction_3d, const double *hyper) {
+  if (!dir) return fail(BA_ERR_INVALID, "ba_append_costs: null argument");
+  const std::string d = std::string(dir) + "/";
+  const char *mode = iteration == 0 ? "w" : "a";  // :7594-7597, :7606-7609
+  if (hyper) {
+    FILE *f = fopen((d + "hyperparameters.jck").c_str(), mode);
+    if (!f) return fail(BA_ERR_INVALID, "cannot write into %s", dir);
+    fprintf(f, "%.6lf %.6lf %.6lf\n", hyper[0], hyper[1], hyper[2]);  // :7599
+    fclose(f);
+  }
+  FILE *f = fopen((d + "costs.jck").c_str(), mode);
+  if (!f) return fail(BA_ERR_INVALID, "cannot write into %s", dir);
+  fprintf(f, "%.6lf %.6lf %.6lf %.6lf %.6lf %.6lf\n", 2.0 * lsq_cost, lsq_redundancy, ml_cost, ml_redundancy, reprojection_2d,
+          reconstruction_3d);  // :7611
+  fclose(f);
+  return 0;
+}
+
 int ba_net_print_qc(const ba_qc *q, const char *truth_path, const char *path) {  // src/main.cpp:7246, 7274-7344
   if (!q) return fail(BA_ERR_INVALID, "ba_net_print_qc: null argument");
   std::ostringstream o;

@@ -18,7 +18,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, c_double_p, C.c_int64, C.c_int32
 KERNEL_LINEARIZE, KERNEL_POINT_APPLY, KERNEL_STATION_GATHER, KERNEL_COST = 0, 1, 2, 3
 
 # every entry point include/ba_gpu.h declares
-EXPORTS = ("ba_default_options", "ba_create", "ba_destroy", "ba_set_parameters", "ba_get_parameters",
+EXPORTS = ("ba_default_options", "ba_create", "ba_destroy", "ba_set_parameters", "ba_get_parameters", "ba_set_corrections",
            "ba_solve_resident", "ba_solve", "ba_evaluate", "ba_covariance", "ba_sparsity", "ba_residual_jacobian", "ba_time_kernel",
            "ba_set_allreduce", "ba_copy_to_host", "ba_copy_to_device", "ba_rccl_unique_id", "ba_use_rccl", "ba_last_error")
 
@@ -49,6 +49,7 @@ def lib():
         L.ba_default_options.restype = None
         L.ba_set_parameters.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]
         L.ba_get_parameters.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]
+        L.ba_set_corrections.argtypes = [C.c_void_p, c_double_p, c_double_p]
         L.ba_solve_resident.argtypes = [C.c_void_p, C.POINTER(BaOptions), C.POINTER(BaSummary), C.POINTER(BaIterRow), C.c_int32]
         L.ba_solve.argtypes = [C.c_void_p, C.POINTER(BaOptions), c_double_p, c_double_p, c_double_p, c_double_p,
                                C.POINTER(BaSummary), C.POINTER(BaIterRow), C.c_int32]
@@ -118,6 +119,13 @@ class Problem:
         eop, xyz, iop, ap = (np.ascontiguousarray(a if a is not None else b, dtype=np.float64)
                              for a, b in ((eop, n.eop), (xyz, n.xyz), (iop, n.iop), (ap, n.ap)))
         _check(lib().ba_set_parameters(self._h, _dp(eop), _dp(xyz), _dp(iop), _dp(ap)))
+
+    def set_corrections(self, obs_cx, obs_cy):
+        """New constant image corrections (columns 7-8 of the .pho file) for the problem on the device."""
+        cx, cy = (np.ascontiguousarray(a, dtype=np.float64) for a in (obs_cx, obs_cy))
+        if cx.shape != (self.net.n_obs,) or cy.shape != (self.net.n_obs,):
+            raise ValueError("one correction per observation")
+        _check(lib().ba_set_corrections(self._h, _dp(cx), _dp(cy)))
 
     def get_parameters(self):
         n = self.net

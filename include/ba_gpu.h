@@ -186,6 +186,14 @@ int ba_set_parameters(ba_problem *p, const double *eop, const double *xyz, const
 int ba_get_parameters(ba_problem *p, double *eop, double *xyz, double *iop, double *ap);
 
 /*
+ * New constant image corrections, [n_obs] each in file order, in place of ba_inputs.obs_cx / obs_cy; everything
+ * else of the problem stays as it is on the device.  In the reference the outer loop writes the regressor's
+ * corrections into columns 7-8 of temp.pho, reads the file again and rebuilds the whole ceres::Problem for the
+ * next adjustment (src/main.cpp:3040-3056, :3130, :4186-4187); this call is that hand-over without the rebuild.
+ */
+int ba_set_corrections(ba_problem *p, const double *obs_cx, const double *obs_cy);
+
+/*
  * Runs the trust-region Levenberg-Marquardt loop on the parameters resident on the device
  * and leaves the result there.  Replaces ceres::Solve, src/main.cpp:4721.
  * rows may be NULL; at most rows_cap rows are written.

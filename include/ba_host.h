@@ -140,6 +140,17 @@ typedef struct {
 int ba_net_qc(const ba_network *net, const char *truth_path, ba_qc *out);
 int ba_net_print_qc(const ba_qc *qc, const char *truth_path, const char *path);
 
+/* ---- the outer loop's hand-over files (src/main.cpp:3040-3056, :7544-7613).  The regression step itself (the
+ * reference shells out to python/nearestNeighbour.py) is the caller's. ---- */
+/* New corrections for columns 7-8 of temp.pho, [n_obs] in file order (pair with ba_set_corrections of ba_gpu.h). */
+int ba_net_set_corrections(ba_network *net, const double *obs_cx, const double *obs_cy);
+/* First row of kNNCost.jck / decisionTreeCost.jck: cost, redundancy, three hyper-parameters (:7562-7590). */
+int ba_read_ml_cost(const char *path, double *cost, double *redundancy, double *hyper /*[3]*/);
+/* One line of costs.jck (2 * lsq_cost first, :7611) and, if hyper != NULL, of hyperparameters.jck (:7599);
+ * iteration 0 starts the files, later ones append. */
+int ba_append_costs(const char *dir, int32_t iteration, double lsq_cost, double lsq_redundancy, double ml_cost,
+                    double ml_redundancy, double reprojection_2d, double reconstruction_3d, const double *hyper);
+
 const char *ba_host_last_error(void);
 
 #ifdef __cplusplus

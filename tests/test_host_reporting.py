@@ -178,3 +178,36 @@ def test_qc_against_truth_file(solved, tmp_path):
     assert hn.qc(path).n_truth == 1
     with pytest.raises(RuntimeError, match="cannot open"):
         hn.qc(str(tmp_path / "missing.xyz"))
+
+
+# ---- the outer loop's hand-over files (src/main.cpp:3040-3056, :7544-7613)
+
+def test_corrections_travel_through_temp_pho(tmp_path):
+    hn = host.synth(n_cam=1, n_sta=6, n_pts=30, rays_per_point=4, seed=3)
+    rng = np.random.default_rng(0)
+    cx, cy = rng.normal(0, 0.3, hn.dims.n_obs), rng.normal(0, 0.3, hn.dims.n_obs)
+    hn.set_corrections(cx, cy)
+    assert np.array_equal(hn.net.obs_cx, cx) and np.array_equal(hn.net.obs_cy, cy)
+    hn.write_results(str(tmp_path))
+    hn.write_inputs(str(tmp_path), "t")
+    back = host.read_network(str(tmp_path / "temp.pho"), str(tmp_path / "t.eop"), str(tmp_path / "t.iop"), str(tmp_path / "t.xyz"))
+    assert np.allclose(back.net.obs_cx, cx, atol=5e-7) and np.allclose(back.net.obs_cy, cy, atol=5e-7)  # "%.6lf" (:3130)
+    with pytest.raises(ValueError):
+        hn.set_corrections(cx[:-1], cy[:-1])
+
+
+def test_ml_cost_and_costs_files(tmp_path):
+    p = tmp_path / "kNNCost.jck"
+    p.write_text("12.5 340 3 0.25 1\n99 1 2 3 4\n")
+    c, r, h = host.read_ml_cost(str(p))
+    assert (c, r, h.tolist()) == (12.5, 340.0, [3.0, 0.25, 1.0])
+    p.write_text("12.5 340 3 0.25 1")  # a single row without a newline is dropped by the reader's end-of-file rule
+    with pytest.raises(RuntimeError, match="no complete row"):
+        host.read_ml_cost(str(p))
+    host.append_costs(str(tmp_path), 0, 100.0, 950.0, 12.5, 340.0, 0.31, 1.25, hyper=[3, 0.25, 1])
+    host.append_costs(str(tmp_path), 1, 90.0, 950.0, 11.0, 340.0, 0.30, 1.20, hyper=[4, 0.5, 1])
+    assert (tmp_path / "costs.jck").read_text() == ("200.000000 950.000000 12.500000 340.000000 0.310000 1.250000\n"
+                                                    "180.000000 950.000000 11.000000 340.000000 0.300000 1.200000\n")
+    assert (tmp_path / "hyperparameters.jck").read_text() == "3.000000 0.250000 1.000000\n4.000000 0.500000 1.000000\n"
+    host.append_costs(str(tmp_path), 0, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0)  # iteration 0 starts the file again (:7606)
+    assert (tmp_path / "costs.jck").read_text() == "2.000000 2.000000 3.000000 4.000000 5.000000 6.000000\n"
