@@ -66,6 +66,9 @@ struct ba_problem {
   int ncam = 0, ncmax = 0, nr = 0, n_chunks = 0;
   double huber_a = 1.0;
   int model = 0;  // projection of the image rows, 0..7
+  // an empirical term AP[7..15] is estimated or non-zero in the resident parameters / in the last set uploaded as a
+  // candidate: the observation kernels skip those terms when neither is the case
+  bool emp = true, emp_c = true;
   hipStream_t stream = nullptr;
   std::vector<void *> allocs;
   // host copies
@@ -494,6 +497,13 @@ int set_parameters(ba_problem *p, const double *eop, const double *xyz, const do
     for (int k = 0; k < 3; ++k) cam[c].iop[k] = iop[3 * c + k];
     for (int k = 0; k < 16; ++k) cam[c].ap[k] = ap[16 * c + k];
   }
+  bool emp = false;
+  for (int c = 0; c < p->C; ++c) {
+    if (cam[c].mask >> BA_NCAMPAR_BROWN) emp = true;
+    for (int k = 7; k < 16; ++k)
+      if (ap[16 * c + k] != 0.0) emp = true;
+  }
+  (candidate ? p->emp_c : p->emp) = emp;
   double *de = candidate ? p->d_eop_c : p->d_eop, *dx = candidate ? p->d_xyz_c : p->d_xyz;
   CamRec *dc = candidate ? p->d_cam_c : p->d_cam;
   if (p->S) HIP_OK(hipMemcpyAsync(de, eop, 6 * (size_t)p->S * sizeof(double), hipMemcpyHostToDevice, p->stream));
@@ -559,7 +569,7 @@ int linearize(ba_problem *p, const LmState &st) {
   la.scale_pt = p->d_scale_pt; la.pt_prior = p->d_pt_prior; la.pt_isig = p->d_pt_isig; la.cam = p->d_cam;
   la.rec = p->d_rec; la.Jp = p->d_Jp; la.Jc = p->d_Jc; la.Mo = p->d_Mo; la.Vinv = p->d_Vinv; la.g_pt = p->d_g_pt;
   la.colnorm_pt = p->d_colnorm_pt; la.diag_pt = p->d_diag_pt; la.cost_partial = p->d_partial; la.flags = p->d_flags;
-  la.huber_a = p->huber_a; la.model = p->model; la.lm_min = st.lm_min; la.lm_max = st.lm_max; la.radius = st.radius; la.reuse_diag = st.reuse_diag;
+  la.huber_a = p->huber_a; la.model = p->model; la.emp = p->emp; la.lm_min = st.lm_min; la.lm_max = st.lm_max; la.radius = st.radius; la.reuse_diag = st.reuse_diag;
   la.Y = (st.reduced == 2) ? p->d_Y : nullptr;
   la.Jt = p->d_Jt;
   la.cam_partial = p->d_campart;
@@ -925,6 +935,7 @@ int cost_at(ba_problem *p, const double *eop, const double *xyz, const CamRec *c
   launch_station_prep(s, p->S, eop, p->d_scale_sta, p->d_sta_cam, sta_buf);
   CostArgs ca{};
   ca.N = p->N; ca.obs = p->d_obs; ca.sta = sta_buf; ca.xyz = xyz; ca.obs_pt = p->d_obs_pt; ca.cam = cam; ca.huber_a = p->huber_a; ca.model = p->model;
+  ca.emp = p->emp || (cam != p->d_cam && p->emp_c);  // candidates made on the device share the resident set's terms
   ca.apply_loss = apply_loss; ca.res_out = res_out; ca.partial = p->d_partial;
   const int b1 = cost_blocks(p->N), b2 = cost_blocks(3 * (int64_t)p->P);
   launch_cost_obs(s, ca, b1);
@@ -1386,7 +1397,7 @@ int ba_residual_jacobian(ba_problem *p, double *r, double *J) {
   launch_station_prep(p->stream, p->S, p->d_eop, p->d_scale_sta, p->d_sta_cam, p->d_sta_c);
   CostArgs ca{};
   ca.N = p->N; ca.obs = p->d_obs; ca.sta = p->d_sta_c; ca.xyz = p->d_xyz; ca.obs_pt = p->d_obs_pt; ca.cam = p->d_cam;
-  ca.huber_a = p->huber_a; ca.model = p->model;
+  ca.huber_a = p->huber_a; ca.model = p->model; ca.emp = p->emp;
   launch_resjac_dense(p->stream, ca, d_r, d_J);
   int rc = p->check_kernels();
   if (!rc && hipStreamSynchronize(p->stream) != hipSuccess) rc = fail(BA_ERR_DEVICE, "residual/Jacobian kernel failed");
@@ -1414,7 +1425,7 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
   la.scale_pt = p->d_scale_pt; la.pt_prior = p->d_pt_prior; la.pt_isig = p->d_pt_isig; la.cam = p->d_cam;
   la.rec = p->d_rec; la.Jp = p->d_Jp; la.Jc = p->d_Jc; la.Mo = p->d_Mo; la.Vinv = p->d_Vinv; la.g_pt = p->d_g_pt;
   la.colnorm_pt = p->d_colnorm_pt; la.diag_pt = p->d_diag_pt; la.cost_partial = p->d_partial; la.flags = p->d_flags;
-  la.huber_a = p->huber_a; la.model = p->model; la.lm_min = st.lm_min; la.lm_max = st.lm_max; la.radius = st.radius; la.reuse_diag = 0;
+  la.huber_a = p->huber_a; la.model = p->model; la.emp = p->emp; la.lm_min = st.lm_min; la.lm_max = st.lm_max; la.radius = st.radius; la.reuse_diag = 0;
   la.Y = p->explicit_ok ? p->d_Y : nullptr;
   la.Jt = p->d_Jt;
   la.cam_partial = p->d_campart;
@@ -1438,7 +1449,7 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
   StationArgs sa = station_args(p, 7, 6);
   CostArgs ca{};
   ca.N = p->N; ca.obs = p->d_obs; ca.sta = p->d_sta; ca.xyz = p->d_xyz; ca.obs_pt = p->d_obs_pt; ca.cam = p->d_cam;
-  ca.huber_a = p->huber_a; ca.model = p->model; ca.partial = p->d_partial;
+  ca.huber_a = p->huber_a; ca.model = p->model; ca.emp = p->emp; ca.partial = p->d_partial;
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));

@@ -23,6 +23,7 @@
 #define BA_REC_STRIDE 16
 #define BA_Y_STRIDE 24  // 6 rows x (3 + 1 pad) doubles = 192 B = three 64-B sectors
 #define BA_NCAMPAR 19
+#define BA_NCAMPAR_BROWN 10  // xp yp c a1 a2 k1 k2 k3 p1 p2: the camera columns when no empirical term is in use
 #define BA_APSCALE 1000.0  // src/main.cpp:55
 
 struct ObsIn {
@@ -84,7 +85,9 @@ __device__ __forceinline__ CamIn load_cam(const CamRec *__restrict__ cam, int c)
 //   7 omnidirectional             model 2 with (|Xc|, |Yc|) for (Xc, Yc)      src/main.cpp:2737-2738
 // (model 0 through this path gives h = -1/Zc).  hr = (dh/drho)/rho and hz = dh/dZc give
 // d(x,y)/d(Xc,Yc,Zc) = c [ h I + hr (Xc,Yc)(Xc,Yc)^T | hz (Xc,Yc) ].
-template <bool JAC, bool GEN = false>
+// EMP = false leaves out the nine empirical terms AP[7..15] (all zero and none of them estimated): the residual is
+// the same number, dc0/dc1 then hold BA_NCAMPAR_BROWN entries only.
+template <bool JAC, bool GEN = false, bool EMP = true>
 __device__ __forceinline__ void eval_obs(const ObsIn &o, const double *__restrict__ st, const double X, const double Y,
                                          const double Z, const CamIn &cm, double &r0, double &r1, double *Js /*12*/,
                                          double *Jp /*6*/, double *dc0 /*19*/, double *dc1 /*19*/, const int model = 0) {
@@ -148,12 +151,24 @@ __device__ __forceinline__ void eval_obs(const ObsIn &o, const double *__restric
   const double xb = (o.x - cm.xp) / BA_APSCALE;  // :1357-1362
   const double yb = (o.y - cm.yp) / BA_APSCALE;
   const double rr = xb * xb + yb * yb;
-  const double rr2 = rr * rr, rr3 = rr2 * rr, rr4 = rr3 * rr, rr5 = rr4 * rr, rr6 = rr5 * rr, rr7 = rr6 * rr;
-  const double rr8 = rr7 * rr, rr9 = rr8 * rr, rr10 = rr9 * rr, rr11 = rr10 * rr, rr12 = rr11 * rr, rr13 = rr12 * rr;
+  const double rr2 = rr * rr, rr3 = rr2 * rr;
+  double rr4 = 0.0, rr5 = 0.0, rr6 = 0.0, rr7 = 0.0, rr8 = 0.0, rr9 = 0.0, rr10 = 0.0, rr11 = 0.0, rr12 = 0.0, rr13 = 0.0;
   const double *ap = cm.ap;
   // :1371-1376 (AP[10] multiplies rr^7 and rr^8)
-  const double G = ap[2] * rr + ap[3] * rr2 + ap[4] * rr3 + ap[7] * rr4 + ap[8] * rr5 + ap[9] * rr6 +
-                   ap[10] * (rr7 + rr8) + ap[11] * rr9 + ap[12] * rr10 + ap[13] * rr11 + ap[14] * rr12 + ap[15] * rr13;
+  double G = ap[2] * rr + ap[3] * rr2 + ap[4] * rr3;
+  if (EMP) {
+    rr4 = rr3 * rr; rr5 = rr4 * rr; rr6 = rr5 * rr; rr7 = rr6 * rr; rr8 = rr7 * rr; rr9 = rr8 * rr; rr10 = rr9 * rr;
+    rr11 = rr10 * rr; rr12 = rr11 * rr; rr13 = rr12 * rr;
+    G += ap[7] * rr4;  // one term at a time: the sum keeps its left-to-right order
+    G += ap[8] * rr5;
+    G += ap[9] * rr6;
+    G += ap[10] * (rr7 + rr8);
+    G += ap[11] * rr9;
+    G += ap[12] * rr10;
+    G += ap[13] * rr11;
+    G += ap[14] * rr12;
+    G += ap[15] * rr13;
+  }
   const double ddx = xb * G + ap[5] * (rr + 2.0 * xb * xb) + 2.0 * ap[6] * xb * yb + ap[0] * xb + ap[1] * yb;
   const double ddy = yb * G + ap[6] * (rr + 2.0 * yb * yb) + 2.0 * ap[5] * xb * yb;
   const double isx = 1.0 / o.sx, isy = 1.0 / o.sy;
@@ -191,9 +206,18 @@ __device__ __forceinline__ void eval_obs(const ObsIn &o, const double *__restric
   Js[3] = -Jp[0]; Js[4] = -Jp[1]; Js[5] = -Jp[2];
   Js[9] = -Jp[3]; Js[10] = -Jp[4]; Js[11] = -Jp[5];
   // camera block
-  const double dG = ap[2] + 2.0 * ap[3] * rr + 3.0 * ap[4] * rr2 + 4.0 * ap[7] * rr3 + 5.0 * ap[8] * rr4 +
-                    6.0 * ap[9] * rr5 + ap[10] * (7.0 * rr6 + 8.0 * rr7) + 9.0 * ap[11] * rr8 + 10.0 * ap[12] * rr9 +
-                    11.0 * ap[13] * rr10 + 12.0 * ap[14] * rr11 + 13.0 * ap[15] * rr12;
+  double dG = ap[2] + 2.0 * ap[3] * rr + 3.0 * ap[4] * rr2;
+  if (EMP) {
+    dG += 4.0 * ap[7] * rr3;
+    dG += 5.0 * ap[8] * rr4;
+    dG += 6.0 * ap[9] * rr5;
+    dG += ap[10] * (7.0 * rr6 + 8.0 * rr7);
+    dG += 9.0 * ap[11] * rr8;
+    dG += 10.0 * ap[12] * rr9;
+    dG += 11.0 * ap[13] * rr10;
+    dG += 12.0 * ap[14] * rr11;
+    dG += 13.0 * ap[15] * rr12;
+  }
   const double xy2 = 2.0 * xb * yb;
   const double dxx = G + 2.0 * xb * xb * dG + 6.0 * ap[5] * xb + 2.0 * ap[6] * yb + ap[0];
   const double dxy = xy2 * dG + 2.0 * ap[5] * yb + 2.0 * ap[6] * xb + ap[1];
@@ -216,6 +240,7 @@ __device__ __forceinline__ void eval_obs(const ObsIn &o, const double *__restric
   dc0[7] = xs * rr3;                dc1[7] = ys * rr3;                 // k3
   dc0[8] = (rr + 2.0 * xb * xb) * isx; dc1[8] = xy2 * isy;             // p1
   dc0[9] = xy2 * isx;               dc1[9] = (rr + 2.0 * yb * yb) * isy;  // p2
+  if (!EMP) return;
   dc0[10] = xs * rr4;               dc1[10] = ys * rr4;                // ep1
   dc0[11] = xs * rr5;               dc1[11] = ys * rr5;
   dc0[12] = xs * rr6;               dc1[12] = ys * rr6;

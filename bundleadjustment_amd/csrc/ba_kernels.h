@@ -29,6 +29,7 @@ struct LinArgs {
   double huber_a, lm_min, lm_max, radius;
   int reuse_diag;
   int model;  // projection, 0..7 (ba_inputs.model)
+  int emp;    // 0: no camera has an empirical term AP[7..15] that is free or non-zero (kernels then skip them)
 };
 
 struct PointArgs {
@@ -74,6 +75,7 @@ struct CostArgs {
   double huber_a;
   int apply_loss;
   int model;
+  int emp;  // as in LinArgs
   double *res_out;  // file order, may be null
   double *partial;
 };

@@ -58,9 +58,10 @@ __global__ void k_station_prep(int S, const double *__restrict__ eop, const doub
 #define LIN_NCB 8
 #define ELIM_STRIDE 40  // per point: u = V^-1 g (3) | L, V^-1 = L L^T (6) | pad (7) | Z = V^-1 B^T (LIN_NCB x 3)
 
-template <bool CAM1, bool GEN>
+template <bool CAM1, bool GEN, bool EMP>
 __global__ void __launch_bounds__(256)
 k_point_elim(LinArgs a) {
+  constexpr int NCP = EMP ? BA_NCAMPAR : BA_NCAMPAR_BROWN;  // camera columns that can be in use
   __shared__ double lds[8];
   const int jj = blockIdx.x * blockDim.x + threadIdx.x;
   double cost = 0.0;
@@ -70,16 +71,16 @@ k_point_elim(LinArgs a) {
     const double X = a.xyz[3 * (int64_t)jj], Y = a.xyz[3 * (int64_t)jj + 1], Z = a.xyz[3 * (int64_t)jj + 2];
     const double s0 = a.scale_pt[3 * (int64_t)jj], s1 = a.scale_pt[3 * (int64_t)jj + 1], s2 = a.scale_pt[3 * (int64_t)jj + 2];
     double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-    double B[CAM1 ? BA_NCAMPAR : 1][3];  // all camera columns; the free ones are picked at the end
+    double B[CAM1 ? NCP : 1][3];  // all camera columns; the free ones are picked at the end
 #pragma unroll
-    for (int k = 0; k < (CAM1 ? BA_NCAMPAR : 1); ++k) B[k][0] = B[k][1] = B[k][2] = 0.0;
+    for (int k = 0; k < (CAM1 ? NCP : 1); ++k) B[k][0] = B[k][1] = B[k][2] = 0.0;
     for (int e = e0; e < e1; ++e) {
       const ObsIn o = load_obs(a.obs, e);
       const double *st = a.sta + (int64_t)BA_STA_STRIDE * o.sta;
       const int c = __double2loint(st[20]);
       const CamIn cm = load_cam(a.cam, c);
-      double r0, r1, Js[12], Jp[6], dc0[BA_NCAMPAR], dc1[BA_NCAMPAR];
-      eval_obs<true, GEN>(o, st, X, Y, Z, cm, r0, r1, Js, Jp, dc0, dc1, a.model);
+      double r0, r1, Js[12], Jp[6], dc0[NCP], dc1[NCP];
+      eval_obs<true, GEN, EMP>(o, st, X, Y, Z, cm, r0, r1, Js, Jp, dc0, dc1, a.model);
       double sc;
       cost += 0.5 * huber_rho(a.huber_a, r0 * r0 + r1 * r1, sc);
       r0 *= sc;
@@ -98,7 +99,7 @@ k_point_elim(LinArgs a) {
       if (CAM1) {
         const uint32_t mask = a.cam[0].mask;
 #pragma unroll
-        for (int p = 0; p < BA_NCAMPAR; ++p)
+        for (int p = 0; p < NCP; ++p)
           if (mask & (1u << p)) {  // uniform: one camera
             const double c0 = dc0[p] * sc, c1 = dc1[p] * sc;
             B[p][0] += c0 * Jp[0] + c1 * Jp[3];
@@ -147,7 +148,7 @@ k_point_elim(LinArgs a) {
       const CamRec &cr = a.cam[0];
       int pos = 0;
 #pragma unroll
-      for (int p = 0; p < BA_NCAMPAR; ++p)
+      for (int p = 0; p < NCP; ++p)
         if (cr.mask & (1u << p)) {
           const double cs = cr.scale[pos];
           double z0, z1, z2;
@@ -188,16 +189,17 @@ __device__ __forceinline__ void tile_store(double *buf, const double (&v)[R], do
 }
 
 #define ROWS_LDS(CAM1) (64 * ((CAM1) ? 25 : 2 * BA_NCAMPAR + 1))
-template <bool CAM1, bool GEN>
+template <bool CAM1, bool GEN, bool EMP>
 __global__ void __launch_bounds__(256)
 k_obs_rows(LinArgs a) {
+  constexpr int NCP = EMP ? BA_NCAMPAR : BA_NCAMPAR_BROWN;
   __shared__ double lds[4][ROWS_LDS(CAM1)];
   __shared__ double lds_cam[4][2 * LIN_NCB];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   double *buf = lds[w];
-  double gc[CAM1 ? 2 * LIN_NCB : 1];
-#pragma unroll
-  for (int k = 0; k < (CAM1 ? 2 * LIN_NCB : 1); ++k) gc[k] = 0.0;
+  // sums of Jc^T r and Jc^T rhat over this wave's tiles: reduced across the wave tile by tile and kept in LDS
+  // (sixteen accumulators per lane across the tile loop would cost the second wave per SIMD)
+  if (CAM1 && lane < 2 * LIN_NCB) lds_cam[w][lane] = 0.0;
   const int64_t n_tiles = (a.N + 63) / 64;
   for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t e0 = tile * 64;
@@ -211,8 +213,8 @@ k_obs_rows(LinArgs a) {
     const CamIn cm = load_cam(a.cam, c);
     const double X = a.xyz[3 * (int64_t)jj], Y = a.xyz[3 * (int64_t)jj + 1], Z = a.xyz[3 * (int64_t)jj + 2];
     const double s0 = a.scale_pt[3 * (int64_t)jj], s1 = a.scale_pt[3 * (int64_t)jj + 1], s2 = a.scale_pt[3 * (int64_t)jj + 2];
-    double r0, r1, Js[12], Jp[6], dc0[BA_NCAMPAR], dc1[BA_NCAMPAR];
-    eval_obs<true, GEN>(o, st, X, Y, Z, cm, r0, r1, Js, Jp, dc0, dc1, a.model);
+    double r0, r1, Js[12], Jp[6], dc0[NCP], dc1[NCP];
+    eval_obs<true, GEN, EMP>(o, st, X, Y, Z, cm, r0, r1, Js, Jp, dc0, dc1, a.model);
     double sc;
     (void)huber_rho(a.huber_a, r0 * r0 + r1 * r1, sc);
     r0 *= sc;
@@ -229,7 +231,7 @@ k_obs_rows(LinArgs a) {
       }
       int pos = 0;
 #pragma unroll
-      for (int p = 0; p < BA_NCAMPAR; ++p) {
+      for (int p = 0; p < NCP; ++p) {
         if (cr.mask & (1u << p)) {
           const double cs = sc * cr.scale[pos];
           mine[pos] = dc0[p] * cs;
@@ -305,20 +307,18 @@ k_obs_rows(LinArgs a) {
         const bool free_k = k < a.ncmax;
         jt[k] = free_k ? c0[k] - (p0 * z0 + p1 * z1 + p2 * z2) : 0.0;
         jt[LIN_NCB + k] = free_k ? c1[k] - (p3 * z0 + p4 * z1 + p5 * z2) : 0.0;
-        if (on && free_k) {
-          gc[k] += c0[k] * r0 + c1[k] * r1;
-          gc[LIN_NCB + k] += c0[k] * h0 + c1[k] * h1;
+        if (free_k) {  // uniform: ncmax is a launch constant
+          const double g0 = wave_sum(on ? c0[k] * r0 + c1[k] * r1 : 0.0), g1 = wave_sum(on ? c0[k] * h0 + c1[k] * h1 : 0.0);
+          if (lane == 0) {
+            lds_cam[w][k] += g0;
+            lds_cam[w][LIN_NCB + k] += g1;
+          }
         }
       }
       tile_store<2 * LIN_NCB>(buf, jt, a.Jt + 2 * (int64_t)LIN_NCB * e0, lane, nvalid);
     }
   }
   if (CAM1) {
-#pragma unroll
-    for (int k = 0; k < 2 * LIN_NCB; ++k) {
-      const double v = wave_sum(gc[k]);
-      if (lane == 0) lds_cam[w][k] = v;
-    }
     __syncthreads();
     if (threadIdx.x < 2 * LIN_NCB)
       a.cam_partial[(int64_t)blockIdx.x * (2 * LIN_NCB) + threadIdx.x] =
@@ -719,7 +719,7 @@ __global__ void k_invert_blocks(int S, const double *__restrict__ src, const int
 // ------------------------------------------------------------------------------------------
 // cost at a candidate point (residuals only), src/main.cpp:1322-1388 + Huber
 // ------------------------------------------------------------------------------------------
-template <bool GEN>
+template <bool GEN, bool EMP>
 __global__ void __launch_bounds__(256)
 k_cost_obs(CostArgs a) {
   __shared__ double lds[8];
@@ -731,7 +731,7 @@ k_cost_obs(CostArgs a) {
     const int jj = a.obs_pt[e];
     const double *x = a.xyz + 3 * (int64_t)jj;
     double r0, r1;
-    eval_obs<false, GEN>(o, st, x[0], x[1], x[2], cm, r0, r1, nullptr, nullptr, nullptr, nullptr, a.model);
+    eval_obs<false, GEN, EMP>(o, st, x[0], x[1], x[2], cm, r0, r1, nullptr, nullptr, nullptr, nullptr, a.model);
     double sc;
     const double rho = huber_rho(a.huber_a, r0 * r0 + r1 * r1, sc);
     cost += 0.5 * rho;
@@ -1244,14 +1244,15 @@ void launch_linearize(hipStream_t s, const LinArgs &a, int part) {
   if (a.P <= 0) return;
   const dim3 gp(nblk(a.P, 256)), go(obs_rows_blocks(a.N)), b(256);
   const bool gen = a.model != 0;
-  void (*elim)(LinArgs), (*rows)(LinArgs);
-  if (a.Jt) {
-    elim = gen ? k_point_elim<true, true> : k_point_elim<true, false>;
-    rows = gen ? k_obs_rows<true, true> : k_obs_rows<true, false>;
-  } else {
-    elim = gen ? k_point_elim<false, true> : k_point_elim<false, false>;
-    rows = gen ? k_obs_rows<false, true> : k_obs_rows<false, false>;
-  }
+  // kernel variants: [single-camera fast path][general projection][empirical terms in use]
+  static void (*const elim_tab[2][2][2])(LinArgs) = {
+      {{k_point_elim<false, false, false>, k_point_elim<false, false, true>}, {k_point_elim<false, true, false>, k_point_elim<false, true, true>}},
+      {{k_point_elim<true, false, false>, k_point_elim<true, false, true>}, {k_point_elim<true, true, false>, k_point_elim<true, true, true>}}};
+  static void (*const rows_tab[2][2][2])(LinArgs) = {
+      {{k_obs_rows<false, false, false>, k_obs_rows<false, false, true>}, {k_obs_rows<false, true, false>, k_obs_rows<false, true, true>}},
+      {{k_obs_rows<true, false, false>, k_obs_rows<true, false, true>}, {k_obs_rows<true, true, false>, k_obs_rows<true, true, true>}}};
+  void (*elim)(LinArgs) = elim_tab[a.Jt ? 1 : 0][gen ? 1 : 0][a.emp ? 1 : 0];
+  void (*rows)(LinArgs) = rows_tab[a.Jt ? 1 : 0][gen ? 1 : 0][a.emp ? 1 : 0];
   if (part & 1) hipLaunchKernelGGL(elim, gp, b, 0, s, a);
   if (part & 2) hipLaunchKernelGGL(rows, go, b, 0, s, a);
 }
@@ -1318,7 +1319,8 @@ int cost_blocks(int64_t n) {
   return b < 1 ? 1 : (b > 4096 ? 4096 : b);
 }
 void launch_cost_obs(hipStream_t s, const CostArgs &a, int blocks) {
-  void (*k)(CostArgs) = a.model ? k_cost_obs<true> : k_cost_obs<false>;
+  void (*k)(CostArgs) = a.model ? (a.emp ? k_cost_obs<true, true> : k_cost_obs<true, false>)
+                                : (a.emp ? k_cost_obs<false, true> : k_cost_obs<false, false>);
   hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, s, a);
 }
 void launch_cost_prior(hipStream_t s, int P, const double *xyz, const double *prior, const double *isig, const int *pt_file,
