@@ -188,9 +188,30 @@ __device__ __forceinline__ void tile_store(double *buf, const double (&v)[R], do
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Sums sixteen values per lane over the wave with 17 exchanges instead of 96: at each of the steps 32, 16, 8, 4 a lane
+// keeps one half of what it holds and takes the partner's share of that half, so the data halves while the number of
+// lanes summed doubles; two plain steps finish.  On return lane l holds the total of value
+// 8 b5 + 4 b4 + 2 b3 + b2 (b = bits of l); the four lanes of a quad hold the same.
+__device__ __forceinline__ double wave_sum16(const double (&v)[16], int lane) {
+  double a[8], b[4], c[2], d;
+  const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = (h5 ? v[8 + k] : v[k]) + __shfl_xor(h5 ? v[k] : v[8 + k], 32, 64);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) b[k] = (h4 ? a[4 + k] : a[k]) + __shfl_xor(h4 ? a[k] : a[4 + k], 16, 64);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) c[k] = (h3 ? b[2 + k] : b[k]) + __shfl_xor(h3 ? b[k] : b[2 + k], 8, 64);
+  d = (h2 ? c[1] : c[0]) + __shfl_xor(h2 ? c[0] : c[1], 4, 64);
+  d += __shfl_xor(d, 2, 64);
+  d += __shfl_xor(d, 1, 64);
+  return d;
+}
+
 #define ROWS_LDS(CAM1) (64 * ((CAM1) ? 25 : 2 * BA_NCAMPAR + 1))
+// Two waves per SIMD where the register budget of that allows it without spilling (one register short otherwise): the
+// collinearity projection without the empirical terms.  The other variants keep one wave with the full register file.
 template <bool CAM1, bool GEN, bool EMP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((GEN || EMP) ? 1 : 2)))
 k_obs_rows(LinArgs a) {
   constexpr int NCP = EMP ? BA_NCAMPAR : BA_NCAMPAR_BROWN;
   __shared__ double lds[4][ROWS_LDS(CAM1)];
@@ -300,22 +321,28 @@ k_obs_rows(LinArgs a) {
       tile_store<24>(buf, y, a.Y + (int64_t)BA_Y_STRIDE * e0, lane, nvalid);
     }
     if (CAM1) {
-      double jt[2 * LIN_NCB];
+      {
+        double jt[2 * LIN_NCB];
 #pragma unroll
-      for (int k = 0; k < LIN_NCB; ++k) {
-        const double z0 = el[16 + 3 * k], z1 = el[17 + 3 * k], z2 = el[18 + 3 * k];
-        const bool free_k = k < a.ncmax;
-        jt[k] = free_k ? c0[k] - (p0 * z0 + p1 * z1 + p2 * z2) : 0.0;
-        jt[LIN_NCB + k] = free_k ? c1[k] - (p3 * z0 + p4 * z1 + p5 * z2) : 0.0;
-        if (free_k) {  // uniform: ncmax is a launch constant
-          const double g0 = wave_sum(on ? c0[k] * r0 + c1[k] * r1 : 0.0), g1 = wave_sum(on ? c0[k] * h0 + c1[k] * h1 : 0.0);
-          if (lane == 0) {
-            lds_cam[w][k] += g0;
-            lds_cam[w][LIN_NCB + k] += g1;
-          }
+        for (int k = 0; k < LIN_NCB; ++k) {
+          const double z0 = el[16 + 3 * k], z1 = el[17 + 3 * k], z2 = el[18 + 3 * k];
+          const bool free_k = k < a.ncmax;
+          jt[k] = free_k ? c0[k] - (p0 * z0 + p1 * z1 + p2 * z2) : 0.0;
+          jt[LIN_NCB + k] = free_k ? c1[k] - (p3 * z0 + p4 * z1 + p5 * z2) : 0.0;
         }
+        tile_store<2 * LIN_NCB>(buf, jt, a.Jt + 2 * (int64_t)LIN_NCB * e0, lane, nvalid);
       }
-      tile_store<2 * LIN_NCB>(buf, jt, a.Jt + 2 * (int64_t)LIN_NCB * e0, lane, nvalid);
+      {
+        double gsum[2 * LIN_NCB];
+#pragma unroll
+        for (int k = 0; k < LIN_NCB; ++k) {
+          const bool use = on && k < a.ncmax;
+          gsum[k] = use ? c0[k] * r0 + c1[k] * r1 : 0.0;
+          gsum[LIN_NCB + k] = use ? c0[k] * h0 + c1[k] * h1 : 0.0;
+        }
+        const double tot = wave_sum16(gsum, lane);
+        if ((lane & 3) == 0) lds_cam[w][((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1)] += tot;
+      }
     }
   }
   if (CAM1) {
