@@ -462,8 +462,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   if (single_camera_path) {
     // single camera with few free parameters: the linearisation kernel also produces the camera border's inputs
     BA_TRY(p->dalloc(&p->d_Jt, 2 * (size_t)border_ncb() * N));
-    const size_t ncorner = (size_t)border_ncb() * (border_ncb() + 1) / 2;
-    BA_TRY(p->dalloc(&p->d_campart, std::max((size_t)obs_rows_blocks(N) * 2 * lin_ncb(), (size_t)camera_corner_blocks(N) * ncorner)));
+    BA_TRY(p->dalloc(&p->d_campart, (size_t)obs_rows_blocks(N) * lin_npart()));
   }
   p->n_partial = 4 * std::max(std::max(linearize_blocks(P), cost_blocks(N)), cost_blocks(6 * (int64_t)S + 3 * (int64_t)P)) + 16;
   BA_TRY(p->dalloc(&p->d_partial, (size_t)p->n_partial));
@@ -681,7 +680,7 @@ int build_reduced(ba_problem *p, bool explicit_blocks) {
     StationArgs sa = station_args(p, 6, border_nacc());
     launch_border_station(s, sa, p->d_Jt);
     launch_border_fold(s, p->S, p->ncam, p->n_chunks, p->d_sta_chunk0, p->d_part, border_nacc(), p->d_Ssc);
-    launch_camera_corner(s, p->N, p->ncmax, p->d_Jc, p->d_Jt, p->d_campart, p->d_corner);
+    launch_camera_corner_fold(s, p->d_campart, obs_rows_blocks(p->N), p->d_corner);  // the sums come out of k_obs_rows
     BA_TRY(p->allreduce(p->d_Ssc, (int64_t)ns * p->ncam, 0));
     BA_TRY(p->allreduce(p->d_corner, border_ncb() * (border_ncb() + 1) / 2, 0));
     launch_border_corner(s, p->ncam, p->d_corner, p->d_diagfull + ns, p->d_Scc);

@@ -103,8 +103,8 @@ int lin_ncb();
 int elim_stride();
 int obs_rows_blocks(int64_t N);
 void launch_camera_rows_fold(hipStream_t s, const double *cam_partial, int nblocks, int ncam, double *out_g, double *out_b);
-int camera_corner_blocks(int64_t N);
-void launch_camera_corner(hipStream_t s, int64_t N, int ncmax, const double *Jc, const double *Jt, double *part, double *corner);
+int lin_npart();
+void launch_camera_corner_fold(hipStream_t s, const double *cam_partial, int nblocks, double *corner);
 void launch_point_pass(hipStream_t s, const PointArgs &a, int mode, bool withcam);
 void launch_station_pass(hipStream_t s, const StationArgs &a, int smode);
 void launch_station_fold(hipStream_t s, int S, const int *sta_chunk0, const double *part, int stride, int ncols, double *out);

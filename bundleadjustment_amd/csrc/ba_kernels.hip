@@ -56,6 +56,8 @@ __global__ void k_station_prep(int S, const double *__restrict__ eop, const doub
 // camera rows Jt = Jc - Jp V^-1 B^T and per-workgroup partial sums of Jc^T r (gradient) and
 // Jc^T rhat (reduced right-hand side), so that no further sweep is needed for those.
 #define LIN_NCB 8
+#define LIN_NCORNER (LIN_NCB * (LIN_NCB + 1) / 2)
+#define LIN_NPART (2 * LIN_NCB + 48)  // per-workgroup partials of k_obs_rows: Jc^T r | Jc^T rhat | upper triangle of Jc^T Jt (36 of 48)
 #define ELIM_STRIDE 40  // per point: u = V^-1 g (3) | L, V^-1 = L L^T (6) | pad (7) | Z = V^-1 B^T (LIN_NCB x 3)
 
 template <bool CAM1, bool GEN, bool EMP>
@@ -215,12 +217,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((GEN |
 k_obs_rows(LinArgs a) {
   constexpr int NCP = EMP ? BA_NCAMPAR : BA_NCAMPAR_BROWN;
   __shared__ double lds[4][ROWS_LDS(CAM1)];
-  __shared__ double lds_cam[4][2 * LIN_NCB];
+  __shared__ double lds_cam[4][LIN_NPART];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   double *buf = lds[w];
   // sums of Jc^T r and Jc^T rhat over this wave's tiles: reduced across the wave tile by tile and kept in LDS
   // (sixteen accumulators per lane across the tile loop would cost the second wave per SIMD)
-  if (CAM1 && lane < 2 * LIN_NCB) lds_cam[w][lane] = 0.0;
+  if (CAM1) lds_cam[w][lane] = 0.0;  // LIN_NPART == 64
   const int64_t n_tiles = (a.N + 63) / 64;
   for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t e0 = tile * 64;
@@ -331,6 +333,24 @@ k_obs_rows(LinArgs a) {
           jt[LIN_NCB + k] = free_k ? c1[k] - (p3 * z0 + p4 * z1 + p5 * z2) : 0.0;
         }
         tile_store<2 * LIN_NCB>(buf, jt, a.Jt + 2 * (int64_t)LIN_NCB * e0, lane, nvalid);
+        // corner of the camera border: upper triangle of Jc^T Jt, 36 sums in three reductions of 16
+        const int slot = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+          double cs[16];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            // entry idx = 16 part + q of the row-major upper triangle: (k, m), k <= m
+            constexpr int tri_k[48] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 3, 3, 3,
+                                       3, 3, 4, 4, 4, 4, 5, 5, 5, 6, 6, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            constexpr int tri_m[48] = {0, 1, 2, 3, 4, 5, 6, 7, 1, 2, 3, 4, 5, 6, 7, 2, 3, 4, 5, 6, 7, 3, 4, 5,
+                                       6, 7, 4, 5, 6, 7, 5, 6, 7, 6, 7, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const int idx = 16 * part + q;
+            cs[q] = (idx < LIN_NCORNER && on) ? c0[tri_k[idx]] * jt[tri_m[idx]] + c1[tri_k[idx]] * jt[LIN_NCB + tri_m[idx]] : 0.0;
+          }
+          const double tot = wave_sum16(cs, lane);
+          if ((lane & 3) == 0) lds_cam[w][2 * LIN_NCB + 16 * part + slot] += tot;
+        }
       }
       {
         double gsum[2 * LIN_NCB];
@@ -347,52 +367,10 @@ k_obs_rows(LinArgs a) {
   }
   if (CAM1) {
     __syncthreads();
-    if (threadIdx.x < 2 * LIN_NCB)
-      a.cam_partial[(int64_t)blockIdx.x * (2 * LIN_NCB) + threadIdx.x] =
+    if (threadIdx.x < LIN_NPART)
+      a.cam_partial[(int64_t)blockIdx.x * LIN_NPART + threadIdx.x] =
           (lds_cam[0][threadIdx.x] + lds_cam[1][threadIdx.x]) + (lds_cam[2][threadIdx.x] + lds_cam[3][threadIdx.x]);
   }
-}
-
-// corner of the camera border: upper triangle of sum Jc^T Jt over all observations, one lane per
-// observation (both arrays are read as whole lines), per-workgroup partial sums
-#define LIN_NCORNER (LIN_NCB * (LIN_NCB + 1) / 2)
-__global__ void __launch_bounds__(256)
-k_camera_corner(int64_t N, int ncmax, const double *__restrict__ Jc, const double *__restrict__ Jt, double *__restrict__ part) {
-  __shared__ double lds[4][LIN_NCORNER];
-  double acc[LIN_NCORNER];
-#pragma unroll
-  for (int k = 0; k < LIN_NCORNER; ++k) acc[k] = 0.0;
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < N; e += (int64_t)gridDim.x * blockDim.x) {
-    const double *jc = Jc + 2 * (int64_t)ncmax * e;
-    const double2 *jt = reinterpret_cast<const double2 *>(Jt + 2 * (int64_t)LIN_NCB * e);
-    double c0[LIN_NCB], c1[LIN_NCB], t0[LIN_NCB], t1[LIN_NCB];
-#pragma unroll
-    for (int k = 0; k < LIN_NCB; ++k) {
-      c0[k] = (k < ncmax) ? jc[k] : 0.0;
-      c1[k] = (k < ncmax) ? jc[ncmax + k] : 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < LIN_NCB / 2; ++k) {
-      const double2 x = jt[k], y = jt[LIN_NCB / 2 + k];
-      t0[2 * k] = x.x; t0[2 * k + 1] = x.y;
-      t1[2 * k] = y.x; t1[2 * k + 1] = y.y;
-    }
-    int idx = 0;
-#pragma unroll
-    for (int k = 0; k < LIN_NCB; ++k)
-#pragma unroll
-      for (int m = k; m < LIN_NCB; ++m) acc[idx++] += c0[k] * t0[m] + c1[k] * t1[m];
-  }
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < LIN_NCORNER; ++k) {
-    const double v = wave_sum(acc[k]);
-    if (lane == 0) lds[w][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < LIN_NCORNER)
-    part[(int64_t)blockIdx.x * LIN_NCORNER + threadIdx.x] =
-        (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
 }
 
 // out[k] = sum over rows of part[row][k]: one workgroup per column, fixed order
@@ -1288,18 +1266,13 @@ int lin_ncb() { return LIN_NCB; }
 // camera rows of the gradient (out_g) and of the reduced right-hand side (out_b) from the partials
 // that k_linearize<true> left; out arrays have ncam entries
 void launch_camera_rows_fold(hipStream_t s, const double *cam_partial, int nblocks, int ncam, double *out_g, double *out_b) {
-  hipLaunchKernelGGL(k_fold_columns, dim3(LIN_NCB), dim3(256), 0, s, cam_partial, nblocks, 2 * LIN_NCB, ncam, out_g);
-  hipLaunchKernelGGL(k_fold_columns, dim3(LIN_NCB), dim3(256), 0, s, cam_partial + LIN_NCB, nblocks, 2 * LIN_NCB, ncam, out_b);
+  hipLaunchKernelGGL(k_fold_columns, dim3(LIN_NCB), dim3(256), 0, s, cam_partial, nblocks, LIN_NPART, ncam, out_g);
+  hipLaunchKernelGGL(k_fold_columns, dim3(LIN_NCB), dim3(256), 0, s, cam_partial + LIN_NCB, nblocks, LIN_NPART, ncam, out_b);
 }
-int camera_corner_blocks(int64_t N) {
-  const int b = nblk(N, 256);
-  return b < 1 ? 1 : (b > 2048 ? 2048 : b);
-}
-// corner[0 .. NCB(NCB+1)/2) = upper triangle of sum Jc^T Jt
-void launch_camera_corner(hipStream_t s, int64_t N, int ncmax, const double *Jc, const double *Jt, double *part, double *corner) {
-  const int nb = camera_corner_blocks(N);
-  hipLaunchKernelGGL(k_camera_corner, dim3(nb), dim3(256), 0, s, N, ncmax, Jc, Jt, part);
-  hipLaunchKernelGGL(k_fold_columns, dim3(LIN_NCORNER), dim3(256), 0, s, part, nb, LIN_NCORNER, LIN_NCORNER, corner);
+int lin_npart() { return LIN_NPART; }
+// corner[0 .. NCB(NCB+1)/2) = upper triangle of sum Jc^T Jt, from the partials that k_obs_rows<true> left
+void launch_camera_corner_fold(hipStream_t s, const double *cam_partial, int nblocks, double *corner) {
+  hipLaunchKernelGGL(k_fold_columns, dim3(LIN_NCORNER), dim3(256), 0, s, cam_partial + 2 * LIN_NCB, nblocks, LIN_NPART, LIN_NCORNER, corner);
 }
 void launch_point_pass(hipStream_t s, const PointArgs &a, int mode, bool withcam) {
   if (a.P <= 0) return;
