@@ -538,7 +538,7 @@ StationArgs station_args(ba_problem *p, int voff, int stride) {
 PointArgs point_args(ba_problem *p, const double *vec) {
   PointArgs a{};
   a.P = p->P; a.S = p->S; a.ncmax = p->ncmax;
-  a.pt_start = p->d_pt_start; a.obs_sta = p->d_obs_sta; a.sta_cam = p->d_sta_cam;
+  a.pt_start = p->d_pt_start; a.obs_sta = p->d_obs_sta; a.sta_cam = p->d_sta_cam; a.obs_pt = p->d_obs_pt;
   a.obs = p->d_obs; a.sta = p->d_sta; a.Jp = p->d_Jp; a.Jc = p->d_Jc; a.Vinv = p->d_Vinv;
   a.vec = vec; a.cam = p->d_cam; a.rec = p->d_rec;
   a.g_pt = p->d_g_pt; a.xyz = p->d_xyz; a.pt_prior = p->d_pt_prior; a.pt_isig = p->d_pt_isig; a.scale_pt = p->d_scale_pt;

@@ -34,7 +34,7 @@ struct LinArgs {
 
 struct PointArgs {
   int P, S, ncmax;
-  const int *pt_start, *obs_sta, *sta_cam;  // obs_sta: station of each observation in point-sorted order
+  const int *pt_start, *obs_sta, *sta_cam, *obs_pt;  // obs_sta, obs_pt: station and point of each observation in point-sorted order
   const double *obs, *sta, *Jp, *Jc, *Vinv, *vec;
   const CamRec *cam;
   double *rec;

@@ -492,6 +492,117 @@ k_point_pass(PointArgs a) {
   }
 }
 
+// Back substitution with the observation rows read the way they lie in memory.  A wave owns 64 consecutive points
+// and therefore one contiguous run of observations.  It walks that run 64 observations at a time, one lane per
+// observation (a = Js y_i + Jc y_c and Jp^T a from whole records), hands the three sums of each observation to the
+// lane that owns its point through LDS, and after u = Vinv (g - sum Jp^T a) walks the run once more for the model
+// cost change.  The products a stay in LDS when the run has at most BS_RUN observations, else in the work slot of the
+// row.  Same sums in the same order as the lane-per-point walk; what changes is that every record is fetched once.
+#define BS_RUN 512
+template <bool WITHCAM>
+__global__ void __launch_bounds__(256)
+k_backsub_tiles(PointArgs a) {
+  __shared__ double lds[8];
+  __shared__ double lds_c[4][64 * 3];
+  __shared__ double lds_u[4][64 * 3];
+  __shared__ double2 lds_a[4][BS_RUN];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int jj0 = (blockIdx.x * 4 + w) * 64;
+  const int jj = jj0 + lane;
+  const bool has_pt = jj < a.P;
+  double acc = 0.0;
+  if (jj0 < a.P) {  // whole waves only
+    const int jend = min(jj0 + 64, a.P);
+    const int eb = a.pt_start[jj0], ee = a.pt_start[jend];
+    const int e0 = has_pt ? a.pt_start[jj] : ee, e1 = has_pt ? a.pt_start[jj + 1] : ee;
+    const bool fits = ee - eb <= BS_RUN;
+    double t0 = 0, t1 = 0, t2 = 0;
+    for (int base = eb; base < ee; base += 64) {
+      const int e = base + lane;
+      const bool on = e < ee;
+      double c0 = 0, c1 = 0, c2 = 0;
+      if (on) {
+        double2 *rec = reinterpret_cast<double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
+        const int sta = a.obs_sta[e];
+        const double2 *pv = reinterpret_cast<const double2 *>(a.vec + 6 * (int64_t)sta);
+        const double2 v0 = pv[0], v1 = pv[1], v2 = pv[2];
+        const double2 j0 = rec[0], j1 = rec[1], j2 = rec[2], j3 = rec[3], j4 = rec[4], j5 = rec[5];
+        double a0 = j0.x * v0.x + j0.y * v0.y + j1.x * v1.x + j1.y * v1.y + j2.x * v2.x + j2.y * v2.y;
+        double a1 = j3.x * v0.x + j3.y * v0.y + j4.x * v1.x + j4.y * v1.y + j5.x * v2.x + j5.y * v2.y;
+        if (WITHCAM) {
+          const int c = a.sta_cam[sta];
+          const int nc = a.cam[c].nc, off = a.cam[c].off;
+          const double *jc = a.Jc + 2 * (int64_t)a.ncmax * e;
+          const double *vc = a.vec + 6 * (int64_t)a.S + off;
+          for (int k = 0; k < nc; ++k) {
+            a0 += jc[k] * vc[k];
+            a1 += jc[a.ncmax + k] * vc[k];
+          }
+        }
+        const double2 *jp = reinterpret_cast<const double2 *>(a.Jp + 6 * (int64_t)e);
+        const double2 q0 = jp[0], q1 = jp[1], q2 = jp[2];
+        c0 = q0.x * a0 + q1.y * a1;
+        c1 = q0.y * a0 + q2.x * a1;
+        c2 = q1.x * a0 + q2.y * a1;
+        if (fits) lds_a[w][e - eb] = make_double2(a0, a1);
+        else rec[7] = make_double2(a0, a1);
+      }
+      lds_c[w][3 * lane] = c0;
+      lds_c[w][3 * lane + 1] = c1;
+      lds_c[w][3 * lane + 2] = c2;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int q_lo = max(e0, base), q_hi = min(e1, base + 64);
+      for (int q = q_lo; q < q_hi; ++q) {  // this point's observations of the chunk, in order
+        t0 += lds_c[w][3 * (q - base)];
+        t1 += lds_c[w][3 * (q - base) + 1];
+        t2 += lds_c[w][3 * (q - base) + 2];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    double u0 = 0, u1 = 0, u2 = 0;
+    if (has_pt) {
+      const double *vi = a.Vinv + 6 * (int64_t)jj;
+      const double Vi[6] = {vi[0], vi[1], vi[2], vi[3], vi[4], vi[5]};
+      const double *g = a.g_pt + 3 * (int64_t)jj;
+      sym3_mul(Vi, g[0] - t0, g[1] - t1, g[2] - t2, u0, u1, u2);
+      double *yo = a.y_pt + 3 * (int64_t)jj;
+      yo[0] = u0; yo[1] = u1; yo[2] = u2;
+      // prior rows of this point
+      const double *pr = a.pt_prior + 3 * (int64_t)jj, *is = a.pt_isig + 3 * (int64_t)jj;
+      const double *x = a.xyz + 3 * (int64_t)jj, *sp = a.scale_pt + 3 * (int64_t)jj;
+      const double m0 = -is[0] * sp[0] * u0, m1 = -is[1] * sp[1] * u1, m2 = -is[2] * sp[2] * u2;
+      acc += m0 * ((x[0] - pr[0]) * is[0] + 0.5 * m0) + m1 * ((x[1] - pr[1]) * is[1] + 0.5 * m1) +
+             m2 * ((x[2] - pr[2]) * is[2] + 0.5 * m2);
+    }
+    lds_u[w][3 * lane] = u0;
+    lds_u[w][3 * lane + 1] = u1;
+    lds_u[w][3 * lane + 2] = u2;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int base = eb; base < ee; base += 64) {
+      const int e = base + lane;
+      if (e < ee) {
+        const int pl = a.obs_pt[e] - jj0;  // the lane that owns this observation's point
+        const double w0 = lds_u[w][3 * pl], w1 = lds_u[w][3 * pl + 1], w2 = lds_u[w][3 * pl + 2];
+        const double2 *rec = reinterpret_cast<const double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
+        const double2 *jp = reinterpret_cast<const double2 *>(a.Jp + 6 * (int64_t)e);
+        const double2 q0 = jp[0], q1 = jp[1], q2 = jp[2];
+        const double2 sv = fits ? lds_a[w][e - eb] : rec[7], r = rec[6];
+        const double m0 = -(sv.x + q0.x * w0 + q0.y * w1 + q1.x * w2);
+        const double m1 = -(sv.y + q1.y * w0 + q2.x * w1 + q2.y * w2);
+        acc += m0 * (r.x + 0.5 * m0) + m1 * (r.y + 0.5 * m1);
+      }
+    }
+  }
+  const double t = block_sum(acc, lds);
+  if (threadIdx.x == 0) a.partial[blockIdx.x] = t;
+}
+
 // ------------------------------------------------------------------------------------------
 // station sweep
 // ------------------------------------------------------------------------------------------
@@ -1281,8 +1392,8 @@ void launch_point_pass(hipStream_t s, const PointArgs &a, int mode, bool withcam
     if (withcam) hipLaunchKernelGGL((k_point_pass<MODE_APPLY, true>), g, b, 0, s, a);
     else hipLaunchKernelGGL((k_point_pass<MODE_APPLY, false>), g, b, 0, s, a);
   } else {
-    if (withcam) hipLaunchKernelGGL((k_point_pass<MODE_BACKSUB, true>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((k_point_pass<MODE_BACKSUB, false>), g, b, 0, s, a);
+    if (withcam) hipLaunchKernelGGL(k_backsub_tiles<true>, g, b, 0, s, a);
+    else hipLaunchKernelGGL(k_backsub_tiles<false>, g, b, 0, s, a);
   }
 }
 void launch_station_pass(hipStream_t s, const StationArgs &a, int smode) {
