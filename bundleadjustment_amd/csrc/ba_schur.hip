@@ -646,7 +646,19 @@ void launch_border_corner(hipStream_t s, int ncam, const double *corner, const d
 int cg2_blocks_spmv(int S) {
   // one resident round of workgroups; also bounds the partials the vector kernel folds (32 loads per thread)
   const int nb = nblk(S, SPMV_WAVES);
-  return nb > 512 ? 512 : nb;
+  // as many workgroups as the device holds at once (three per CU on MI355X: 768; a fourth hundred would wait for a
+  // second round and costs 10 %), at most the 1024 partials the fold takes
+  static int cap = 0;
+  if (!cap) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bsr_spmv, 64 * SPMV_WAVES, 0) == hipSuccess && cus > 0 && per_cu > 0)
+      cap = std::min(1024, cus * per_cu);
+    else
+      cap = 512;
+    (void)hipGetLastError();
+  }
+  return nb > cap ? cap : nb;
 }
 int cg2_blocks_vec(int S) { return nblk(S, 256) > 0 ? nblk(S, 256) : 1; }
 void launch_cg2_init(hipStream_t s, const BsrCgArgs &a, double rtol) {
