@@ -1360,6 +1360,50 @@ int ba_covariance(ba_problem *p, double *var_eop, double *var_xyz, double *var_i
   return 0;
 }
 
+int ba_covariance_cameras(ba_problem *p, double *var_iop, double *var_ap) {
+  if (!p) return fail(BA_ERR_INVALID, "ba_covariance_cameras: null problem");
+  if (!p->have_params) return fail(BA_ERR_INVALID, "ba_covariance_cameras: no parameters set");
+  if (p->ncam > 0 && !p->explicit_ok)
+    return fail(BA_ERR_UNSUPPORTED, "ba_covariance_cameras: needs the explicit block-sparse reduced system (pattern too dense for it)");
+  hipStream_t s = p->stream;
+  ba_options opt;
+  ba_default_options(&opt);
+  std::vector<double> var((size_t)std::max(p->ncam, 1), 0.0), scale((size_t)std::max(p->ncam, 1), 1.0);
+  if (p->ncam > 0) {
+    // as ba_covariance: Jacobi scaling for the conditioning (undone below), no damping; then column k of the
+    // camera corner of S^-1 is the camera part of the solution of S x = e_k
+    BA_TRY(init_scaling(p, &opt));
+    LmState st{1e300, opt.min_lm_diagonal, opt.max_lm_diagonal, false, false, 2};
+    BA_TRY(linearize(p, st));
+    HIP_OK(hipMemcpyAsync(scale.data(), p->d_scale_cam, p->ncam * sizeof(double), hipMemcpyDeviceToHost, s));
+    const int64_t o = 6 * (int64_t)p->S;
+    for (int k = 0; k < p->ncam; ++k) {
+      launch_unit(s, p->nr, p->d_b, o + k);
+      int iters = 0;
+      BA_TRY(solve_pcg_explicit(p, &opt, &iters));
+      HIP_OK(hipMemcpyAsync(&var[k], p->d_x + o + k, sizeof(double), hipMemcpyDeviceToHost, s));
+      HIP_OK(hipStreamSynchronize(s));
+      if (!(var[k] > 0.0) || !std::isfinite(var[k]))
+        return fail(BA_ERR_NUMERIC, "ba_covariance_cameras: camera column %d: the reduced normal matrix is not positive definite", k);
+    }
+    BA_TRY(p->check_kernels());
+  }
+  for (int c = 0; c < p->C; ++c) {
+    const CamRec &r = p->cam_h[c];
+    if (var_iop) var_iop[3 * c] = var_iop[3 * c + 1] = var_iop[3 * c + 2] = 0.0;
+    if (var_ap) std::fill(var_ap + 16 * (size_t)c, var_ap + 16 * (size_t)c + 16, 0.0);
+    int pos = 0;
+    for (int q = 0; q < BA_NCAMPAR; ++q) {
+      if (!(r.mask & (1u << q))) continue;
+      const double v = var[r.off + pos] * scale[r.off + pos] * scale[r.off + pos];
+      if (q < 3) { if (var_iop) var_iop[3 * c + q] = v; }
+      else if (var_ap) var_ap[16 * (size_t)c + q - 3] = v;
+      ++pos;
+    }
+  }
+  return 0;
+}
+
 int ba_evaluate(ba_problem *p, const double *eop, const double *xyz, const double *iop, const double *ap, int apply_loss,
                 double *cost, double *residuals) {
   if (!p) return fail(BA_ERR_INVALID, "ba_evaluate: null problem");

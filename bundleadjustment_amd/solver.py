@@ -18,7 +18,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, c_double_p, C.c_int64, C.c_int32
 KERNEL_LINEARIZE, KERNEL_POINT_APPLY, KERNEL_STATION_GATHER, KERNEL_COST = 0, 1, 2, 3
 
 # every entry point include/ba_gpu.h declares
-EXPORTS = ("ba_default_options", "ba_create", "ba_destroy", "ba_set_parameters", "ba_get_parameters", "ba_set_corrections",
+EXPORTS = ("ba_default_options", "ba_create", "ba_destroy", "ba_set_parameters", "ba_get_parameters", "ba_set_corrections", "ba_covariance_cameras",
            "ba_solve_resident", "ba_solve", "ba_evaluate", "ba_covariance", "ba_sparsity", "ba_residual_jacobian", "ba_time_kernel",
            "ba_set_allreduce", "ba_copy_to_host", "ba_copy_to_device", "ba_rccl_unique_id", "ba_use_rccl", "ba_last_error")
 
@@ -50,6 +50,7 @@ def lib():
         L.ba_set_parameters.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]
         L.ba_get_parameters.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]
         L.ba_set_corrections.argtypes = [C.c_void_p, c_double_p, c_double_p]
+        L.ba_covariance_cameras.argtypes = [C.c_void_p, c_double_p, c_double_p]
         L.ba_solve_resident.argtypes = [C.c_void_p, C.POINTER(BaOptions), C.POINTER(BaSummary), C.POINTER(BaIterRow), C.c_int32]
         L.ba_solve.argtypes = [C.c_void_p, C.POINTER(BaOptions), c_double_p, c_double_p, c_double_p, c_double_p,
                                C.POINTER(BaSummary), C.POINTER(BaIterRow), C.c_int32]
@@ -158,6 +159,13 @@ class Problem:
         _check(lib().ba_evaluate(self._h, _dp(eop), _dp(xyz), _dp(iop), _dp(ap), int(bool(apply_loss)), C.byref(cost),
                                  _dp(res) if residuals else None))
         return cost.value, res
+
+    def covariance_cameras(self):
+        """(var_iop [C,3], var_ap [C,16]) at the parameters the problem holds; works for networks of any size."""
+        n = self.net
+        vi, va = np.zeros((n.n_cam, 3)), np.zeros((n.n_cam, 16))
+        _check(lib().ba_covariance_cameras(self._h, _dp(vi), _dp(va)))
+        return vi, va
 
     def covariance(self):
         """Variances of all parameters at the values the problem holds: (var_eop [S,6], var_xyz [P,3], var_iop [C,3], var_ap [C,16])."""

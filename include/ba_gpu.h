@@ -231,6 +231,13 @@ int ba_evaluate(ba_problem *p, const double *eop, const double *xyz, const doubl
 int ba_covariance(ba_problem *p, double *var_eop, double *var_xyz, double *var_iop, double *var_ap);
 
 /*
+ * The camera part of the same: variances of xp, yp, c [3*n_cam] and of the additional parameters [16*n_cam] only
+ * (src/main.cpp:5459-5565, the figures a self-calibration is run for), for networks of any size.  One solve of the
+ * reduced system per free camera parameter (right-hand side e_k, PCG to 1e-12) instead of the dense inverse.
+ */
+int ba_covariance_cameras(ba_problem *p, double *var_iop, double *var_ap);
+
+/*
  * Structure of the Jacobian that problem.Evaluate(..., &jacobian) returns at
  * src/main.cpp:6664 as a ceres::CRSMatrix: rows[] has num_rows+1 offsets, cols[] the column
  * of every structural non-zero.  Call with rows == cols == NULL to get the sizes.

@@ -185,6 +185,42 @@ def test_covariance_after_the_solve(which):
         assert np.all(np.abs(g[nz] - w[nz]) <= 1e-7 * w[nz]), (name, np.max(np.abs(g[nz] - w[nz]) / w[nz]))
 
 
+@pytest.mark.parametrize("which", ["cfg1", "three_cameras"])
+def test_camera_variances_by_iterative_solves_equal_the_dense_inverse(which):
+    # ba_covariance_cameras (one PCG solve per camera column) against ba_covariance (dense inverse); 1e-6: the PCG
+    # stops at a relative residual of 1e-12 and the condition number of these networks takes the rest
+    if which == "cfg1":
+        net = host.synth_config("cfg1").net
+    else:
+        net = host.synth(n_cam=3, n_sta=12, n_pts=150, rays_per_point=6, ap_free_mask=host.AP_K1K2P1P2, seed=5).net
+    with solver.Problem(net) as P:
+        P.set_parameters()
+        P.solve_resident(options(capi.SOLVER_DENSE_SCHUR))
+        _, _, vi, va = P.covariance()
+        wi, wa = P.covariance_cameras()
+        eop, xyz, iop, ap = P.get_parameters()
+        assert np.array_equal(np.stack(P.get_parameters()[2]), iop)  # the parameters are left alone
+    for g, w in ((wi, vi), (wa, va)):
+        assert np.array_equal(g == 0.0, w == 0.0)
+        nz = w != 0.0
+        assert np.all(np.abs(g[nz] - w[nz]) <= 1e-6 * w[nz]), np.max(np.abs(g[nz] - w[nz]) / w[nz])
+
+
+def test_camera_variances_of_a_network_too_large_for_the_dense_inverse():
+    net = host.synth(n_cam=1, n_sta=1400, n_pts=6000, rays_per_point=4, seed=1, ap_free_mask=host.AP_K1K2P1P2).net
+    with solver.Problem(net) as P:
+        P.set_parameters()
+        P.solve_resident(options(capi.SOLVER_PCG_SCHUR))
+        with pytest.raises(solver.BaError):
+            P.covariance()
+        vi, va = P.covariance_cameras()
+    free = [2, 3, 5, 6]  # k1 k2 p1 p2
+    assert np.all(vi > 0.0) and np.all(va[0, free] > 0.0)
+    assert np.all(np.delete(va[0], free) == 0.0)
+    # the posterior is tighter than the prior (sigma 10, 10, 1000 on xp, yp, c: src/main.cpp:4612-4623)
+    assert np.all(np.sqrt(vi[0]) < np.array([10.0, 10.0, 1000.0]))
+
+
 def test_covariance_too_large_is_refused():
     net = host.synth(n_cam=1, n_sta=1400, n_pts=3000, rays_per_point=3, seed=1).net
     with solver.Problem(net) as P:
