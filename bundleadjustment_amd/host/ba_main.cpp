@@ -98,11 +98,18 @@ int main(int argc, char **argv) {
          sm.termination == BA_CONVERGENCE ? "CONVERGENCE" : sm.termination == BA_NO_CONVERGENCE ? "NO_CONVERGENCE" : "FAILURE");
   if (covariance) {
     std::vector<double> ve(6 * (size_t)d.n_sta + 1), vx(3 * (size_t)d.n_pts + 1), vi(3 * (size_t)d.n_cam + 1), va(16 * (size_t)d.n_cam + 1);
-    if (ba_covariance(p, ve.data(), vx.data(), vi.data(), va.data())) {
+    const int rc = ba_covariance(p, ve.data(), vx.data(), vi.data(), va.data());
+    if (rc == BA_ERR_UNSUPPORTED) {
+      // too large for the dense inverse: the camera parameters only, the other files keep the default sigma
+      printf("  %s: standard deviations of the camera parameters only\n", ba_last_error());
+      if (ba_covariance_cameras(p, vi.data(), va.data())) { fprintf(stderr, "error: %s\n", ba_last_error()); return 1; }
+      ba_net_set_variances(net, nullptr, nullptr, vi.data(), va.data());
+    } else if (rc) {
       fprintf(stderr, "error: %s\n", ba_last_error());
       return 1;
+    } else {
+      ba_net_set_variances(net, ve.data(), vx.data(), vi.data(), va.data());
     }
-    ba_net_set_variances(net, ve.data(), vx.data(), vi.data(), va.data());
   }
   std::vector<double> res(2 * (size_t)d.n_obs + 3 * (size_t)d.n_pts + 3 * (size_t)d.n_cam);
   double cost = 0;
