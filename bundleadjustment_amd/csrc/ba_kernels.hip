@@ -179,11 +179,22 @@ __device__ __forceinline__ void tile_store(double *buf, const double (&v)[R], do
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (R % 2 == 0) {
+    // two doubles per lane and store: a pair never straddles records when R is even, and g is 16-byte aligned
 #pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int q = i * 64 + lane;
-    const double x = buf[(q / R) * (R + 1) + q % R];
-    if (q < nvalid * R) g[q] = x;
+    for (int i = 0; i < R / 2; ++i) {
+      const int q = 2 * (i * 64 + lane);
+      const double *src = buf + (q / R) * (R + 1) + q % R;
+      const double2 x = make_double2(src[0], src[1]);
+      if (q < nvalid * R) *reinterpret_cast<double2 *>(g + q) = x;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int q = i * 64 + lane;
+      const double x = buf[(q / R) * (R + 1) + q % R];
+      if (q < nvalid * R) g[q] = x;
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
