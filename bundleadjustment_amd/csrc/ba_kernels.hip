@@ -203,15 +203,28 @@ __device__ __forceinline__ void tile_store(double *buf, const double (&v)[R], do
 
 // Sums sixteen values per lane over the wave with 17 exchanges instead of 96: at each of the steps 32, 16, 8, 4 a lane
 // keeps one half of what it holds and takes the partner's share of that half, so the data halves while the number of
-// lanes summed doubles; two plain steps finish.  On return lane l holds the total of value
+// lanes summed doubles; two plain steps finish.  The first two steps are what the lane-swap instructions of gfx950
+// do in one go: v_permlane32_swap exchanges the upper half of one register with the lower half of another,
+// v_permlane16_swap the odd rows of one with the even rows of the other, so "keep mine, fetch yours" is a swap and an
+// add with no select and no trip through the LDS crossbar.  On return lane l holds the total of value
 // 8 b5 + 4 b4 + 2 b3 + b2 (b = bits of l); the four lanes of a quad hold the same.
+__device__ __forceinline__ double swap_add32(double a, double b) {  // lanes < 32: a[l] + a[l+32]; lanes >= 32: b[l-32] + b[l]
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double swap_add16(double a, double b) {  // even rows: a[l] + a[l+16]; odd rows: b[l-16] + b[l]
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
 __device__ __forceinline__ double wave_sum16(const double (&v)[16], int lane) {
   double a[8], b[4], c[2], d;
-  const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
+  const bool h3 = lane & 8, h2 = lane & 4;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) a[k] = (h5 ? v[8 + k] : v[k]) + __shfl_xor(h5 ? v[k] : v[8 + k], 32, 64);
+  for (int k = 0; k < 8; ++k) a[k] = swap_add32(v[k], v[8 + k]);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) b[k] = (h4 ? a[4 + k] : a[k]) + __shfl_xor(h4 ? a[k] : a[4 + k], 16, 64);
+  for (int k = 0; k < 4; ++k) b[k] = swap_add16(a[k], a[4 + k]);
 #pragma unroll
   for (int k = 0; k < 2; ++k) c[k] = (h3 ? b[2 + k] : b[k]) + __shfl_xor(h3 ? b[k] : b[2 + k], 8, 64);
   d = (h2 ? c[1] : c[0]) + __shfl_xor(h2 ? c[0] : c[1], 4, 64);
@@ -277,7 +290,13 @@ k_obs_rows(LinArgs a) {
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       double *gj = a.Jc + (int64_t)R * e0;
-      for (int q = lane; q < nvalid * R; q += 64) gj[q] = buf[(q / R) * (R + 1) + q % R];
+      // q / R by a multiplication: exact for q < 64 * 38 with this constant (R is not known at compile time, and a
+      // vector division per element would cost more than the rest of the copy)
+      const unsigned magic = 0xFFFFFFFFu / (unsigned)R + 1u;
+      for (int q = lane; q < nvalid * R; q += 64) {
+        const int rec = (int)__umulhi((unsigned)q, magic);
+        gj[q] = buf[rec * (R + 1) + (q - rec * R)];
+      }
       if (CAM1) {
 #pragma unroll
         for (int k = 0; k < LIN_NCB; ++k) {
