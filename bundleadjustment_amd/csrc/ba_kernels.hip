@@ -201,38 +201,6 @@ __device__ __forceinline__ void tile_store(double *buf, const double (&v)[R], do
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Sums sixteen values per lane over the wave with 17 exchanges instead of 96: at each of the steps 32, 16, 8, 4 a lane
-// keeps one half of what it holds and takes the partner's share of that half, so the data halves while the number of
-// lanes summed doubles; two plain steps finish.  The first two steps are what the lane-swap instructions of gfx950
-// do in one go: v_permlane32_swap exchanges the upper half of one register with the lower half of another,
-// v_permlane16_swap the odd rows of one with the even rows of the other, so "keep mine, fetch yours" is a swap and an
-// add with no select and no trip through the LDS crossbar.  On return lane l holds the total of value
-// 8 b5 + 4 b4 + 2 b3 + b2 (b = bits of l); the four lanes of a quad hold the same.
-__device__ __forceinline__ double swap_add32(double a, double b) {  // lanes < 32: a[l] + a[l+32]; lanes >= 32: b[l-32] + b[l]
-  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
-}
-__device__ __forceinline__ double swap_add16(double a, double b) {  // even rows: a[l] + a[l+16]; odd rows: b[l-16] + b[l]
-  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
-}
-__device__ __forceinline__ double wave_sum16(const double (&v)[16], int lane) {
-  double a[8], b[4], c[2], d;
-  const bool h3 = lane & 8, h2 = lane & 4;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) a[k] = swap_add32(v[k], v[8 + k]);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) b[k] = swap_add16(a[k], a[4 + k]);
-#pragma unroll
-  for (int k = 0; k < 2; ++k) c[k] = (h3 ? b[2 + k] : b[k]) + __shfl_xor(h3 ? b[k] : b[2 + k], 8, 64);
-  d = (h2 ? c[1] : c[0]) + __shfl_xor(h2 ? c[0] : c[1], 4, 64);
-  d += __shfl_xor(d, 2, 64);
-  d += __shfl_xor(d, 1, 64);
-  return d;
-}
-
 #define ROWS_LDS(CAM1) (64 * ((CAM1) ? 25 : 2 * BA_NCAMPAR + 1))
 // Two waves per SIMD where the register budget of that allows it without spilling (one register short otherwise): the
 // collinearity projection without the empirical terms.  The other variants keep one wave with the full register file.
@@ -707,11 +675,7 @@ k_station_pass(StationArgs a) {
     }
   }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < NACC; ++k) {
-    const double v = wave_sum(acc[k]);
-    if (lane == 0) lds[w * NACC + k] = v;
-  }
+  wave_sums_to<NACC>(acc, lds + w * NACC, lane);
   __syncthreads();
   if (threadIdx.x < NACC) {
     const int k = threadIdx.x;

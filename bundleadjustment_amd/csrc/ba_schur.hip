@@ -155,11 +155,7 @@ k_border_station(StationArgs a, const double *__restrict__ Jt) {
       for (int k = 0; k < NCB; ++k) acc[p * NCB + k] += r0[p] * t0[k] + r1[p] * t1[k];
   }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < NBORDER; ++k) {
-    const double v = wave_sum(acc[k]);
-    if (lane == 0) lds[w * NBORDER + k] = v;
-  }
+  wave_sums_to<NBORDER>(acc, lds + w * NBORDER, lane);
   __syncthreads();
   if (threadIdx.x < NBORDER) {
     const int k = threadIdx.x;
