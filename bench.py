@@ -70,7 +70,7 @@ def kernel_bytes(which, n_obs, n_pts, n_sta, n_blocks=0, n_pairs=0, ncam=0):
     return 292.0 * n_blocks + 48.0 * ncam * n_sta + 96.0 * n_sta  # 6 spmv: matrix, border, p read, q written
 
 
-KERNEL_NAMES = {0: "linearisation (k_point_elim + k_obs_rows)", 7: "k_point_elim", 8: "k_obs_rows", 1: "k_point_pass<APPLY>", 2: "k_station_pass<GATHER>", 3: "k_cost_obs",
+KERNEL_NAMES = {0: "linearisation (k_point_elim + k_obs_rows)", 7: "k_point_elim", 8: "k_obs_rows", 1: "k_point_apply", 2: "k_station_pass<GATHER>", 3: "k_cost_obs",
                 4: "k_schur_blocks", 5: "pcg iteration (k_bsr_spmv + k_cg2_update1 + k_amg_restrict x levels + k_amg_prolong + k_amg_update2)", 6: "k_bsr_spmv"}
 
 

@@ -383,113 +383,58 @@ k_fold_columns(const double *__restrict__ part, int nrows, int ncols, int out_co
 }
 
 // ------------------------------------------------------------------------------------------
-// point sweep 2: the point half of the reduced operator, or back substitution
+// point sweep 2: the point half of the matrix-free reduced operator
 // ------------------------------------------------------------------------------------------
-//   MODE_APPLY   : a = Js p_i (+ Jc p_c);  t = sum Jp^T a;  u = Vinv t;  slot = a - Jp u
-//   MODE_BACKSUB : a = Js y_i + Jc y_c;    y_p = Vinv (g - sum Jp^T a);
-//                  partial sums of (J step).(r + J step / 2) for step = -y  [model cost change]
-template <int MODE, bool WITHCAM>
+//   a = Js p_i (+ Jc p_c);  t = sum Jp^T a;  u = Vinv t;  slot = a - Jp u      (one lane per point)
+template <bool WITHCAM>
 __global__ void __launch_bounds__(256)
-k_point_pass(PointArgs a) {
-  __shared__ double lds[8];
+k_point_apply(PointArgs a) {
   const int jj = blockIdx.x * blockDim.x + threadIdx.x;
-  double acc = 0.0;
-  if (jj < a.P) {
-    const int e0 = a.pt_start[jj], e1 = a.pt_start[jj + 1];
-    // Back substitution keeps the products a = J_cam step of up to BS_KEEP observations in registers,
-    // so that the second walk neither reads nor writes the work slot of those rows.
-    constexpr int BS_KEEP = 8;
-    const bool keep = (MODE == MODE_BACKSUB) && (e1 - e0 <= BS_KEEP);
-    double ka0[BS_KEEP], ka1[BS_KEEP];
-    double t0 = 0, t1 = 0, t2 = 0;
-    for (int e = e0; e < e1; ++e) {
-      double2 *rec = reinterpret_cast<double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
-      const int sta = a.obs_sta[e];
-      const double2 *pv = reinterpret_cast<const double2 *>(a.vec + 6 * (int64_t)sta);
-      const double2 v0 = pv[0], v1 = pv[1], v2 = pv[2];
-      const double2 j0 = rec[0], j1 = rec[1], j2 = rec[2], j3 = rec[3], j4 = rec[4], j5 = rec[5];
-      double a0 = j0.x * v0.x + j0.y * v0.y + j1.x * v1.x + j1.y * v1.y + j2.x * v2.x + j2.y * v2.y;
-      double a1 = j3.x * v0.x + j3.y * v0.y + j4.x * v1.x + j4.y * v1.y + j5.x * v2.x + j5.y * v2.y;
-      if (WITHCAM) {
-        const int c = a.sta_cam[sta];
-        const int nc = a.cam[c].nc, off = a.cam[c].off;
-        const double *jc = a.Jc + 2 * (int64_t)a.ncmax * e;
-        const double *vc = a.vec + 6 * (int64_t)a.S + off;
-        for (int k = 0; k < nc; ++k) {
-          a0 += jc[k] * vc[k];
-          a1 += jc[a.ncmax + k] * vc[k];
-        }
-      }
-      const double2 *jp = reinterpret_cast<const double2 *>(a.Jp + 6 * (int64_t)e);
-      const double2 q0 = jp[0], q1 = jp[1], q2 = jp[2];
-      t0 += q0.x * a0 + q1.y * a1;
-      t1 += q0.y * a0 + q2.x * a1;
-      t2 += q1.x * a0 + q2.y * a1;
-      if (keep) {
-#pragma unroll
-        for (int k = 0; k < BS_KEEP; ++k)
-          if (k == e - e0) {
-            ka0[k] = a0;
-            ka1[k] = a1;
-          }
-      } else {
-        rec[7] = make_double2(a0, a1);
+  if (jj >= a.P) return;
+  const int e0 = a.pt_start[jj], e1 = a.pt_start[jj + 1];
+  double t0 = 0, t1 = 0, t2 = 0;
+  for (int e = e0; e < e1; ++e) {
+    double2 *rec = reinterpret_cast<double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
+    const int sta = a.obs_sta[e];
+    const double2 *pv = reinterpret_cast<const double2 *>(a.vec + 6 * (int64_t)sta);
+    const double2 v0 = pv[0], v1 = pv[1], v2 = pv[2];
+    const double2 j0 = rec[0], j1 = rec[1], j2 = rec[2], j3 = rec[3], j4 = rec[4], j5 = rec[5];
+    double a0 = j0.x * v0.x + j0.y * v0.y + j1.x * v1.x + j1.y * v1.y + j2.x * v2.x + j2.y * v2.y;
+    double a1 = j3.x * v0.x + j3.y * v0.y + j4.x * v1.x + j4.y * v1.y + j5.x * v2.x + j5.y * v2.y;
+    if (WITHCAM) {
+      const int c = a.sta_cam[sta];
+      const int nc = a.cam[c].nc, off = a.cam[c].off;
+      const double *jc = a.Jc + 2 * (int64_t)a.ncmax * e;
+      const double *vc = a.vec + 6 * (int64_t)a.S + off;
+      for (int k = 0; k < nc; ++k) {
+        a0 += jc[k] * vc[k];
+        a1 += jc[a.ncmax + k] * vc[k];
       }
     }
-    const double *vi = a.Vinv + 6 * (int64_t)jj;
-    const double Vi[6] = {vi[0], vi[1], vi[2], vi[3], vi[4], vi[5]};
-    double u0, u1, u2;
-    if (MODE == MODE_APPLY) {
-      sym3_mul(Vi, t0, t1, t2, u0, u1, u2);
-      for (int e = e0; e < e1; ++e) {
-        double2 *rec = reinterpret_cast<double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
-        const double2 *jp = reinterpret_cast<const double2 *>(a.Jp + 6 * (int64_t)e);
-        const double2 q0 = jp[0], q1 = jp[1], q2 = jp[2];
-        const double2 s = rec[7];
-        rec[7] = make_double2(s.x - (q0.x * u0 + q0.y * u1 + q1.x * u2), s.y - (q1.y * u0 + q2.x * u1 + q2.y * u2));
-      }
-    } else {
-      const double *g = a.g_pt + 3 * (int64_t)jj;
-      sym3_mul(Vi, g[0] - t0, g[1] - t1, g[2] - t2, u0, u1, u2);
-      double *yo = a.y_pt + 3 * (int64_t)jj;
-      yo[0] = u0; yo[1] = u1; yo[2] = u2;
-      if (keep) {
-#pragma unroll
-        for (int k = 0; k < BS_KEEP; ++k)
-          if (k < e1 - e0) {
-            const int64_t e = e0 + k;
-            const double2 *jp = reinterpret_cast<const double2 *>(a.Jp + 6 * e);
-            const double2 q0 = jp[0], q1 = jp[1], q2 = jp[2];
-            const double2 r = reinterpret_cast<const double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e)[6];
-            const double m0 = -(ka0[k] + q0.x * u0 + q0.y * u1 + q1.x * u2);
-            const double m1 = -(ka1[k] + q1.y * u0 + q2.x * u1 + q2.y * u2);
-            acc += m0 * (r.x + 0.5 * m0) + m1 * (r.y + 0.5 * m1);
-          }
-      } else {
-        for (int e = e0; e < e1; ++e) {
-          const double2 *rec = reinterpret_cast<const double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
-          const double2 *jp = reinterpret_cast<const double2 *>(a.Jp + 6 * (int64_t)e);
-          const double2 q0 = jp[0], q1 = jp[1], q2 = jp[2];
-          const double2 s = rec[7], r = rec[6];
-          const double m0 = -(s.x + q0.x * u0 + q0.y * u1 + q1.x * u2);
-          const double m1 = -(s.y + q1.y * u0 + q2.x * u1 + q2.y * u2);
-          acc += m0 * (r.x + 0.5 * m0) + m1 * (r.y + 0.5 * m1);
-        }
-      }
-      // prior rows of this point
-      const double *pr = a.pt_prior + 3 * (int64_t)jj, *is = a.pt_isig + 3 * (int64_t)jj;
-      const double *x = a.xyz + 3 * (int64_t)jj, *sp = a.scale_pt + 3 * (int64_t)jj;
-      const double m0 = -is[0] * sp[0] * u0, m1 = -is[1] * sp[1] * u1, m2 = -is[2] * sp[2] * u2;
-      acc += m0 * ((x[0] - pr[0]) * is[0] + 0.5 * m0) + m1 * ((x[1] - pr[1]) * is[1] + 0.5 * m1) +
-             m2 * ((x[2] - pr[2]) * is[2] + 0.5 * m2);
-    }
+    const double2 *jp = reinterpret_cast<const double2 *>(a.Jp + 6 * (int64_t)e);
+    const double2 q0 = jp[0], q1 = jp[1], q2 = jp[2];
+    t0 += q0.x * a0 + q1.y * a1;
+    t1 += q0.y * a0 + q2.x * a1;
+    t2 += q1.x * a0 + q2.y * a1;
+    rec[7] = make_double2(a0, a1);
   }
-  if (MODE == MODE_BACKSUB) {
-    const double t = block_sum(acc, lds);
-    if (threadIdx.x == 0) a.partial[blockIdx.x] = t;
+  const double *vi = a.Vinv + 6 * (int64_t)jj;
+  const double Vi[6] = {vi[0], vi[1], vi[2], vi[3], vi[4], vi[5]};
+  double u0, u1, u2;
+  sym3_mul(Vi, t0, t1, t2, u0, u1, u2);
+  for (int e = e0; e < e1; ++e) {
+    double2 *rec = reinterpret_cast<double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
+    const double2 *jp = reinterpret_cast<const double2 *>(a.Jp + 6 * (int64_t)e);
+    const double2 q0 = jp[0], q1 = jp[1], q2 = jp[2];
+    const double2 s = rec[7];
+    rec[7] = make_double2(s.x - (q0.x * u0 + q0.y * u1 + q1.x * u2), s.y - (q1.y * u0 + q2.x * u1 + q2.y * u2));
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// back substitution: y_p = Vinv (g - sum Jp^T a), a = Js y_i + Jc y_c, and the partial sums of
+// (J step).(r + J step / 2) for step = -y  [model cost change]
+// ------------------------------------------------------------------------------------------
 // Back substitution with the observation rows read the way they lie in memory.  A wave owns 64 consecutive points
 // and therefore one contiguous run of observations.  It walks that run 64 observations at a time, one lane per
 // observation (a = Js y_i + Jc y_c and Jp^T a from whole records), hands the three sums of each observation to the
@@ -1383,8 +1328,8 @@ void launch_point_pass(hipStream_t s, const PointArgs &a, int mode, bool withcam
   if (a.P <= 0) return;
   const dim3 g(nblk(a.P, 256)), b(256);
   if (mode == MODE_APPLY) {
-    if (withcam) hipLaunchKernelGGL((k_point_pass<MODE_APPLY, true>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((k_point_pass<MODE_APPLY, false>), g, b, 0, s, a);
+    if (withcam) hipLaunchKernelGGL(k_point_apply<true>, g, b, 0, s, a);
+    else hipLaunchKernelGGL(k_point_apply<false>, g, b, 0, s, a);
   } else {
     if (withcam) hipLaunchKernelGGL(k_backsub_tiles<true>, g, b, 0, s, a);
     else hipLaunchKernelGGL(k_backsub_tiles<false>, g, b, 0, s, a);
