@@ -306,6 +306,26 @@ def test_constant_blocks_and_partial_masks():
         assert np.array_equal(g[2][0][:2], net.iop[0][:2])
 
 
+def test_empirical_terms_held_constant_at_non_zero_values():
+    # no empirical term is estimated, but AP[7] and AP[10] are not zero: the kernels must not take the variant that
+    # leaves those terms out (it is chosen from the values, not from the masks alone)
+    net = host.synth(n_cam=1, n_sta=10, n_pts=120, rays_per_point=5, seed=6, ap_free_mask=host.AP_K1K2P1P2).net
+    ap = net.ap.copy()
+    ap[0, 7], ap[0, 10] = 2e-3, -3e-5
+    net2 = modified(net, ap=ap)
+    with solver.Problem(net2) as P:
+        c, r = P.evaluate()
+        g = P.solve(options(capi.SOLVER_DENSE_SCHUR))
+        # ba_evaluate with other values than the resident ones: zero empirical terms here
+        c0, _ = P.evaluate(ap=net.ap)
+    co, ro = po.evaluate(net2)
+    assert abs(c - co) <= 1e-13 * co and np.max(np.abs(r - ro)) < 1e-10
+    assert abs(c0 - po.evaluate(net)[0]) <= 1e-13 * co and abs(c0 - c) > 1e-6 * c
+    o = po.solve(net2, options(capi.SOLVER_DENSE_SCHUR), po.SCHUR_DENSE)
+    assert_solve_parity(g, o)
+    assert g[3][0, 7] == 2e-3 and g[3][0, 10] == -3e-5  # held
+
+
 def test_no_observations_and_empty_problem():
     net = host.synth(n_cam=1, n_sta=3, n_pts=5, rays_per_point=2, seed=8).net
     empty = modified(net, obs_pt=np.zeros(0, np.int32), obs_sta=np.zeros(0, np.int32), obs_x=np.zeros(0),
