@@ -60,7 +60,7 @@ class BaSummary(C.Structure):
         ("num_successful_steps", C.c_int32), ("num_unsuccessful_steps", C.c_int32),
         ("num_residuals_reduced", C.c_int32), ("num_parameters_reduced", C.c_int32),
         ("num_effective_parameters_reduced", C.c_int32), ("num_parameters", C.c_int32),
-        ("num_residuals", C.c_int32), ("total_linear_iterations", C.c_int32), ("reserved", C.c_int32),
+        ("num_residuals", C.c_int32), ("total_linear_iterations", C.c_int32), ("linear_solver_used", C.c_int32),
         ("t_total_s", C.c_double),
     ]
 
@@ -68,13 +68,15 @@ class BaSummary(C.Structure):
 SOLVER_DENSE_SCHUR = 0
 SOLVER_PCG_SCHUR = 1
 SOLVER_PCG_IMPLICIT = 2
+SOLVER_AUTO = 3
+AUTO_DENSE_ORDER = 4096
 CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
 ERR_INVALID, ERR_DEVICE, ERR_NUMERIC, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -4, -5
 STOP_REASONS = {0: "none", 1: "max_iterations", 2: "gradient_tol", 3: "parameter_tol",
                 4: "function_tol", 5: "min_radius", 6: "invalid_steps", 7: "linear_solver"}
 
 
-def default_options(linear_solver=SOLVER_DENSE_SCHUR, pcg_rtol=1e-12, pcg_max_iters=2000):
+def default_options(linear_solver=SOLVER_AUTO, pcg_rtol=1e-12, pcg_max_iters=2000):
     """Option values of src/main.cpp:4705-4719 over the Ceres 1.13 defaults."""
     o = BaOptions()
     o.min_lm_diagonal = 1e-150

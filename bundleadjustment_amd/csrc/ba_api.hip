@@ -1032,7 +1032,7 @@ void ba_default_options(ba_options *o) {
   o->max_num_iterations = 100;  // src/main.cpp:4718
   o->max_num_consecutive_invalid_steps = 5;
   o->jacobi_scaling = 1;
-  o->linear_solver = BA_SOLVER_DENSE_SCHUR;
+  o->linear_solver = BA_SOLVER_AUTO;
   o->pcg_rtol = 1e-12;
   o->pcg_max_iters = 2000;
 }
@@ -1122,15 +1122,17 @@ int ba_get_parameters(ba_problem *p, double *eop, double *xyz, double *iop, doub
 int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary, ba_iter_row *rows, int32_t rows_cap) {
   if (!p || !opt) return fail(BA_ERR_INVALID, "ba_solve_resident: null argument");
   if (!p->have_params) return fail(BA_ERR_INVALID, "ba_solve_resident: call ba_set_parameters first");
-  if (opt->linear_solver != BA_SOLVER_DENSE_SCHUR && opt->linear_solver != BA_SOLVER_PCG_SCHUR &&
-      opt->linear_solver != BA_SOLVER_PCG_IMPLICIT)
+  int linear_solver = opt->linear_solver;
+  if (linear_solver == BA_SOLVER_AUTO) linear_solver = p->nr <= BA_AUTO_DENSE_ORDER ? BA_SOLVER_DENSE_SCHUR : BA_SOLVER_PCG_SCHUR;
+  if (linear_solver != BA_SOLVER_DENSE_SCHUR && linear_solver != BA_SOLVER_PCG_SCHUR && linear_solver != BA_SOLVER_PCG_IMPLICIT)
     return fail(BA_ERR_UNSUPPORTED, "linear_solver %d", opt->linear_solver);
-  const bool use_explicit = p->explicit_ok && opt->linear_solver != BA_SOLVER_PCG_IMPLICIT;
+  const bool use_explicit = p->explicit_ok && linear_solver != BA_SOLVER_PCG_IMPLICIT;
   if (!(opt->initial_trust_region_radius > 0.0)) return fail(BA_ERR_INVALID, "initial_trust_region_radius must be positive");
   const double t_begin = now_s();
   ba_summary sm;
   std::memset(&sm, 0, sizeof sm);
   fill_sizes(p, &sm);
+  sm.linear_solver_used = linear_solver;
   int n_rows = 0;
   LmState st{opt->initial_trust_region_radius, opt->min_lm_diagonal, opt->max_lm_diagonal, false,
              opt->min_lm_diagonal != opt->max_lm_diagonal, use_explicit ? 2 : 1};
@@ -1187,7 +1189,7 @@ int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary,
     }
     int lin_iters = 0;
     int lrc;
-    if (opt->linear_solver == BA_SOLVER_DENSE_SCHUR) lrc = solve_dense(p, use_explicit);
+    if (linear_solver == BA_SOLVER_DENSE_SCHUR) lrc = solve_dense(p, use_explicit);
     else if (use_explicit) lrc = solve_pcg_explicit(p, opt, &lin_iters);
     else lrc = solve_pcg(p, opt, &lin_iters);
     it.linear_iterations = lin_iters;

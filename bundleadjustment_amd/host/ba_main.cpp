@@ -15,7 +15,7 @@
 static void usage() {
   fprintf(stderr,
           "usage: ba_main <file.pho> <file.eop> <file.iop> <file.xyz> [--out DIR] [--free-ap MASK] [--free-iop MASK]\n"
-          "               [--solver dense|pcg] [--pcg-rtol X] [--max-iter N] [--covariance] [--model M]\n"
+          "               [--solver auto|dense|pcg|implicit] [--pcg-rtol X] [--max-iter N] [--covariance] [--model M]\n"
           "               [--bins B] [--truth file.xyz]\n"
           "       ba_main --synth C S P RAYS [same options]\n"
           "  MASK: bit k of --free-ap frees AP[k] (a1 a2 k1 k2 k3 p1 p2 ep1..ep9); default 0x4 = k1 only,\n"
@@ -45,7 +45,10 @@ int main(int argc, char **argv) {
     if (a == "--out") out = next();
     else if (a == "--free-ap") ap_mask = (unsigned)strtoul(next(), nullptr, 0);
     else if (a == "--free-iop") iop_mask = (unsigned)strtoul(next(), nullptr, 0);
-    else if (a == "--solver") opt.linear_solver = (std::string(next()) == "pcg") ? BA_SOLVER_PCG_SCHUR : BA_SOLVER_DENSE_SCHUR;
+    else if (a == "--solver") {
+      const std::string v = next();
+      opt.linear_solver = v == "pcg" ? BA_SOLVER_PCG_SCHUR : v == "implicit" ? BA_SOLVER_PCG_IMPLICIT : v == "dense" ? BA_SOLVER_DENSE_SCHUR : BA_SOLVER_AUTO;
+    }
     else if (a == "--pcg-rtol") opt.pcg_rtol = atof(next());
     else if (a == "--max-iter") opt.max_num_iterations = atoi(next());
     else if (a == "--synth") synth = true;

@@ -58,8 +58,13 @@ enum ba_linear_solver {
   BA_SOLVER_DENSE_SCHUR = 0, /* point elimination + dense fp64 Cholesky of the reduced system */
   BA_SOLVER_PCG_SCHUR = 1,   /* point elimination + block-Jacobi PCG on the reduced system, held as 6x6
                                 blocks in block-sparse form (matrix-free when it is too dense for that) */
-  BA_SOLVER_PCG_IMPLICIT = 2 /* same PCG, always matrix-free: S p = Jc^T (I - Jp V^-1 Jp^T) Jc p */
+  BA_SOLVER_PCG_IMPLICIT = 2, /* same PCG, always matrix-free: S p = Jc^T (I - Jp V^-1 Jp^T) Jc p */
+  BA_SOLVER_AUTO = 3          /* the default: DENSE_SCHUR while the reduced system has at most
+                                 BA_AUTO_DENSE_ORDER unknowns (6 per station + the free camera
+                                 parameters), PCG_SCHUR above.  The reference fixes its solver at
+                                 src/main.cpp:4706, so a caller coming from it never chooses one. */
 };
+#define BA_AUTO_DENSE_ORDER 4096
 
 typedef struct {
   int32_t n_obs; /* rows of the .pho file  */
@@ -157,7 +162,7 @@ typedef struct {
   int32_t num_parameters;                   /* ambient size of every block                          */
   int32_t num_residuals;
   int32_t total_linear_iterations;
-  int32_t reserved;
+  int32_t linear_solver_used; /* what BA_SOLVER_AUTO resolved to (else the option as given) */
   double t_total_s;
 } ba_summary;
 

@@ -133,6 +133,25 @@ def test_scaled_configs_solve_parity(name, scale, ls):
     assert_solve_parity(g, o)
 
 
+def test_default_options_pick_the_solver_by_size():
+    # the reference fixes its linear solver (src/main.cpp:4706), so its callers never choose one: the default
+    # options must work at any size.  Dense up to capi.AUTO_DENSE_ORDER reduced unknowns, PCG above.
+    small = host.synth_config("cfg2", scale=0.05).net
+    assert 6 * small.n_sta + 10 <= capi.AUTO_DENSE_ORDER
+    opt = solver.default_options()
+    assert opt.linear_solver == capi.SOLVER_AUTO
+    g = gpu_solve(small, opt)
+    assert g[4]["linear_solver_used"] == capi.SOLVER_DENSE_SCHUR and g[4]["total_linear_iterations"] == 0
+    assert_solve_parity(g, po.solve(small, opt, po.SCHUR_DENSE))
+    large = host.synth(n_cam=1, n_sta=700, n_pts=20000, rays_per_point=6, seed=3).net
+    assert 6 * large.n_sta > capi.AUTO_DENSE_ORDER
+    g = gpu_solve(large, opt)
+    assert g[4]["linear_solver_used"] == capi.SOLVER_PCG_SCHUR and g[4]["total_linear_iterations"] > 0
+    assert g[4]["termination"] == capi.CONVERGENCE
+    explicit = gpu_solve(large, options(capi.SOLVER_PCG_SCHUR))
+    assert g[4]["final_cost"] == explicit[4]["final_cost"]
+
+
 def test_multilevel_preconditioner_same_answer_fewer_iterations():
     # 300 stations: three levels of the aggregation hierarchy; the preconditioner must not change what
     # the PCG converges to, only how fast
