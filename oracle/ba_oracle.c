@@ -310,6 +310,7 @@ typedef struct {
   double *scale;              /* [nt] Jacobi scaling                                 */
   double *grad;               /* [nt] gradient J^T r from the unscaled Jacobian      */
   double cost, fixed_cost;
+  const double *iop_lo, *iop_hi; /* [3C] box of the IOP blocks, NULL = none (src/main.cpp:4252-4256) */
 } prob_t;
 
 static int popcount32(unsigned v) {
@@ -1191,6 +1192,27 @@ static void plus(const prob_t *q, const params_t *x, const double *delta, params
       if (par < 3) out->iop[3 * c + par] = x->iop[3 * c + par] + dv;
       else out->ap[16 * c + par - 3] = x->ap[16 * c + par - 3] + dv;
     }
+  /* [CERES] ParameterBlock::Plus: project the whole block onto its box */
+  for (int c = 0; c < q->C; ++c)
+    if (iop_in_program(q, c))
+      for (int k = 0; k < 3; ++k) {
+        if (q->iop_lo) out->iop[3 * c + k] = fmax(out->iop[3 * c + k], q->iop_lo[3 * c + k]);
+        if (q->iop_hi) out->iop[3 * c + k] = fmin(out->iop[3 * c + k], q->iop_hi[3 * c + k]);
+      }
+}
+
+/* max-norm of x - Plus(x, -g)  [CERES] TrustRegionMinimizer::EvaluateGradientAndJacobian */
+static double projected_gradient_max(const prob_t *q, const params_t *x, double *neg, params_t *tmp) {
+  for (int i = 0; i < q->nt; ++i) neg[i] = -q->grad[i];
+  plus(q, x, neg, tmp);
+  double m = 0.0;
+  for (int i = 0; i < 6 * q->S; ++i) m = fmax(m, fabs(x->eop[i] - tmp->eop[i]));
+  for (int i = 0; i < 3 * q->P; ++i) m = fmax(m, fabs(x->xyz[i] - tmp->xyz[i]));
+  for (int c = 0; c < q->C; ++c) {
+    if (iop_in_program(q, c)) for (int k = 0; k < 3; ++k) m = fmax(m, fabs(x->iop[3 * c + k] - tmp->iop[3 * c + k]));
+    if (ap_in_program(q, c)) for (int k = 0; k < 16; ++k) m = fmax(m, fabs(x->ap[16 * c + k] - tmp->ap[16 * c + k]));
+  }
+  return m;
 }
 
 /* norms over the ambient coordinates of the blocks in the reduced program */
@@ -1208,11 +1230,173 @@ static double ambient_norm(const prob_t *q, const params_t *a, const params_t *b
   return sqrt(s);
 }
 
+
+/* ------------------------------------------------------------------------------------ */
+/* Projected line search of bounds-constrained problems                                   */
+/* [CERES] line_search.cc ArmijoLineSearch::DoSearch, polynomial.cc                       */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct { double x, value, gradient; int value_ok, gradient_ok; } ls_sample;
+
+/* coefficients highest power first, as in [CERES] polynomial.h */
+static double poly_eval(const double *p, int n, double x) {
+  double v = 0.0;
+  for (int i = 0; i < n; ++i) v = v * x + p[i];
+  return v;
+}
+
+/* [CERES] FindInterpolatingPolynomial: one row per valid value, one per valid gradient; solved with
+ * complete pivoting (Eigen fullPivLu there). Returns the number of coefficients. */
+static int poly_fit(const ls_sample *s, int ns, double *coef) {
+  int nc = 0;
+  for (int i = 0; i < ns; ++i) nc += (s[i].value_ok != 0) + (s[i].gradient_ok != 0);
+  const int deg = nc - 1;
+  double A[8][9];
+  int row = 0;
+  for (int i = 0; i < ns; ++i) {
+    if (s[i].value_ok) {
+      for (int j = 0; j <= deg; ++j) A[row][j] = pow(s[i].x, deg - j);
+      A[row][nc] = s[i].value;
+      ++row;
+    }
+    if (s[i].gradient_ok) {
+      for (int j = 0; j < deg; ++j) A[row][j] = (deg - j) * pow(s[i].x, deg - j - 1);
+      A[row][deg] = 0.0;
+      A[row][nc] = s[i].gradient;
+      ++row;
+    }
+  }
+  int perm[8];
+  for (int j = 0; j < nc; ++j) perm[j] = j;
+  for (int k = 0; k < nc; ++k) {
+    int pr = k, pc = k;
+    double best = -1.0;
+    for (int r = k; r < nc; ++r)
+      for (int c = k; c < nc; ++c)
+        if (fabs(A[r][c]) > best) { best = fabs(A[r][c]); pr = r; pc = c; }
+    if (best <= 0.0) break; /* singular: remaining unknowns stay zero */
+    for (int c = 0; c <= nc; ++c) { const double t = A[k][c]; A[k][c] = A[pr][c]; A[pr][c] = t; }
+    for (int r = 0; r < nc; ++r) { const double t = A[r][k]; A[r][k] = A[r][pc]; A[r][pc] = t; }
+    { const int t = perm[k]; perm[k] = perm[pc]; perm[pc] = t; }
+    for (int r = k + 1; r < nc; ++r) {
+      const double f = A[r][k] / A[k][k];
+      for (int c = k; c <= nc; ++c) A[r][c] -= f * A[k][c];
+    }
+  }
+  double y[8];
+  for (int k = nc - 1; k >= 0; --k) {
+    double v = A[k][nc];
+    for (int c = k + 1; c < nc; ++c) v -= A[k][c] * y[c];
+    y[k] = (A[k][k] != 0.0) ? v / A[k][k] : 0.0;
+  }
+  for (int k = 0; k < nc; ++k) coef[perm[k]] = y[k];
+  return nc;
+}
+
+/* real roots of p (n coefficients) inside [lo, hi]: between two neighbouring roots of p' the polynomial is
+ * monotone, so every sign change there brackets exactly one root, which bisection pins to the last bit.
+ * ([CERES] FindPolynomialRoots takes the eigenvalues of the companion matrix; only the real roots inside the
+ * interval can win in MinimizePolynomial.) */
+static int poly_real_roots(const double *p, int n, double lo, double hi, double *roots) {
+  while (n > 0 && p[0] == 0.0) { ++p; --n; }
+  if (n <= 1) return 0;
+  int nr = 0;
+  if (n == 2) {
+    const double r = -p[1] / p[0];
+    if (r >= lo && r <= hi) roots[nr++] = r;
+    return nr;
+  }
+  double dp[8], crit[8];
+  for (int i = 0; i < n - 1; ++i) dp[i] = (n - 1 - i) * p[i];
+  const int ncrit = poly_real_roots(dp, n - 1, lo, hi, crit);
+  for (int i = 1; i < ncrit; ++i) /* insertion sort */
+    for (int j = i; j > 0 && crit[j] < crit[j - 1]; --j) { const double t = crit[j]; crit[j] = crit[j - 1]; crit[j - 1] = t; }
+  double a = lo, fa = poly_eval(p, n, lo);
+  for (int i = 0; i <= ncrit; ++i) {
+    const double b = (i < ncrit) ? crit[i] : hi, fb = poly_eval(p, n, b);
+    if (fa == 0.0) {
+      if (nr == 0 || roots[nr - 1] != a) roots[nr++] = a;
+    } else if (fb != 0.0 && (fa < 0.0) != (fb < 0.0)) {
+      double l = a, h = b, fl = fa;
+      for (int it = 0; it < 200; ++it) {
+        const double m = 0.5 * (l + h);
+        if (m <= l || m >= h) break;
+        const double fm = poly_eval(p, n, m);
+        if (fm == 0.0) { l = h = m; break; }
+        if ((fm < 0.0) == (fl < 0.0)) { l = m; fl = fm; } else h = m;
+      }
+      roots[nr++] = 0.5 * (l + h);
+    }
+    a = b; fa = fb;
+  }
+  if (fa == 0.0 && (nr == 0 || roots[nr - 1] != a)) roots[nr++] = a;
+  return nr;
+}
+
+/* [CERES] LineSearch::InterpolatingPolynomialMinimizingStepSize (CUBIC) + MinimizeInterpolatingPolynomial */
+double bao_interpolating_step(const double *lower, const double *previous, const double *current, double x_min,
+                              double x_max) {
+  /* each sample: x, value, gradient, value_ok, gradient_ok */
+  ls_sample s[3];
+  int ns = 0;
+  if (!(current[3] != 0.0)) return fmin(fmax(current[0] * 0.5, x_min), x_max);
+  const double *src[3] = {lower, current, previous};
+  for (int i = 0; i < 3; ++i) {
+    if (i == 2 && !(previous && previous[3] != 0.0)) break;
+    s[ns].x = src[i][0]; s[ns].value = src[i][1]; s[ns].gradient = src[i][2];
+    s[ns].value_ok = src[i][3] != 0.0; s[ns].gradient_ok = src[i][4] != 0.0;
+    ++ns;
+  }
+  double coef[8], der[8], roots[8];
+  const int n = poly_fit(s, ns, coef);
+  /* MinimizePolynomial: middle, ends, then the stationary points inside */
+  double best_x = (x_min + x_max) / 2.0, best = poly_eval(coef, n, best_x);
+  const double v_min = poly_eval(coef, n, x_min), v_max = poly_eval(coef, n, x_max);
+  if (v_min < best) { best = v_min; best_x = x_min; }
+  if (v_max < best) { best = v_max; best_x = x_max; }
+  if (n > 2) {
+    for (int i = 0; i < n - 1; ++i) der[i] = (n - 1 - i) * coef[i];
+    const int nroots = poly_real_roots(der, n - 1, x_min, x_max, roots);
+    for (int i = 0; i < nroots; ++i) {
+      const double v = poly_eval(coef, n, roots[i]);
+      if (v < best) { best = v; best_x = roots[i]; }
+    }
+  }
+  for (int i = 0; i < ns; ++i) {
+    if (s[i].x < x_min || s[i].x > x_max) continue;
+    const double v = poly_eval(coef, n, s[i].x);
+    if (v < best) { best = v; best_x = s[i].x; }
+  }
+  return best_x;
+}
+
 int bao_solve(const ba_dims *d, const ba_inputs *in, const ba_options *opt, int mode, double *eop, double *xyz,
               double *iop, double *ap, ba_summary *summary, ba_iter_row *rows, int32_t rows_cap) {
+  return bao_solve_bounded(d, in, opt, mode, NULL, NULL, eop, xyz, iop, ap, summary, rows, rows_cap);
+}
+
+int bao_solve_bounded(const ba_dims *d, const ba_inputs *in, const ba_options *opt, int mode, const double *iop_lower,
+                      const double *iop_upper, double *eop, double *xyz, double *iop, double *ap, ba_summary *summary,
+                      ba_iter_row *rows, int32_t rows_cap) {
   prob_t q;
   int rc = prob_init(&q, d, in, 1);
   if (rc) { prob_free(&q); return rc; }
+  q.iop_lo = iop_lower;
+  q.iop_hi = iop_upper;
+  /* [CERES] Program::IsFeasible: a constant block must lie inside its box, a variable one needs a non-empty box;
+   * Program::IsBoundsConstrained: some variable block has a finite bound */
+  int constrained = 0;
+  for (int c = 0; c < q.C; ++c)
+    for (int k = 0; k < 3; ++k) {
+      const double lo = iop_lower ? iop_lower[3 * c + k] : -DBL_MAX, hi = iop_upper ? iop_upper[3 * c + k] : DBL_MAX;
+      if (iop_in_program(&q, c)) {
+        if (lo >= hi) { prob_free(&q); FAIL(BA_ERR_INVALID, "camera %d: IOP[%d] has the empty interval [%g, %g]", c, k, lo, hi); }
+        if (lo > -DBL_MAX || hi < DBL_MAX) constrained = 1;
+      } else if (iop[3 * c + k] < lo || iop[3 * c + k] > hi) {
+        prob_free(&q);
+        FAIL(BA_ERR_INVALID, "camera %d: constant IOP[%d] = %g lies outside [%g, %g]", c, k, iop[3 * c + k], lo, hi);
+      }
+    }
   const double t_begin = now_s();
   const int nt = q.nt;
   params_t x, cand;
@@ -1224,6 +1408,10 @@ int bao_solve(const ba_dims *d, const ba_inputs *in, const ba_options *opt, int 
   memcpy(x.ap, ap, sizeof(double) * 16 * q.C);
   double *diag = calloc(nt + 1, sizeof(double)), *D2 = calloc(nt + 1, sizeof(double));
   double *step = calloc(nt + 1, sizeof(double)), *delta = calloc(nt + 1, sizeof(double));
+  double *trial = calloc(nt + 1, sizeof(double));
+  params_t tmp;
+  params_alloc(&tmp, &q);
+  int stale = 0; /* the line search left the linearisation of another point in q */
   ba_summary sm;
   memset(&sm, 0, sizeof sm);
   int n_rows = 0;
@@ -1249,6 +1437,12 @@ int bao_solve(const ba_dims *d, const ba_inputs *in, const ba_options *opt, int 
   /* ---- IterationZero ---- */
   double radius = opt->initial_trust_region_radius, decrease_factor = 2.0;
   int reuse_diagonal = 0, num_invalid = 0;
+  if (constrained) {
+    /* [CERES] TrustRegionMinimizer::IterationZero: start from the projection of the initial point */
+    memset(delta, 0, sizeof(double) * nt);
+    plus(&q, &x, delta, &cand);
+    params_copy(&x, &cand, &q);
+  }
   double x_norm = ambient_norm(&q, &x, NULL);
   double t0 = now_s();
   linearize(&q, x.eop, x.xyz, x.iop, x.ap); /* scale == 1 here */
@@ -1260,8 +1454,7 @@ int bao_solve(const ba_dims *d, const ba_inputs *in, const ba_options *opt, int 
   }
   double x_cost = q.cost;
   const double fixed_cost = q.fixed_cost;
-  double grad_max = 0.0;
-  for (int i = 0; i < nt; ++i) grad_max = fmax(grad_max, fabs(q.grad[i]));
+  double grad_max = projected_gradient_max(&q, &x, trial, &tmp);
   sm.initial_cost = x_cost + fixed_cost;
   sm.fixed_cost = fixed_cost;
   min_iter_cost = sm.initial_cost;
@@ -1296,6 +1489,10 @@ int bao_solve(const ba_dims *d, const ba_inputs *in, const ba_options *opt, int 
 
     /* ---- LevenbergMarquardtStrategy::ComputeStep ---- */
     t0 = now_s();
+    if (stale) {
+      linearize(&q, x.eop, x.xyz, x.iop, x.ap);
+      stale = 0;
+    }
     if (!reuse_diagonal) {
       column_sqnorm(&q, diag);
       for (int i = 0; i < nt; ++i) diag[i] = fmin(fmax(diag[i], opt->min_lm_diagonal), opt->max_lm_diagonal);
@@ -1342,6 +1539,32 @@ int bao_solve(const ba_dims *d, const ba_inputs *in, const ba_options *opt, int 
     num_invalid = 0;
     for (int i = 0; i < nt; ++i) delta[i] = step[i] * q.scale[i];
 
+    if (constrained) {
+      /* ---- DoLineSearch: Armijo backtracking along Plus(x, a delta), cubic interpolation ---- */
+      /* [CERES] defaults: sufficient decrease 1e-4, contraction within [1e-3, 0.6], 20 iterations, min step 1e-9 */
+      double g0 = 0.0, dmax = 0.0;
+      for (int i = 0; i < nt; ++i) { g0 += q.grad[i] * delta[i]; dmax = fmax(dmax, fabs(delta[i])); }
+      double lower[5] = {0.0, x_cost, g0, 1.0, 1.0}, prev[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, cur[5] = {1.0, 0.0, 0.0, 0.0, 0.0};
+      int ls_iters = 0, ls_ok = 0;
+      for (;;) {
+        for (int i = 0; i < nt; ++i) trial[i] = cur[0] * delta[i];
+        plus(&q, &x, trial, &cand);
+        linearize(&q, cand.eop, cand.xyz, cand.iop, cand.ap);
+        stale = 1;
+        double gd = 0.0;
+        for (int i = 0; i < nt; ++i) gd += delta[i] * q.grad[i];
+        cur[1] = q.cost; cur[2] = gd;
+        cur[3] = cur[4] = (isfinite(q.cost) && isfinite(gd)) ? 1.0 : 0.0;
+        if (cur[3] != 0.0 && !(cur[1] > x_cost + 1e-4 * g0 * cur[0])) { ls_ok = 1; break; }
+        if (++ls_iters >= 20) break;
+        const double a = bao_interpolating_step(lower, prev, cur, 1e-3 * cur[0], 0.6 * cur[0]);
+        if (a * dmax < 1e-9) break;
+        memcpy(prev, cur, sizeof prev);
+        cur[0] = a;
+      }
+      if (ls_ok) for (int i = 0; i < nt; ++i) delta[i] *= cur[0];
+    }
+
     /* ---- ComputeCandidatePointAndEvaluateCost ---- */
     t0 = now_s();
     plus(&q, &x, delta, &cand);
@@ -1371,10 +1594,10 @@ int bao_solve(const ba_dims *d, const ba_inputs *in, const ba_options *opt, int 
       x_norm = ambient_norm(&q, &x, NULL);
       t0 = now_s();
       linearize(&q, x.eop, x.xyz, x.iop, x.ap);
+      stale = 0;
       it.t_linearize_s = now_s() - t0;
       x_cost = q.cost;
-      grad_max = 0.0;
-      for (int i = 0; i < nt; ++i) grad_max = fmax(grad_max, fabs(q.grad[i]));
+      grad_max = projected_gradient_max(&q, &x, trial, &tmp);
       it.gradient_max_norm = grad_max;
       it.cost = x_cost + fixed_cost;
       it.step_is_successful = 1;
@@ -1402,7 +1625,8 @@ int bao_solve(const ba_dims *d, const ba_inputs *in, const ba_options *opt, int 
   memcpy(ap, x.ap, sizeof(double) * 16 * q.C);
   if (summary) *summary = sm;
 out:
-  free(diag); free(D2); free(step); free(delta);
+  free(diag); free(D2); free(step); free(delta); free(trial);
+  params_free(&tmp);
   params_free(&x);
   params_free(&cand);
   prob_free(&q);

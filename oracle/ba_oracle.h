@@ -67,6 +67,20 @@ int bao_solve(const ba_dims *d, const ba_inputs *in, const ba_options *opt, int 
               double *xyz, double *iop, double *ap, ba_summary *summary, ba_iter_row *rows,
               int32_t rows_cap);
 
+/* bao_solve with the box on the IOP blocks that the reference's fisheye branches set (src/main.cpp:3957-3961,
+ * 4252-4256: xp in [xMin, xMax], yp in [-yMax, yMin], c >= 0).  iop_lower / iop_upper are [3*n_cam] or NULL;
+ * -DBL_MAX / DBL_MAX mean no bound.  With a finite bound on a variable block the loop takes the bounds-constrained
+ * route of Ceres 1.13: the start point is projected, Plus projects, the gradient norm is that of the projected
+ * gradient step, and every valid step goes through an Armijo line search along the projected path. */
+int bao_solve_bounded(const ba_dims *d, const ba_inputs *in, const ba_options *opt, int mode, const double *iop_lower,
+                      const double *iop_upper, double *eop, double *xyz, double *iop, double *ap, ba_summary *summary,
+                      ba_iter_row *rows, int32_t rows_cap);
+
+/* Step size of one backtracking move: minimiser, inside [x_min, x_max], of the polynomial through the samples
+ * (each: x, value, gradient, value valid, gradient valid; previous may be NULL).  For tests. */
+double bao_interpolating_step(const double *lower, const double *previous, const double *current, double x_min,
+                              double x_max);
+
 /* One residual+Jacobian+point-elimination pass (what the GPU's fused kernel does), for the
  * Jacobian obs/s CPU figure.  Returns the cost. */
 double bao_linearize_once(const ba_dims *d, const ba_inputs *in, const double *eop,

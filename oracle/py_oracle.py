@@ -115,15 +115,28 @@ def sparsity(net):
     return nr.value, nc.value, rows, cols
 
 
-def solve(net, options, mode=SCHUR_DENSE, rows_cap=256):
-    """Returns (eop, xyz, iop, ap, summary dict, list of iteration-row dicts)."""
+def solve(net, options, mode=SCHUR_DENSE, rows_cap=256, iop_bounds=None):
+    """Returns (eop, xyz, iop, ap, summary dict, list of iteration-row dicts).
+    iop_bounds = (lower [C,3], upper [C,3]): the box of src/main.cpp:4252-4256."""
     d, inp = net.dims(), net.inputs()
     eop, xyz, iop, ap = net.params_copy()
     sm = BaSummary()
     rows = (BaIterRow * rows_cap)()
-    _check(lib().bao_solve(C.byref(d), C.byref(inp), C.byref(options), int(mode), _dp(eop), _dp(xyz), _dp(iop),
-                           _dp(ap), C.byref(sm), rows, rows_cap))
+    lo = hi = None
+    if iop_bounds is not None:
+        lo, hi = (np.ascontiguousarray(b, dtype=np.float64).reshape(net.n_cam, 3) for b in iop_bounds)
+    _check(lib().bao_solve_bounded(C.byref(d), C.byref(inp), C.byref(options), int(mode),
+                                   _dp(lo) if lo is not None else None, _dp(hi) if hi is not None else None,
+                                   _dp(eop), _dp(xyz), _dp(iop), _dp(ap), C.byref(sm), rows, rows_cap))
     return eop, xyz, iop, ap, summary_to_dict(sm), rows_to_dicts(rows, min(sm.num_iterations, rows_cap))
+
+
+def interpolating_step(lower, previous, current, x_min, x_max):
+    """One backtracking move of the Armijo search; samples are (x, value, gradient, value_ok, gradient_ok)."""
+    L = lib()
+    L.bao_interpolating_step.restype = C.c_double
+    arr = [None if s is None else np.ascontiguousarray(s, dtype=np.float64) for s in (lower, previous, current)]
+    return L.bao_interpolating_step(*[None if a is None else _dp(a) for a in arr], C.c_double(x_min), C.c_double(x_max))
 
 
 def covariance(net, eop=None, xyz=None, iop=None, ap=None):
