@@ -65,6 +65,11 @@ class BaSummary(C.Structure):
     ]
 
 
+class BaLsSample(C.Structure):
+    _fields_ = [("x", C.c_double), ("value", C.c_double), ("gradient", C.c_double),
+                ("value_is_valid", C.c_int32), ("gradient_is_valid", C.c_int32)]
+
+
 SOLVER_DENSE_SCHUR = 0
 SOLVER_PCG_SCHUR = 1
 SOLVER_PCG_IMPLICIT = 2

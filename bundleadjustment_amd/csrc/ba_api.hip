@@ -9,6 +9,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cfloat>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -56,7 +57,7 @@ int popcount32(unsigned v) { return __builtin_popcount(v); }
 
 enum Scal {
   SC_COST = 0, SC_FIXED, SC_GMAX, SC_MCC, SC_STEP2_SC, SC_CNORM2_SC, SC_STEP2_P, SC_CNORM2_P, SC_CCOST, SC_XNORM2_SC,
-  SC_XNORM2_P, SC_GMAX_P, SC_GMAX_SC, SC_COUNT = 32
+  SC_XNORM2_P, SC_GMAX_P, SC_GMAX_SC, SC_LS_DOT_P, SC_LS_DOT_SC, SC_LS_MAX_P, SC_LS_MAX_SC, SC_COUNT = 32
 };
 
 }  // namespace
@@ -126,6 +127,8 @@ struct ba_problem {
   int *d_col_cam = nullptr, *d_col_pos = nullptr;
   // state
   bool have_params = false;
+  bool boxed = false;        // ba_set_iop_bounds gave some camera a finite bound
+  bool constrained = false;  // ... and that camera's IOP block is variable: the solve takes Ceres' bounds-constrained route
   // multi-GPU
   ba_allreduce_fn ar = nullptr;
   void *ar_user = nullptr;
@@ -227,6 +230,8 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
     for (int k = 0; k < 3; ++k) {
       r.prior[k] = in->iop_prior[3 * c + k];
       r.isig[k] = 1.0 / in->iop_sigma[3 * c + k];
+      r.lo[k] = -DBL_MAX;
+      r.hi[k] = DBL_MAX;
     }
     p->ncmax = std::max(p->ncmax, r.nc);
   }
@@ -611,16 +616,15 @@ int linearize(ba_problem *p, const LmState &st) {
     ca.camdiag = p->d_diagfull + 6 * (size_t)p->S; ca.g_cam = p->d_g + 6 * (size_t)p->S; ca.b_cam = p->d_b + 6 * (size_t)p->S;
     launch_camera_finish(s, ca);
   }
-  // gradient max norm: |g_scaled / scale| over points (local), stations and cameras (replicated)
+  // gradient max norm: |x - Plus(x, -g_scaled / scale)| over points (local), stations and cameras (replicated)
   const int bp = cost_blocks(3 * (int64_t)p->P), bs = cost_blocks(6 * (int64_t)p->S);
-  launch_absmax_ratio(s, 3 * (int64_t)p->P, p->d_g_pt, p->d_scale_pt, p->d_partial, bp);
+  launch_absmax_ratio(s, 3 * (int64_t)p->P, p->d_g_pt, p->d_scale_pt, p->d_xyz, p->d_partial, bp);
   launch_max_partials(s, p->d_partial, bp, p->d_scal, SC_GMAX_P);
   BA_TRY(p->allreduce(p->d_scal + SC_GMAX_P, 1, 1));
-  launch_absmax_ratio(s, 6 * (int64_t)p->S, p->d_g, p->d_scale_sta, p->d_partial + bp, bs);
+  launch_absmax_ratio(s, 6 * (int64_t)p->S, p->d_g, p->d_scale_sta, p->d_eop, p->d_partial + bp, bs);
   launch_max_partials(s, p->d_partial + bp, bs, p->d_scal, SC_GMAX_SC);
   if (p->ncam > 0) {
-    launch_absmax_ratio(s, p->ncam, p->d_g + 6 * (size_t)p->S, p->d_scale_cam, p->d_partial + bp + bs, 1);
-    launch_max_partials(s, p->d_partial + bp + bs, 1, p->d_scal, SC_GMAX);
+    launch_camera_gradient_step(s, p->C, p->d_cam, p->d_g + 6 * (size_t)p->S, p->d_scal, SC_GMAX);
   } else {
     HIP_OK(hipMemsetAsync(p->d_scal + SC_GMAX, 0, sizeof(double), s));
   }
@@ -906,6 +910,8 @@ int solve_dense(ba_problem *p, bool explicit_blocks) {
   return 0;
 }
 
+int make_candidate(ba_problem *p, double alpha);
+
 // y_p = V^-1 (g_p - W^T y_c); model cost change; candidate = x - y*scale; norms.  Reads d_x.
 int step_and_candidate(ba_problem *p) {
   hipStream_t s = p->stream;
@@ -914,7 +920,14 @@ int step_and_candidate(ba_problem *p) {
   launch_sum_partials(s, p->d_partial, linearize_blocks(p->P), p->d_scal, SC_MCC);
   BA_TRY(p->allreduce(p->d_scal + SC_MCC, 1, 0));
   launch_camera_mcc(s, p->C, p->d_cam, p->d_x + 6 * (size_t)p->S, p->d_scal, SC_MCC);
+  return make_candidate(p, 1.0);
+}
+
+// candidate = Plus(x, alpha * delta), its norm and the norm of the step taken
+int make_candidate(ba_problem *p, double alpha) {
+  hipStream_t s = p->stream;
   CandArgs ca{};
+  ca.alpha = alpha;
   ca.S = p->S; ca.P = p->P; ca.C = p->C; ca.sta_used = p->d_sta_used; ca.eop = p->d_eop; ca.xyz = p->d_xyz; ca.y_cam = p->d_x;
   ca.y_pt = p->d_y_pt; ca.scale_sta = p->d_scale_sta; ca.scale_pt = p->d_scale_pt; ca.cam = p->d_cam;
   ca.eop_c = p->d_eop_c; ca.xyz_c = p->d_xyz_c; ca.cam_c = p->d_cam_c; ca.partial = p->d_partial;
@@ -1095,6 +1108,36 @@ int ba_set_corrections(ba_problem *p, const double *obs_cx, const double *obs_cy
   return rc;
 }
 
+int ba_set_iop_bounds(ba_problem *p, const double *lower, const double *upper) {
+  if (!p) return fail(BA_ERR_INVALID, "ba_set_iop_bounds: null problem");
+  std::vector<double> lo(3 * (size_t)p->C, -DBL_MAX), hi(3 * (size_t)p->C, DBL_MAX);
+  bool boxed = false, constrained = false;
+  for (int c = 0; c < p->C; ++c)
+    for (int k = 0; k < 3; ++k) {
+      double &l = lo[3 * c + k], &h = hi[3 * c + k];
+      if (lower) l = lower[3 * c + k];
+      if (upper) h = upper[3 * c + k];
+      if (std::isnan(l) || std::isnan(h)) return fail(BA_ERR_INVALID, "ba_set_iop_bounds: camera %d, IOP[%d]: bound is not a number", c, k);
+      l = std::max(l, -DBL_MAX);  // -inf / +inf: no bound
+      h = std::min(h, DBL_MAX);
+      const bool finite = l > -DBL_MAX || h < DBL_MAX;
+      boxed = boxed || finite;
+      if (p->cam_h[c].in_program & 1) {
+        // [Ceres 1.13 Program::IsFeasible] a variable block needs a box with an interior
+        if (l >= h) return fail(BA_ERR_INVALID, "ba_set_iop_bounds: camera %d, IOP[%d]: empty interval [%g, %g]", c, k, l, h);
+        constrained = constrained || finite;  // [Program::IsBoundsConstrained]
+      }
+    }
+  for (int c = 0; c < p->C; ++c)
+    for (int k = 0; k < 3; ++k) {
+      p->cam_h[c].lo[k] = lo[3 * c + k];
+      p->cam_h[c].hi[k] = hi[3 * c + k];
+    }
+  p->boxed = boxed;
+  p->constrained = constrained;
+  return 0;
+}
+
 int ba_get_parameters(ba_problem *p, double *eop, double *xyz, double *iop, double *ap) {
   if (!p) return fail(BA_ERR_INVALID, "ba_get_parameters: null problem");
   if (!p->have_params) return fail(BA_ERR_INVALID, "ba_get_parameters: no parameters were set");
@@ -1114,6 +1157,82 @@ int ba_get_parameters(ba_problem *p, double *eop, double *xyz, double *iop, doub
       if (ap) for (int k = 0; k < 16; ++k) ap[16 * c + k] = cam[c].ap[k];
     }
   }
+  return 0;
+}
+
+// g . delta for the gradient now on the device and the step of the last solve: delta = -y * scale and
+// g = g_scaled / scale, so the scales cancel
+static int gradient_dot_step(ba_problem *p, double *out) {
+  hipStream_t s = p->stream;
+  const int bp = cost_blocks(3 * (int64_t)p->P), bs = cost_blocks(p->nr);
+  launch_dot(s, 3 * (int64_t)p->P, p->d_g_pt, p->d_y_pt, p->d_partial, bp);
+  launch_sum_partials(s, p->d_partial, bp, p->d_scal, SC_LS_DOT_P);
+  BA_TRY(p->allreduce(p->d_scal + SC_LS_DOT_P, 1, 0));
+  launch_dot(s, p->nr, p->d_g, p->d_x, p->d_partial + bp, bs);
+  launch_sum_partials(s, p->d_partial + bp, bs, p->d_scal, SC_LS_DOT_SC);
+  BA_TRY(p->check_kernels());
+  BA_TRY(p->read_scal());
+  *out = -(p->h_scal[SC_LS_DOT_P] + p->h_scal[SC_LS_DOT_SC]);
+  return 0;
+}
+
+// max |delta|  [Ceres 1.13 LineSearchFunction::DirectionInfinityNorm]
+static int step_max_norm(ba_problem *p, double *out) {
+  hipStream_t s = p->stream;
+  const int bp = cost_blocks(3 * (int64_t)p->P), bs = cost_blocks(6 * (int64_t)p->S);
+  launch_absmax_prod(s, 3 * (int64_t)p->P, p->d_y_pt, p->d_scale_pt, p->d_partial, bp);
+  launch_max_partials(s, p->d_partial, bp, p->d_scal, SC_LS_MAX_P);
+  BA_TRY(p->allreduce(p->d_scal + SC_LS_MAX_P, 1, 1));
+  launch_absmax_prod(s, 6 * (int64_t)p->S, p->d_x, p->d_scale_sta, p->d_partial + bp, bs);
+  if (p->ncam > 0) launch_absmax_prod(s, p->ncam, p->d_x + 6 * (size_t)p->S, p->d_scale_cam, p->d_partial + bp + bs, 1);
+  launch_max_partials(s, p->d_partial + bp, bs + (p->ncam > 0 ? 1 : 0), p->d_scal, SC_LS_MAX_SC);
+  BA_TRY(p->check_kernels());
+  BA_TRY(p->read_scal());
+  *out = std::max(p->h_scal[SC_LS_MAX_P], p->h_scal[SC_LS_MAX_SC]);
+  return 0;
+}
+
+// [Ceres 1.13 TrustRegionMinimizer::DoLineSearch + ArmijoLineSearch::DoSearch] Backtracking along
+// a -> Plus(x, a * delta) from a = 1 until cost(a) <= cost(0) + 1e-4 * a * g.delta; every trial is a full
+// evaluation (cost and gradient, for the cubic interpolation).  Leaves the candidate buffers at the accepted
+// step, or at the full step when the search gives up, and the row buffers at the last trial point.
+static int projected_line_search(ba_problem *p, const LmState &st, double x_cost) {
+  const double sufficient_decrease = 1e-4, max_contraction = 1e-3, min_contraction = 0.6, min_step = 1e-9;
+  const int max_trials = 20;
+  ba_ls_sample start{0.0, x_cost, 0.0, 1, 1}, previous{0.0, 0.0, 0.0, 0, 0}, current{1.0, 0.0, 0.0, 0, 0};
+  BA_TRY(gradient_dot_step(p, &start.gradient));
+  LmState trial = st;
+  trial.reuse_diag = false;
+  trial.reduced = 0;  // cost and gradient only: no reduced system at a trial point
+  double dmax = -1.0;
+  int contractions = 0;
+  bool found = false;
+  for (;;) {
+    if (current.x != 1.0) BA_TRY(make_candidate(p, current.x));  // the full step is already in the candidate buffers
+    std::swap(p->d_eop, p->d_eop_c);
+    std::swap(p->d_xyz, p->d_xyz_c);
+    std::swap(p->d_cam, p->d_cam_c);
+    int rc = linearize(p, trial);
+    if (!rc) {
+      current.value = p->h_scal[SC_COST];
+      rc = gradient_dot_step(p, &current.gradient);
+    }
+    std::swap(p->d_eop, p->d_eop_c);
+    std::swap(p->d_xyz, p->d_xyz_c);
+    std::swap(p->d_cam, p->d_cam_c);
+    if (rc && rc != BA_ERR_NUMERIC) return rc;
+    const bool valid = !rc && std::isfinite(current.value) && std::isfinite(current.gradient);
+    current.value_is_valid = current.gradient_is_valid = valid ? 1 : 0;
+    if (valid && !(current.value > x_cost + sufficient_decrease * start.gradient * current.x)) { found = true; break; }
+    if (++contractions >= max_trials) break;
+    const double next = ba_line_search_contract(&start, &previous, &current, max_contraction * current.x, min_contraction * current.x);
+    if (dmax < 0.0) BA_TRY(step_max_norm(p, &dmax));
+    if (next * dmax < min_step) break;
+    previous = current;
+    current.x = next;
+  }
+  if (!found && current.x != 1.0) BA_TRY(make_candidate(p, 1.0));
+  BA_TRY(p->read_scal());
   return 0;
 }
 
@@ -1138,6 +1257,25 @@ int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary,
              opt->min_lm_diagonal != opt->max_lm_diagonal, use_explicit ? 2 : 1};
   double decrease_factor = 2.0;
   int num_invalid = 0;
+
+  if (p->boxed) {
+    // [Ceres 1.13 Program::IsFeasible] a constant block must start inside its box: nothing can move it there
+    for (int c = 0; c < p->C; ++c)
+      for (int k = 0; k < 3; ++k) {
+        const CamRec &r = p->cam_h[c];
+        if (!(r.in_program & 1) && (r.iop[k] < r.lo[k] || r.iop[k] > r.hi[k]))
+          return fail(BA_ERR_INVALID, "camera %d: constant IOP[%d] = %g lies outside [%g, %g]", c, k, r.iop[k], r.lo[k], r.hi[k]);
+      }
+  }
+  const bool constrained = p->constrained;
+  if (constrained) {
+    // [Ceres 1.13 TrustRegionMinimizer::IterationZero] x = Plus(x, 0): the start point projected onto the box
+    // (init_scaling uploads the camera records)
+    for (auto &r : p->cam_h)
+      if (r.in_program & 1)
+        for (int k = 0; k < 3; ++k) r.iop[k] = std::min(std::max(r.iop[k], r.lo[k]), r.hi[k]);
+  }
+  bool rows_hold_x = true;  // the per-observation rows and the gradient on the device belong to x (not to a trial point)
 
   // ---- IterationZero ----
   double t0 = now_s();
@@ -1180,8 +1318,10 @@ int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary,
     // ---- LevenbergMarquardtStrategy::ComputeStep ----
     t0 = now_s();
     if (!linearized_for_radius) {
-      // same point, smaller radius: the eliminated blocks depend on the radius through D
-      st.reuse_diag = true;
+      // same point, smaller radius: the eliminated blocks depend on the radius through D.  After a line search the
+      // rows are those of its last trial point: then everything is computed again, to the same values as before
+      st.reuse_diag = rows_hold_x;
+      rows_hold_x = true;
       BA_TRY(linearize(p, st));
       it.t_linearize_s += now_s() - t0;
       t0 = now_s();
@@ -1224,6 +1364,16 @@ int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary,
     }
     num_invalid = 0;
 
+    if (constrained) {
+      // ---- DoLineSearch ----
+      t0 = now_s();
+      rows_hold_x = false;
+      linearized_for_radius = false;
+      BA_TRY(projected_line_search(p, st, x_cost));
+      it.step_norm = std::sqrt(p->h_scal[SC_STEP2_SC] + p->h_scal[SC_STEP2_P]);
+      it.t_linearize_s += now_s() - t0;
+    }
+
     // ---- ComputeCandidatePointAndEvaluateCost ----
     t0 = now_s();
     BA_TRY(cost_at(p, p->d_eop_c, p->d_xyz_c, p->d_cam_c, p->d_sta_c, SC_CCOST, -1, 0, nullptr));
@@ -1262,6 +1412,7 @@ int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary,
       BA_TRY(linearize(p, st));
       it.t_linearize_s += now_s() - t0;
       linearized_for_radius = true;
+      rows_hold_x = true;
       x_cost = p->h_scal[SC_COST];
       it.gradient_max_norm = p->h_scal[SC_GMAX];
       it.cost = x_cost + fixed_cost;

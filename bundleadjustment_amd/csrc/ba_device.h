@@ -58,6 +58,7 @@ struct CamRec {
   uint32_t mask;
   int32_t nc, off;
   int32_t in_program;        // bit0: IOP block is variable, bit1: AP block is variable and observed
+  double lo[3], hi[3];       // box of xp yp c (src/main.cpp:4252-4256); -DBL_MAX / DBL_MAX = no bound
 };
 
 __device__ __forceinline__ CamIn load_cam(const CamRec *__restrict__ cam, int c) {

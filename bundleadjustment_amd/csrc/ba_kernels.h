@@ -88,6 +88,7 @@ struct CandArgs {
   double *eop_c, *xyz_c;
   CamRec *cam_c;
   double *partial;
+  double alpha;  // the candidate is Plus(x, alpha * delta); 1 outside the line search
 };
 
 struct CgArgs {
@@ -120,7 +121,10 @@ void launch_cost_prior(hipStream_t s, int P, const double *xyz, const double *pr
                        double *res_out, double *partial, int blocks);
 void launch_sum_partials(hipStream_t s, const double *partial, int n, double *out, int slot);
 void launch_max_partials(hipStream_t s, const double *partial, int n, double *out, int slot);
-void launch_absmax_ratio(hipStream_t s, int64_t n, const double *g, const double *scale, double *partial, int blocks);
+void launch_absmax_ratio(hipStream_t s, int64_t n, const double *g, const double *scale, const double *x, double *partial, int blocks);
+void launch_camera_gradient_step(hipStream_t s, int C, const CamRec *cam, const double *g_cam, double *out, int slot);
+void launch_dot(hipStream_t s, int64_t n, const double *a, const double *b, double *partial, int blocks);
+void launch_absmax_prod(hipStream_t s, int64_t n, const double *a, const double *b, double *partial, int blocks);
 void launch_make_scale(hipStream_t s, int64_t n, const double *colnorm, double *scale);
 void launch_fill(hipStream_t s, int64_t n, double *v, double val);
 void launch_candidate(hipStream_t s, const CandArgs &a, int blocks);

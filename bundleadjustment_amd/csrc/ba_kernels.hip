@@ -858,11 +858,61 @@ k_max_partials(const double *__restrict__ partial, int n, double *__restrict__ o
 
 // max |g_scaled / scale| over a vector
 __global__ void __launch_bounds__(256)
-k_absmax_ratio(int64_t n, const double *__restrict__ g, const double *__restrict__ scale, double *__restrict__ partial) {
+k_absmax_ratio(int64_t n, const double *__restrict__ g, const double *__restrict__ scale, const double *__restrict__ x,
+               double *__restrict__ partial) {
+  // max |x - Plus(x, -gradient)|, gradient = g / scale  [Ceres 1.13 TrustRegionMinimizer::EvaluateGradientAndJacobian]:
+  // the gradient as it survives the addition to x, not the gradient itself
   __shared__ double lds[8];
   double m = 0.0;
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
-    m = fmax(m, fabs(g[t] / scale[t]));
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    const double xv = x[t], moved = xv + (-(g[t] / scale[t]));
+    m = fmax(m, fabs(xv - moved));
+  }
+  const double r = block_max(m, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// the same over the camera blocks, where Plus also projects xp yp c onto their box.  One thread: a few values.
+__global__ void k_camera_gradient_step(int C, const CamRec *__restrict__ cam, const double *__restrict__ g_cam,
+                                       double *__restrict__ out, int slot) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  double m = 0.0;
+  for (int c = 0; c < C; ++c) {
+    const CamRec &r = cam[c];
+    double step[BA_NCAMPAR];
+    int pos = 0;
+    for (int p = 0; p < BA_NCAMPAR; ++p) {
+      step[p] = 0.0;
+      if (r.mask & (1u << p)) {
+        step[p] = -(g_cam[r.off + pos] / r.scale[pos]);
+        ++pos;
+      }
+    }
+    if (r.in_program & 1)
+      for (int k = 0; k < 3; ++k) {
+        const double v = fmin(fmax(r.iop[k] + step[k], r.lo[k]), r.hi[k]);
+        m = fmax(m, fabs(r.iop[k] - v));
+      }
+    if (r.in_program & 2)
+      for (int k = 0; k < 16; ++k) m = fmax(m, fabs(r.ap[k] - (r.ap[k] + step[3 + k])));
+  }
+  out[slot] = m;
+}
+
+__global__ void __launch_bounds__(256)
+k_dot(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ partial) {
+  __shared__ double lds[8];
+  double acc = 0.0;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) acc += a[t] * b[t];
+  const double r = block_sum(acc, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+__global__ void __launch_bounds__(256)
+k_absmax_prod(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ partial) {
+  __shared__ double lds[8];
+  double m = 0.0;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) m = fmax(m, fabs(a[t] * b[t]));
   const double r = block_max(m, lds);
   if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
@@ -879,7 +929,8 @@ __global__ void k_fill(int64_t n, double *__restrict__ v, double val) {
 }
 
 // ------------------------------------------------------------------------------------------
-// candidate point  x + delta,  delta = -y * scale  on the free coordinates
+// candidate point  Plus(x, alpha * delta),  delta = -y * scale  on the free coordinates; xp yp c are projected
+// onto their box  [Ceres 1.13 ParameterBlock::Plus]
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_candidate(CandArgs a) {
@@ -891,13 +942,13 @@ k_candidate(CandArgs a) {
     if (t < n_s) {
       const int i = (int)(t / 6);
       const bool used = a.sta_used[i] != 0;
-      const double d = used ? -a.y_cam[t] * a.scale_sta[t] : 0.0;
+      const double d = used ? a.alpha * (-a.y_cam[t] * a.scale_sta[t]) : 0.0;
       const double v = a.eop[t] + d;
       a.eop_c[t] = v;
       if (used) { step2 += d * d; norm2 += v * v; }
     } else {
       const int64_t u = t - n_s;
-      const double d = -a.y_pt[u] * a.scale_pt[u];
+      const double d = a.alpha * (-a.y_pt[u] * a.scale_pt[u]);
       const double v = a.xyz[u] + d;
       a.xyz_c[u] = v;
       pstep2 += d * d;
@@ -911,11 +962,15 @@ k_candidate(CandArgs a) {
       int pos = 0;
       for (int p = 0; p < BA_NCAMPAR; ++p) {
         if (r.mask & (1u << p)) {
-          const double d = -a.y_cam[n_s + r.off + pos] * r.scale[pos];
-          if (p < 3) r.iop[p] += d; else r.ap[p - 3] += d;
-          step2 += d * d;
+          const double d = a.alpha * (-a.y_cam[n_s + r.off + pos] * r.scale[pos]);
+          if (p < 3) r.iop[p] += d; else { r.ap[p - 3] += d; step2 += d * d; }
           ++pos;
         }
+      }
+      for (int k = 0; k < 3; ++k) {
+        if (r.in_program & 1) r.iop[k] = fmin(fmax(r.iop[k], r.lo[k]), r.hi[k]);
+        const double moved = r.iop[k] - a.cam[c].iop[k];  // the step as taken, after the projection
+        step2 += moved * moved;
       }
       if (r.in_program & 1) for (int k = 0; k < 3; ++k) norm2 += r.iop[k] * r.iop[k];
       if (r.in_program & 2) for (int k = 0; k < 16; ++k) norm2 += r.ap[k] * r.ap[k];
@@ -1383,8 +1438,17 @@ void launch_sum_partials(hipStream_t s, const double *partial, int n, double *ou
 void launch_max_partials(hipStream_t s, const double *partial, int n, double *out, int slot) {
   hipLaunchKernelGGL(k_max_partials, dim3(1), dim3(1024), 0, s, partial, n, out, slot);
 }
-void launch_absmax_ratio(hipStream_t s, int64_t n, const double *g, const double *scale, double *partial, int blocks) {
-  hipLaunchKernelGGL(k_absmax_ratio, dim3(blocks), dim3(256), 0, s, n, g, scale, partial);
+void launch_absmax_ratio(hipStream_t s, int64_t n, const double *g, const double *scale, const double *x, double *partial, int blocks) {
+  hipLaunchKernelGGL(k_absmax_ratio, dim3(blocks), dim3(256), 0, s, n, g, scale, x, partial);
+}
+void launch_camera_gradient_step(hipStream_t s, int C, const CamRec *cam, const double *g_cam, double *out, int slot) {
+  hipLaunchKernelGGL(k_camera_gradient_step, dim3(1), dim3(1), 0, s, C, cam, g_cam, out, slot);
+}
+void launch_dot(hipStream_t s, int64_t n, const double *a, const double *b, double *partial, int blocks) {
+  hipLaunchKernelGGL(k_dot, dim3(blocks), dim3(256), 0, s, n, a, b, partial);
+}
+void launch_absmax_prod(hipStream_t s, int64_t n, const double *a, const double *b, double *partial, int blocks) {
+  hipLaunchKernelGGL(k_absmax_prod, dim3(blocks), dim3(256), 0, s, n, a, b, partial);
 }
 void launch_make_scale(hipStream_t s, int64_t n, const double *colnorm, double *scale) {
   if (n > 0) hipLaunchKernelGGL(k_make_scale, dim3(nblk(n, 256)), dim3(256), 0, s, n, colnorm, scale);

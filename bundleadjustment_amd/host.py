@@ -102,6 +102,7 @@ def lib():
         L.ba_net_set_variances.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]
         L.ba_net_num_ap_correction.argtypes = [C.c_void_p]
         L.ba_net_set_model.argtypes = [C.c_void_p, C.c_int32]
+        L.ba_net_iop_bounds.argtypes = [C.c_void_p, c_double_p, c_double_p]
         for f in ("ba_stat_median", "ba_stat_stddev"):
             getattr(L, f).restype = C.c_double
             getattr(L, f).argtypes = [c_double_p, C.c_int64]
@@ -196,6 +197,12 @@ class HostNetwork:
         """Projection of the image rows: 0 collinearity, 1 collinearity stereographic, 2..5 the fisheye functors."""
         _check(lib().ba_net_set_model(self._h, int(model)))
         self.net = self._export()
+
+    def iop_bounds(self):
+        """(lower, upper), [C,3] each: the box of src/main.cpp:4252-4256 from the sensor format columns of the .iop file."""
+        lo, hi = np.zeros((self.dims.n_cam, 3)), np.zeros((self.dims.n_cam, 3))
+        _check(lib().ba_net_iop_bounds(self._h, lo.ctypes.data_as(c_double_p), hi.ctypes.data_as(c_double_p)))
+        return lo, hi
 
     def set_corrections(self, obs_cx, obs_cy):
         """New image corrections (columns 7-8 of temp.pho) from the regression step of the outer loop."""

@@ -3,6 +3,7 @@
 #include "ba_host.h"
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -491,6 +492,16 @@ void ba_net_free(ba_network *net) { delete net; }
 int ba_net_set_model(ba_network *n, int32_t model) {
   if (!n || model < 0 || model > 7) return fail(BA_ERR_INVALID, "ba_net_set_model: model must be 0..7");
   n->model = model;
+  return 0;
+}
+
+int ba_net_iop_bounds(const ba_network *n, double *lower, double *upper) {
+  if (!n || !lower || !upper) return fail(BA_ERR_INVALID, "ba_net_iop_bounds: null argument");
+  for (size_t c = 0; c < n->iopCamera.size(); ++c) {
+    lower[3 * c + 0] = n->iopXMin[c];  upper[3 * c + 0] = n->iopXMax[c];
+    lower[3 * c + 1] = -n->iopYMax[c]; upper[3 * c + 1] = n->iopYMin[c];  // "Y is flipped"
+    lower[3 * c + 2] = 0.0;            upper[3 * c + 2] = DBL_MAX;        // principal distance positive
+  }
   return 0;
 }
 

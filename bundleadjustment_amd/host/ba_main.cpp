@@ -16,7 +16,7 @@ static void usage() {
   fprintf(stderr,
           "usage: ba_main <file.pho> <file.eop> <file.iop> <file.xyz> [--out DIR] [--free-ap MASK] [--free-iop MASK]\n"
           "               [--solver auto|dense|pcg|implicit] [--pcg-rtol X] [--max-iter N] [--covariance] [--model M]\n"
-          "               [--bins B] [--truth file.xyz]\n"
+          "               [--bins B] [--truth file.xyz] [--iop-bounds]\n"
           "       ba_main --synth C S P RAYS [same options]\n"
           "  MASK: bit k of --free-ap frees AP[k] (a1 a2 k1 k2 k3 p1 p2 ep1..ep9); default 0x4 = k1 only,\n"
           "        the reference's choice (src/main.cpp:4487-4504).  --free-iop: bits xp yp c, default 7.\n"
@@ -26,6 +26,8 @@ static void usage() {
           "  --bins: quantile bins of the residual statistics printed after the solve (default 30 = the reference's\n"
           "        QUANTILE_RESIDUALS_BINS, src/main.cpp:51; 0 leaves them out).  --truth: object-space QC against a file\n"
           "        of rows \"id X Y Z sX sY sZ\" (src/main.cpp:7242-7346).\n"
+          "  --iop-bounds: the box on xp, yp, c from the sensor format columns of the .iop file, as the reference's\n"
+          "        stereographic and fisheye branches set it (src/main.cpp:4252-4256); its collinearity branches set none.\n"
           "  --covariance: standard deviations of all parameters in the result files (the reference's COMPUTECX\n"
           "        branch, src/main.cpp:5261); small networks only.\n");
 }
@@ -34,7 +36,7 @@ int main(int argc, char **argv) {
   std::vector<std::string> pos;
   std::string out = ".";
   unsigned ap_mask = 0x4, iop_mask = 7;
-  bool synth = false, covariance = false;
+  bool synth = false, covariance = false, iop_bounds = false;
   int model = 0, bins = 30;
   std::string truth;
   ba_options opt;
@@ -53,6 +55,7 @@ int main(int argc, char **argv) {
     else if (a == "--max-iter") opt.max_num_iterations = atoi(next());
     else if (a == "--synth") synth = true;
     else if (a == "--covariance") covariance = true;
+    else if (a == "--iop-bounds") iop_bounds = true;
     else if (a == "--model") model = atoi(next());
     else if (a == "--bins") bins = atoi(next());
     else if (a == "--truth") truth = next();
@@ -85,6 +88,11 @@ int main(int argc, char **argv) {
          d.n_obs, d.n_sta, d.n_cam, d.n_pts);
   ba_problem *p = nullptr;
   if (ba_create(&d, &in, &p)) { fprintf(stderr, "error: %s\n", ba_last_error()); return 1; }
+  if (iop_bounds) {
+    std::vector<double> lo(3 * (size_t)d.n_cam), hi(3 * (size_t)d.n_cam);
+    ba_net_iop_bounds(net, lo.data(), hi.data());
+    if (ba_set_iop_bounds(p, lo.data(), hi.data())) { fprintf(stderr, "error: %s\n", ba_last_error()); return 1; }
+  }
   ba_summary sm;
   std::vector<ba_iter_row> rows(opt.max_num_iterations + 2);
   if (ba_solve(p, &opt, ba_net_eop(net), ba_net_xyz(net), ba_net_iop(net), ba_net_ap(net), &sm, rows.data(), (int32_t)rows.size())) {

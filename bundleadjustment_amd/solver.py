@@ -7,7 +7,7 @@ import os
 
 import numpy as np
 
-from .capi import (BaDims, BaInputs, BaIterRow, BaOptions, BaSummary, Network, c_double_p, c_int32_p,
+from .capi import (BaDims, BaInputs, BaIterRow, BaLsSample, BaOptions, BaSummary, Network, c_double_p, c_int32_p,
                    rows_to_dicts, summary_to_dict)
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
@@ -19,6 +19,7 @@ KERNEL_LINEARIZE, KERNEL_POINT_APPLY, KERNEL_STATION_GATHER, KERNEL_COST = 0, 1,
 
 # every entry point include/ba_gpu.h declares
 EXPORTS = ("ba_default_options", "ba_create", "ba_destroy", "ba_set_parameters", "ba_get_parameters", "ba_set_corrections", "ba_covariance_cameras",
+           "ba_set_iop_bounds", "ba_line_search_contract",
            "ba_solve_resident", "ba_solve", "ba_evaluate", "ba_covariance", "ba_sparsity", "ba_residual_jacobian", "ba_time_kernel",
            "ba_set_allreduce", "ba_copy_to_host", "ba_copy_to_device", "ba_rccl_unique_id", "ba_use_rccl", "ba_last_error")
 
@@ -51,6 +52,9 @@ def lib():
         L.ba_get_parameters.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]
         L.ba_set_corrections.argtypes = [C.c_void_p, c_double_p, c_double_p]
         L.ba_covariance_cameras.argtypes = [C.c_void_p, c_double_p, c_double_p]
+        L.ba_set_iop_bounds.argtypes = [C.c_void_p, c_double_p, c_double_p]
+        L.ba_line_search_contract.argtypes = [C.POINTER(BaLsSample)] * 3 + [C.c_double, C.c_double]
+        L.ba_line_search_contract.restype = C.c_double
         L.ba_solve_resident.argtypes = [C.c_void_p, C.POINTER(BaOptions), C.POINTER(BaSummary), C.POINTER(BaIterRow), C.c_int32]
         L.ba_solve.argtypes = [C.c_void_p, C.POINTER(BaOptions), c_double_p, c_double_p, c_double_p, c_double_p,
                                C.POINTER(BaSummary), C.POINTER(BaIterRow), C.c_int32]
@@ -127,6 +131,12 @@ class Problem:
         if cx.shape != (self.net.n_obs,) or cy.shape != (self.net.n_obs,):
             raise ValueError("one correction per observation")
         _check(lib().ba_set_corrections(self._h, _dp(cx), _dp(cy)))
+
+    def set_iop_bounds(self, lower=None, upper=None):
+        """Box on xp, yp, c per camera ([C,3] each, None = unbounded): the SetParameterLowerBound/UpperBound calls of
+        src/main.cpp:4252-4256.  A finite bound on a variable block switches the solve to the bounds-constrained route."""
+        lo, hi = (None if b is None else np.ascontiguousarray(b, dtype=np.float64).reshape(self.net.n_cam, 3) for b in (lower, upper))
+        _check(lib().ba_set_iop_bounds(self._h, None if lo is None else _dp(lo), None if hi is None else _dp(hi)))
 
     def get_parameters(self):
         n = self.net
@@ -229,3 +239,11 @@ def rccl_unique_id() -> bytes:
     buf = C.create_string_buffer(128)
     _check(lib().ba_rccl_unique_id(buf))
     return buf.raw
+
+
+def line_search_contract(start, previous, current, min_step, max_step):
+    """Next step size of the Armijo search (samples: x, value, gradient, value valid, gradient valid; previous may be None)."""
+    def sample(t):
+        return None if t is None else BaLsSample(float(t[0]), float(t[1]), float(t[2]), int(t[3]), int(t[4]))
+    s, p, c = sample(start), sample(previous), sample(current)
+    return lib().ba_line_search_contract(C.byref(s), None if p is None else C.byref(p), C.byref(c), float(min_step), float(max_step))

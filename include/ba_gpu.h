@@ -199,6 +199,34 @@ int ba_get_parameters(ba_problem *p, double *eop, double *xyz, double *iop, doub
 int ba_set_corrections(ba_problem *p, const double *obs_cx, const double *obs_cy);
 
 /*
+ * Box on the interior orientation blocks.  Replaces the Problem::SetParameterLowerBound / SetParameterUpperBound
+ * calls that the reference's stereographic and fisheye branches make (src/main.cpp:3957-3961, 4252-4256:
+ * xp in [xMin, xMax], yp in [-yMax, yMin], c >= 0; its collinearity branches set none).
+ * lower / upper are [3*n_cam] in the order xp, yp, c; NULL, -DBL_MAX / DBL_MAX and -inf / +inf mean no bound.
+ * With a finite bound on a camera whose IOP block is variable, ba_solve_resident follows the bounds-constrained
+ * route of Ceres 1.13: the start point is projected onto the box, every Plus projects, gradient_max_norm is the
+ * norm of the projected gradient step, and every valid trust-region step is shortened by an Armijo line search
+ * along the projected path (cubic interpolation, sufficient decrease 1e-4, contraction within [1e-3, 0.6], at most
+ * 20 trials, minimum step 1e-9: the Solver::Options defaults, which the reference leaves alone) before it is tested.
+ * Errors as Program::IsFeasible: lower >= upper on a variable block at this call; a constant block outside its box
+ * when the solve starts.
+ */
+int ba_set_iop_bounds(ba_problem *p, const double *lower, const double *upper);
+
+/*
+ * One contraction of that line search, exposed so it can be checked without a device: the minimiser over
+ * [min_step, max_step] of the polynomial that interpolates the values and gradients of the samples (start = step 0;
+ * previous may be NULL or invalid), i.e. LineSearch::InterpolatingPolynomialMinimizingStepSize of Ceres 1.13 with
+ * CUBIC interpolation; half the current step, clamped, when the current sample is not valid.
+ */
+typedef struct {
+  double x, value, gradient;
+  int32_t value_is_valid, gradient_is_valid;
+} ba_ls_sample;
+double ba_line_search_contract(const ba_ls_sample *start, const ba_ls_sample *previous, const ba_ls_sample *current,
+                               double min_step, double max_step);
+
+/*
  * Runs the trust-region Levenberg-Marquardt loop on the parameters resident on the device
  * and leaves the result there.  Replaces ceres::Solve, src/main.cpp:4721.
  * rows may be NULL; at most rows_cap rows are written.

@@ -74,6 +74,11 @@ int ba_net_set_free(ba_network *net, uint16_t ap_free_mask, uint8_t iop_free_mas
  * 1 collinearity stereographic, 2..5 fisheye equidistant / equisolid-angle / orthographic / stereographic,
  * 6 collinearity orthographic (:1412), 7 omnidirectional (:2700). */
 int ba_net_set_model(ba_network *net, int32_t model);
+/* The box the reference's stereographic and fisheye branches put on each IOP block from columns 3-6 of the .iop file
+ * (src/main.cpp:3957-3961, 4252-4256): lower = xMin, -yMax, 0; upper = xMax, yMin, none (DBL_MAX); [3*n_cam] each,
+ * for ba_set_iop_bounds of ba_gpu.h.  The formula is kept as written there: it presumes image rows counted from
+ * yMin = 0 with y negated, and gives an empty yp interval for a sensor format centred on zero. */
+int ba_net_iop_bounds(const ba_network *net, double *lower, double *upper);
 
 /* First-match id lookup with a hash map: out[n] = first i with ids[i] == keys[n].
  * Returns BA_ERR_INVALID and sets out[n] = n_ids for every key that is absent. */
