@@ -103,8 +103,9 @@ def structure_counts(net):
     return n_pairs, 2 * off + net.n_sta
 
 
-def cpu_baseline(config, cpu_scale, pcg_rtol):
-    """The CPU oracle (plain C, one thread) on a shrunk copy of the same network."""
+def cpu_baseline(config, cpu_scale, pcg_rtol, omp=False):
+    """The CPU oracle (plain C; one thread, or its OpenMP build on all the cores this process may use) on a shrunk
+    copy of the same network."""
     from bundleadjustment_amd import capi, host
     from oracle import py_oracle as po
     hn = host.synth_config(config, scale=cpu_scale)
@@ -115,11 +116,11 @@ def cpu_baseline(config, cpu_scale, pcg_rtol):
     opt.parameter_tolerance = 0.0
     opt.gradient_tolerance = 0.0
     t0 = time.time()
-    *_, sm, rows = po.solve(net, opt, po.SCHUR_PCG)
+    *_, sm, rows = po.solve(net, opt, po.SCHUR_PCG, omp=omp)
     t_solve = time.time() - t0
     iters = max(1, sm["num_iterations"] - 1)
     t0 = time.time()
-    po.linearize_once(net)
+    po.linearize_once(net, omp=omp)
     t_lin = time.time() - t0
     return net.n_obs, iters / t_solve, net.n_obs / t_lin, sm["total_linear_iterations"] / iters
 
@@ -261,6 +262,14 @@ def main():
             "value": it_s * n_cpu / full.n_obs, "unit": "iter/s", "cores": 1, "kind": "port",
             "sample": f"oracle (C, 1 thread), same generator at {n_cpu} observations: {it_s:.3f} LM iter/s measured with "
                       f"{cg:.0f} PCG iterations per step, scaled linearly in observations to {full.n_obs}; "
+                      f"Jacobian pass {obs_s:.3e} obs/s",
+            "jacobian_obs_per_s": obs_s, "measured_iter_per_s_on_sample": it_s, "sample_observations": n_cpu}
+        from oracle import py_oracle as po
+        n_cpu, it_s, obs_s, cg = cpu_baseline(args.config, args.cpu_scale * args.scale, args.pcg_rtol, omp=True)
+        out["cpu_baseline_all_cores"] = {
+            "value": it_s * n_cpu / full.n_obs, "unit": "iter/s", "cores": po.omp_threads(), "kind": "port",
+            "sample": f"the same oracle built with OpenMP (loops over observations and points; OMP_NUM_THREADS as set), "
+                      f"same sample of {n_cpu} observations: {it_s:.3f} LM iter/s measured, scaled linearly to {full.n_obs}; "
                       f"Jacobian pass {obs_s:.3e} obs/s",
             "jacobian_obs_per_s": obs_s, "measured_iter_per_s_on_sample": it_s, "sample_observations": n_cpu}
     if rank == 0:

@@ -36,6 +36,42 @@ static double now_s(void) {
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* Threads.  The checker (libba_oracle.so) is built without OpenMP: one thread, the pragmas */
+/* below vanish and every sum runs in the written order.  libba_oracle_omp.so is the same   */
+/* source with -fopenmp, used only to time the all-cores CPU baseline.                      */
+/* ------------------------------------------------------------------------------------ */
+#ifdef _OPENMP
+#include <omp.h>
+#define BAO_TID() omp_get_thread_num()
+#define BAO_NT() omp_get_max_threads()
+#else
+#define BAO_TID() 0
+#define BAO_NT() 1
+#endif
+
+int bao_num_threads(void) { return BAO_NT(); }
+
+/* Scatter-add target of a parallel loop: thread t adds into its own zeroed copy, acc_end folds the copies into
+ * dst in thread order.  With one thread the copy is dst itself. */
+typedef struct { double *buf, *dst; size_t n; int T; } acc_t;
+static void acc_begin(acc_t *a, double *dst, size_t n) {
+  a->T = BAO_NT(); a->dst = dst; a->n = n;
+  a->buf = (a->T > 1) ? calloc((size_t)a->T * n + 1, sizeof(double)) : NULL;
+}
+static double *acc_mine(const acc_t *a) { return a->buf ? a->buf + (size_t)BAO_TID() * a->n : a->dst; }
+static void acc_end(acc_t *a) {
+  if (!a->buf) return;
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < (long)a->n; ++i) {
+    double v = a->dst[i];
+    for (int t = 0; t < a->T; ++t) v += a->buf[(size_t)t * a->n + i];
+    a->dst[i] = v;
+  }
+  free(a->buf);
+  a->buf = NULL;
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* Cost model                                                                             */
 /* ------------------------------------------------------------------------------------ */
 
@@ -409,6 +445,7 @@ static double eval_cost(const prob_t *q, const double *eop, const double *xyz, c
                         const double *ap, double *fixed, int apply_loss, double *residuals) {
   const ba_inputs *in = q->in;
   double cost = 0.0, fx = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : cost)
   for (int n = 0; n < q->N; ++n) {
     const int i = in->obs_sta[n], j = in->obs_pt[n], c = in->sta_cam[i];
     const double obs[6] = {in->obs_x[n], in->obs_y[n], in->obs_sx[n], in->obs_sy[n], in->obs_cx[n], in->obs_cy[n]};
@@ -447,7 +484,11 @@ static void linearize(prob_t *q, const double *eop, const double *xyz, const dou
   const int ncm = q->ncmax ? q->ncmax : 1;
   double cost = 0.0, fx = 0.0;
   memset(q->grad, 0, sizeof(double) * q->nt);
+  acc_t ga;
+  acc_begin(&ga, q->grad, (size_t)q->nt);
+#pragma omp parallel for schedule(static) reduction(+ : cost)
   for (int n = 0; n < q->N; ++n) {
+    double *grad = acc_mine(&ga);
     const int i = in->obs_sta[n], j = in->obs_pt[n], c = in->sta_cam[i];
     const double obs[6] = {in->obs_x[n], in->obs_y[n], in->obs_sx[n], in->obs_sy[n], in->obs_cx[n], in->obs_cy[n]};
     double r[2], J[56], rho[3];
@@ -459,7 +500,7 @@ static void linearize(prob_t *q, const double *eop, const double *xyz, const dou
     r[1] *= sc;
     double *Js = q->Js + 12 * (size_t)n, *Jp = q->Jp + 6 * (size_t)n, *Jc = q->Jc + 2 * (size_t)ncm * n;
     const double *ss = q->scale + COL_STA(q, i), *sp = q->scale + COL_PT(q, j), *scm = q->scale + COL_CAM(q, c);
-    double *gs = q->grad + COL_STA(q, i), *gp = q->grad + COL_PT(q, j), *gc = q->grad + COL_CAM(q, c);
+    double *gs = grad + COL_STA(q, i), *gp = grad + COL_PT(q, j), *gc = grad + COL_CAM(q, c);
     for (int k = 0; k < 6; ++k) {
       const double a = sc * J[k], b = sc * J[28 + k];
       gs[k] += a * r[0] + b * r[1];
@@ -482,6 +523,7 @@ static void linearize(prob_t *q, const double *eop, const double *xyz, const dou
     q->res[2 * (size_t)n] = r[0];
     q->res[2 * (size_t)n + 1] = r[1];
   }
+  acc_end(&ga);
   for (int j = 0; j < q->P; ++j) {
     double r[3];
     bao_constrain_point(xyz + 3 * j, in->pt_prior + 3 * j, in->pt_sigma + 3 * j, r);
@@ -520,13 +562,18 @@ static void column_sqnorm(const prob_t *q, double *out) {
   const ba_inputs *in = q->in;
   const int ncm = q->ncmax ? q->ncmax : 1;
   memset(out, 0, sizeof(double) * q->nt);
+  acc_t oa;
+  acc_begin(&oa, out, (size_t)q->nt);
+#pragma omp parallel for schedule(static)
   for (int n = 0; n < q->N; ++n) {
+    double *o = acc_mine(&oa);
     const int i = in->obs_sta[n], j = in->obs_pt[n], c = in->sta_cam[i];
     const double *Js = q->Js + 12 * (size_t)n, *Jp = q->Jp + 6 * (size_t)n, *Jc = q->Jc + 2 * (size_t)ncm * n;
-    for (int k = 0; k < 6; ++k) out[COL_STA(q, i) + k] += Js[k] * Js[k] + Js[6 + k] * Js[6 + k];
-    for (int k = 0; k < 3; ++k) out[COL_PT(q, j) + k] += Jp[k] * Jp[k] + Jp[3 + k] * Jp[3 + k];
-    for (int k = 0; k < q->cam_nc[c]; ++k) out[COL_CAM(q, c) + k] += Jc[k] * Jc[k] + Jc[ncm + k] * Jc[ncm + k];
+    for (int k = 0; k < 6; ++k) o[COL_STA(q, i) + k] += Js[k] * Js[k] + Js[6 + k] * Js[6 + k];
+    for (int k = 0; k < 3; ++k) o[COL_PT(q, j) + k] += Jp[k] * Jp[k] + Jp[3 + k] * Jp[3 + k];
+    for (int k = 0; k < q->cam_nc[c]; ++k) o[COL_CAM(q, c) + k] += Jc[k] * Jc[k] + Jc[ncm + k] * Jc[ncm + k];
   }
+  acc_end(&oa);
   for (int j = 0; j < 3 * q->P; ++j) out[6 * q->S + j] += q->jp[j] * q->jp[j];
   for (int k = 0; k < q->ncam; ++k) out[6 * q->S + 3 * q->P + k] += q->jc[k] * q->jc[k];
 }
@@ -536,6 +583,7 @@ static double model_cost_change(const prob_t *q, const double *v) {
   const ba_inputs *in = q->in;
   const int ncm = q->ncmax ? q->ncmax : 1;
   double acc = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : acc)
   for (int n = 0; n < q->N; ++n) {
     const int i = in->obs_sta[n], j = in->obs_pt[n], c = in->sta_cam[i];
     const double *Js = q->Js + 12 * (size_t)n, *Jp = q->Jp + 6 * (size_t)n, *Jc = q->Jc + 2 * (size_t)ncm * n;
@@ -624,14 +672,19 @@ static void normal_rhs(const prob_t *q, double *g) {
   const ba_inputs *in = q->in;
   const int ncm = q->ncmax ? q->ncmax : 1;
   memset(g, 0, sizeof(double) * q->nt);
+  acc_t ga;
+  acc_begin(&ga, g, (size_t)q->nt);
+#pragma omp parallel for schedule(static)
   for (int n = 0; n < q->N; ++n) {
+    double *o = acc_mine(&ga);
     const int i = in->obs_sta[n], j = in->obs_pt[n], c = in->sta_cam[i];
     const double *Js = q->Js + 12 * (size_t)n, *Jp = q->Jp + 6 * (size_t)n, *Jc = q->Jc + 2 * (size_t)ncm * n;
     const double r0 = q->res[2 * (size_t)n], r1 = q->res[2 * (size_t)n + 1];
-    for (int k = 0; k < 6; ++k) g[COL_STA(q, i) + k] += Js[k] * r0 + Js[6 + k] * r1;
-    for (int k = 0; k < 3; ++k) g[COL_PT(q, j) + k] += Jp[k] * r0 + Jp[3 + k] * r1;
-    for (int k = 0; k < q->cam_nc[c]; ++k) g[COL_CAM(q, c) + k] += Jc[k] * r0 + Jc[ncm + k] * r1;
+    for (int k = 0; k < 6; ++k) o[COL_STA(q, i) + k] += Js[k] * r0 + Js[6 + k] * r1;
+    for (int k = 0; k < 3; ++k) o[COL_PT(q, j) + k] += Jp[k] * r0 + Jp[3 + k] * r1;
+    for (int k = 0; k < q->cam_nc[c]; ++k) o[COL_CAM(q, c) + k] += Jc[k] * r0 + Jc[ncm + k] * r1;
   }
+  acc_end(&ga);
   for (int j = 0; j < 3 * q->P; ++j) g[6 * q->S + j] += q->jp[j] * q->rp[j];
   for (int k = 0; k < q->ncam; ++k) g[6 * q->S + 3 * q->P + k] += q->jc[k] * q->rc[k];
 }
@@ -675,6 +728,8 @@ static int solve_full_dense(const prob_t *q, const double *D2, double *y) {
 
 /* Point elimination shared by the two Schur modes: V_j^-1 and g_pj */
 static int eliminate_points(const prob_t *q, const double *D2, const double *g, double *Vinv) {
+  int bad = q->P; /* first point whose block cannot be inverted */
+#pragma omp parallel for schedule(static) reduction(min : bad)
   for (int j = 0; j < q->P; ++j) {
     double V[6] = {0, 0, 0, 0, 0, 0};
     for (int e = q->pt_start[j]; e < q->pt_start[j + 1]; ++e) {
@@ -690,9 +745,10 @@ static int eliminate_points(const prob_t *q, const double *D2, const double *g, 
     V[0] += jp[0] * jp[0] + d2[0];
     V[3] += jp[1] * jp[1] + d2[1];
     V[5] += jp[2] * jp[2] + d2[2];
-    if (inv3(V, Vinv + 6 * (size_t)j)) FAIL(BA_ERR_NUMERIC, "point block %d is not positive definite", j);
+    if (inv3(V, Vinv + 6 * (size_t)j) && j < bad) bad = j;
   }
   (void)g;
+  if (bad < q->P) FAIL(BA_ERR_NUMERIC, "point block %d is not positive definite", bad);
   return 0;
 }
 
@@ -711,9 +767,10 @@ static int cam_side(const prob_t *q, int n, int *idx, double *v0, double *v1) {
 
 static void back_substitute(const prob_t *q, const double *Vinv, const double *g, const double *yc, double *y) {
   /* y_p = V^-1 (g_p - W^T y_c), W^T y_c = sum_obs Jp^T (Jc_side y_c) */
-  int idx[6 + NCAMPAR];
-  double v0[6 + NCAMPAR], v1[6 + NCAMPAR];
+#pragma omp parallel for schedule(static)
   for (int j = 0; j < q->P; ++j) {
+    int idx[6 + NCAMPAR];
+    double v0[6 + NCAMPAR], v1[6 + NCAMPAR];
     double t[3] = {0, 0, 0};
     for (int e = q->pt_start[j]; e < q->pt_start[j + 1]; ++e) {
       const int n = q->pt_obs[e];
@@ -818,10 +875,14 @@ done:
 /* implicit reduced operator: out = S p,  S = Jc^T (I - Jp V^-1 Jp^T) Jc + prior + D^2 */
 static void schur_apply(const prob_t *q, const double *D2, const double *Vinv, const double *p, double *out, double *tmp2N) {
   const int S6 = 6 * q->S, nr = q->nr;
-  int idx[6 + NCAMPAR];
-  double v0[6 + NCAMPAR], v1[6 + NCAMPAR];
   for (int i = 0; i < nr; ++i) out[i] = 0.0;
+  acc_t oa;
+  acc_begin(&oa, out, (size_t)nr);
+#pragma omp parallel for schedule(static)
   for (int j = 0; j < q->P; ++j) {
+    double *o = acc_mine(&oa);
+    int idx[6 + NCAMPAR];
+    double v0[6 + NCAMPAR], v1[6 + NCAMPAR];
     double t[3] = {0, 0, 0}, u[3];
     for (int e = q->pt_start[j]; e < q->pt_start[j + 1]; ++e) {
       const int n = q->pt_obs[e];
@@ -840,9 +901,10 @@ static void schur_apply(const prob_t *q, const double *D2, const double *Vinv, c
       const double b0 = tmp2N[2 * (size_t)n] - (Jp[0] * u[0] + Jp[1] * u[1] + Jp[2] * u[2]);
       const double b1 = tmp2N[2 * (size_t)n + 1] - (Jp[3] * u[0] + Jp[4] * u[1] + Jp[5] * u[2]);
       const int m = cam_side(q, n, idx, v0, v1);
-      for (int k = 0; k < m; ++k) out[idx[k]] += v0[k] * b0 + v1[k] * b1;
+      for (int k = 0; k < m; ++k) o[idx[k]] += v0[k] * b0 + v1[k] * b1;
     }
   }
+  acc_end(&oa);
   for (int k = 0; k < q->ncam; ++k) out[S6 + k] += q->jc[k] * q->jc[k] * p[S6 + k];
   for (int i = 0; i < S6; ++i) out[i] += D2[i] * p[i];
   for (int k = 0; k < q->ncam; ++k) out[S6 + k] += D2[S6 + 3 * q->P + k] * p[S6 + k];
@@ -870,13 +932,20 @@ static int solve_schur_pcg(const prob_t *q, const double *D2, double rtol, int m
   if ((rc = eliminate_points(q, D2, g, Vinv))) goto done;
   /* rhs: b = g_c - sum Jc^T Jp V^-1 g_p  == Jc^T (r - Jp V^-1 g_p) + prior part */
   {
-    int idx[6 + NCAMPAR];
-    double v0[6 + NCAMPAR], v1[6 + NCAMPAR];
     for (int i = 0; i < S6; ++i) b[i] = g[i];
     for (int k = 0; k < nc; ++k) b[S6 + k] = g[S6 + 3 * q->P + k];
     const int ncm = q->ncmax ? q->ncmax : 1;
-    double *B = calloc((size_t)3 * (nc + 1), sizeof(double));
+    double *Ball = calloc((size_t)3 * (nc + 1) * BAO_NT(), sizeof(double));
+    acc_t ba, mba, mca;
+    acc_begin(&ba, b, (size_t)nr);
+    acc_begin(&mba, Mb, (size_t)36 * q->S);
+    acc_begin(&mca, Mc, (size_t)nc * nc);
+#pragma omp parallel for schedule(static)
     for (int j = 0; j < q->P; ++j) {
+      double *b = acc_mine(&ba), *Mb = acc_mine(&mba), *Mc = acc_mine(&mca); /* this thread's copies */
+      double *B = Ball + (size_t)3 * (nc + 1) * BAO_TID();
+      int idx[6 + NCAMPAR];
+      double v0[6 + NCAMPAR], v1[6 + NCAMPAR];
       double vg[3];
       sym3_mul(Vinv + 6 * (size_t)j, g + S6 + 3 * j, vg);
       const double *Vi = Vinv + 6 * (size_t)j;
@@ -919,7 +988,10 @@ static int solve_schur_pcg(const prob_t *q, const double *D2, double rtol, int m
           Mc[(size_t)a * nc + c2] -= zb[0] * B[3 * c2] + zb[1] * B[3 * c2 + 1] + zb[2] * B[3 * c2 + 2];
       }
     }
-    free(B);
+    acc_end(&ba);
+    acc_end(&mba);
+    acc_end(&mca);
+    free(Ball);
     for (int i = 0; i < q->S; ++i) {
       double *blk = Mb + 36 * (size_t)i;
       for (int k = 0; k < 6; ++k) blk[7 * k] += D2[6 * i + k];

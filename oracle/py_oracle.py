@@ -16,20 +16,38 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 FULL_DENSE, SCHUR_DENSE, SCHUR_PCG = 0, 1, 2
 
 _lib = None
+_lib_omp = None
 _ref = None
 
 
+def _load(name):
+    path = os.path.join(_HERE, name)
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `make -C oracle` (or __graft_entry__.build())")
+    L = C.CDLL(path)
+    L.bao_last_error.restype = C.c_char_p
+    L.bao_linearize_once.restype = C.c_double
+    return L
+
+
 def lib():
+    """The checker: one thread, every sum in the written order."""
     global _lib
     if _lib is None:
-        path = os.path.join(_HERE, "libba_oracle.so")
-        if not os.path.exists(path):
-            raise RuntimeError(f"{path} is missing: run `make -C oracle` (or __graft_entry__.build())")
-        L = C.CDLL(path)
-        L.bao_last_error.restype = C.c_char_p
-        L.bao_linearize_once.restype = C.c_double
-        _lib = L
+        _lib = _load("libba_oracle.so")
     return _lib
+
+
+def lib_omp():
+    """The same source built with OpenMP: only for timing the all-cores CPU baseline, never for checking."""
+    global _lib_omp
+    if _lib_omp is None:
+        _lib_omp = _load("libba_oracle_omp.so")
+    return _lib_omp
+
+
+def omp_threads():
+    return int(lib_omp().bao_num_threads())
 
 
 def ref_lib():
@@ -115,7 +133,7 @@ def sparsity(net):
     return nr.value, nc.value, rows, cols
 
 
-def solve(net, options, mode=SCHUR_DENSE, rows_cap=256, iop_bounds=None):
+def solve(net, options, mode=SCHUR_DENSE, rows_cap=256, iop_bounds=None, omp=False):
     """Returns (eop, xyz, iop, ap, summary dict, list of iteration-row dicts).
     iop_bounds = (lower [C,3], upper [C,3]): the box of src/main.cpp:4252-4256."""
     d, inp = net.dims(), net.inputs()
@@ -125,7 +143,7 @@ def solve(net, options, mode=SCHUR_DENSE, rows_cap=256, iop_bounds=None):
     lo = hi = None
     if iop_bounds is not None:
         lo, hi = (np.ascontiguousarray(b, dtype=np.float64).reshape(net.n_cam, 3) for b in iop_bounds)
-    _check(lib().bao_solve_bounded(C.byref(d), C.byref(inp), C.byref(options), int(mode),
+    _check((lib_omp() if omp else lib()).bao_solve_bounded(C.byref(d), C.byref(inp), C.byref(options), int(mode),
                                    _dp(lo) if lo is not None else None, _dp(hi) if hi is not None else None,
                                    _dp(eop), _dp(xyz), _dp(iop), _dp(ap), C.byref(sm), rows, rows_cap))
     return eop, xyz, iop, ap, summary_to_dict(sm), rows_to_dicts(rows, min(sm.num_iterations, rows_cap))
@@ -152,9 +170,9 @@ def covariance(net, eop=None, xyz=None, iop=None, ap=None):
     return ve, vx, vi, va
 
 
-def linearize_once(net):
+def linearize_once(net, omp=False):
     d, inp = net.dims(), net.inputs()
-    return lib().bao_linearize_once(C.byref(d), C.byref(inp), _dp(net.eop), _dp(net.xyz), _dp(net.iop), _dp(net.ap))
+    return (lib_omp() if omp else lib()).bao_linearize_once(C.byref(d), C.byref(inp), _dp(net.eop), _dp(net.xyz), _dp(net.iop), _dp(net.ap))
 
 
 # ---- the reference functors themselves (present only where /root/reference was available at build time)

@@ -147,3 +147,20 @@ def test_huber_known_answers():
     assert c0 == pytest.approx(0.5 * rho.sum() + 0.5 * (pri ** 2).sum(), rel=1e-14)
     sc = np.where(s > 1, s ** -0.25, 1.0)
     assert np.allclose(r1[0:2 * N:2], sc * r0[0:2 * N:2], rtol=1e-15, atol=0)
+
+
+def test_openmp_build_of_the_oracle_agrees_with_the_checker():
+    # libba_oracle_omp.so only times the all-cores CPU baseline; it must still be the same computation
+    from bundleadjustment_amd import capi, host
+    net = host.synth_config("cfg4", scale=0.001).net
+    opt = capi.default_options(linear_solver=capi.SOLVER_PCG_SCHUR)
+    opt.max_num_iterations = 3
+    a = po.solve(net, opt, po.SCHUR_PCG)
+    b = po.solve(net, opt, po.SCHUR_PCG, omp=True)
+    assert po.omp_threads() >= 1
+    assert a[4]["num_iterations"] == b[4]["num_iterations"]
+    for ra, rb in zip(a[5], b[5]):
+        assert abs(ra["cost"] - rb["cost"]) <= 1e-11 * ra["cost"]
+    for x, y in zip(a[:4], b[:4]):
+        assert np.max(np.abs(x - y)) <= 1e-9 * max(1.0, np.max(np.abs(x)))
+    assert abs(po.linearize_once(net) - po.linearize_once(net, omp=True)) <= 1e-11 * abs(po.linearize_once(net))
