@@ -14,9 +14,11 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ba_device.h"
@@ -172,7 +174,40 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // set-up
 // ---------------------------------------------------------------------------------------------
+// Host worker threads for the set-up's memory-bound loops: OMP_NUM_THREADS when set (job schedulers size it to
+// the cores a process may use), else the hardware's count, at most 16.
+int setup_threads() {
+  int n = 0;
+  if (const char *e = std::getenv("OMP_NUM_THREADS")) n = std::atoi(e);
+  if (n <= 0) n = (int)std::thread::hardware_concurrency();
+  return std::max(1, std::min(n, 16));
+}
+
+// fn(begin, end) over [0, n) split into one contiguous range per thread
+template <class F>
+void parallel_ranges(int64_t n, F fn) {
+  const int T = (n < (1 << 16)) ? 1 : setup_threads();
+  if (T == 1) { fn((int64_t)0, n); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t) th.emplace_back(fn, n * t / T, n * (t + 1) / T);
+  for (auto &x : th) x.join();
+}
+
+// Wall-clock marks of the set-up phases on stderr when BA_TRACE_SETUP is set in the environment
+// (the reference prints its own timers the same way, src/main.cpp:3027, 4703).
+struct SetupTrace {
+  bool on = std::getenv("BA_TRACE_SETUP") != nullptr;
+  double t = now_s();
+  void mark(const char *what) {
+    if (!on) return;
+    const double u = now_s();
+    fprintf(stderr, "ba_create: %-28s %8.3f s\n", what, u - t);
+    t = u;
+  }
+};
+
 int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
+  SetupTrace trace;
   const int N = d->n_obs, S = d->n_sta, P = d->n_pts, C = d->n_cam;
   if (N < 0 || S < 0 || P < 0 || C < 0) return fail(BA_ERR_INVALID, "negative dimension");
   if (in->model < 0 || in->model > 7)
@@ -197,6 +232,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   for (int k = 0; k < 3 * C; ++k)
     if (!(in->iop_sigma[k] > 0.0)) return fail(BA_ERR_INVALID, "camera %d: prior sigma must be positive", k / 3);
 
+  trace.mark("validation");
   p->obs_pt_h.assign(in->obs_pt, in->obs_pt + N);
   p->obs_sta_h.assign(in->obs_sta, in->obs_sta + N);
   p->sta_cam_h.assign(in->sta_cam, in->sta_cam + S);
@@ -238,6 +274,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   p->ncam = off;
   p->nr = 6 * S + p->ncam;
 
+  trace.mark("degrees, cameras");
   // internal point order: by number of observations (descending, stable) so that the lanes of
   // a wave walk segments of similar length
   p->pt_file.resize(P);
@@ -250,18 +287,21 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   // observations sorted by internal point, file order inside a point
   std::vector<int> fill(pt_start.begin(), pt_start.end() - 1);
   std::vector<double> obs((size_t)N * BA_OBS_STRIDE, 0.0);
-  std::vector<int> obs_pt(N), e_sta(N);
-  for (int n = 0; n < N; ++n) {
-    const int jj = pt_int[in->obs_pt[n]];
-    const int e = fill[jj]++;
-    double *o = &obs[(size_t)e * BA_OBS_STRIDE];
-    o[0] = in->obs_x[n]; o[1] = in->obs_y[n]; o[2] = in->obs_sx[n]; o[3] = in->obs_sy[n];
-    o[4] = in->obs_cx[n]; o[5] = in->obs_cy[n];
-    int32_t w[2] = {in->obs_sta[n], n};
-    std::memcpy(&o[6], w, sizeof w);
-    obs_pt[e] = jj;
-    e_sta[e] = in->obs_sta[n];
-  }
+  std::vector<int> obs_pt(N), e_sta(N), slot(N);
+  for (int n = 0; n < N; ++n) slot[n] = fill[pt_int[in->obs_pt[n]]]++;  // the only order-dependent part
+  parallel_ranges(N, [&](int64_t n0, int64_t n1) {
+    for (int64_t n = n0; n < n1; ++n) {
+      const int e = slot[n];
+      double *o = &obs[(size_t)e * BA_OBS_STRIDE];
+      o[0] = in->obs_x[n]; o[1] = in->obs_y[n]; o[2] = in->obs_sx[n]; o[3] = in->obs_sy[n];
+      o[4] = in->obs_cx[n]; o[5] = in->obs_cy[n];
+      int32_t w[2] = {in->obs_sta[n], (int32_t)n};
+      std::memcpy(&o[6], w, sizeof w);
+      obs_pt[e] = pt_int[in->obs_pt[n]];
+      e_sta[e] = in->obs_sta[n];
+    }
+  });
+  trace.mark("observations by point");
   // station-sorted index list and its chunks
   std::vector<int> sta_start(S + 1, 0);
   for (int i = 0; i < S; ++i) sta_start[i + 1] = sta_start[i] + sdeg[i];
@@ -285,6 +325,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   // (chunks are laid out in station order and stations are contiguous in sta_list, so
   //  chunk_begin[ch+1] is also the end of chunk ch)
 
+  trace.mark("observations by station");
   // Block structure of the reduced matrix: every unordered pair of observations of one point
   // couples the two stations.  Pairs are grouped by (lo station, hi station); the groups become
   // the upper-triangular blocks, mirrored into a full BSR pattern for the SpMV.
@@ -318,6 +359,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
           hi_of[q] = hi; ea_of[q] = a; eb_of[q] = b;
         });
       }
+      trace.mark("pairs by low station");
       // inside a row: stable counting sort by hi (keeps point order inside a block)
       pairs.resize(tot);
       std::vector<int> cnt(S + 1), nb_lo(S, 0), nb_hi(S, 0);
@@ -346,6 +388,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
         }
         for (int h : touched) cnt[h] = 0;
       }
+      trace.mark("pairs by block");
       const int nu = (int)ub_lo.size();
       // full BSR pattern: diagonal first, then neighbours in ascending column order
       std::vector<int> nnb(S, 1);
@@ -379,6 +422,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
     }
   }
 
+  trace.mark("block-sparse pattern");
   std::vector<double> prior(3 * (size_t)P), isig(3 * (size_t)P);
   for (int jj = 0; jj < P; ++jj)
     for (int k = 0; k < 3; ++k) {
@@ -386,7 +430,9 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
       isig[3 * (size_t)jj + k] = 1.0 / in->pt_sigma[3 * (size_t)p->pt_file[jj] + k];
     }
 
+  trace.mark("point priors");
   HIP_OK(hipStreamCreate(&p->stream));
+  trace.mark("stream");
   BA_TRY(p->upload(&p->d_pt_start, pt_start));
   BA_TRY(p->upload(&p->d_obs_pt, obs_pt));
   BA_TRY(p->upload(&p->d_obs_sta, e_sta));
@@ -401,6 +447,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   BA_TRY(p->upload(&p->d_pt_prior, prior));
   BA_TRY(p->upload(&p->d_pt_isig, isig));
   BA_TRY(p->upload(&p->d_cam, p->cam_h));
+  trace.mark("uploads");
   BA_TRY(p->dalloc(&p->d_cam_c, (size_t)C));
   BA_TRY(p->dalloc(&p->d_info, 4));
   BA_TRY(p->dalloc(&p->d_flags, 4));
@@ -436,6 +483,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   BA_TRY(p->dalloc(&p->d_part, (size_t)std::max(std::max(39, border_nacc()), 6 * p->ncam) * p->n_chunks));
   BA_TRY(p->dalloc(&p->d_Sdiag, 36 * (size_t)S));
   BA_TRY(p->dalloc(&p->d_corner, 64));
+  trace.mark("allocations");
   if (p->explicit_ok) {
     BA_TRY(p->upload(&p->d_bsr_rowptr, bsr_rowptr));
     BA_TRY(p->upload(&p->d_bsr_col, bsr_col));
@@ -450,6 +498,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
     BA_TRY(p->dalloc(&p->d_part_rz, npart));
     BA_TRY(p->dalloc(&p->d_cg2scal, 16));
   }
+  trace.mark("pair lists upload");
   const bool single_camera_path = C == 1 && p->ncmax > 0 && p->ncmax <= border_ncb() && border_ncb() == lin_ncb();
   if (p->ncam > 0 && !single_camera_path && (double)P * p->ncam * 24.0 <= 16e9) {
     std::vector<int> col_cam(p->ncam), col_pos(p->ncam);
@@ -488,6 +537,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   HIP_OK(hipMemsetAsync(p->d_flags, 0, 4 * sizeof(unsigned), p->stream));
   HIP_OK(hipMemsetAsync(p->d_scal, 0, SC_COUNT * sizeof(double), p->stream));
   HIP_OK(hipStreamSynchronize(p->stream));
+  trace.mark("remaining allocations");
   return 0;
 }
 
