@@ -24,7 +24,23 @@ def _make_net(n_cam=1):
                       control_every=8).net
 
 
-def _worker(rank, world, port, ls, n_cam, out):
+def _box(net):
+    """A box on xp yp c whose upper bound on camera 0's xp is active at the solution."""
+    lo = np.tile([-100.0, -100.0, 0.0], (net.n_cam, 1))
+    hi = np.tile([100.0, 100.0, np.finfo(np.float64).max], (net.n_cam, 1))
+    hi[0, 0] = net.truth["iop"][0, 0] - 1.0
+    return lo, hi
+
+
+def _options(ls, bounded):
+    from bundleadjustment_amd import capi
+    opt = capi.default_options(linear_solver=ls)
+    if bounded:  # LM damping, so that the projected steps keep descending (see test_gpu_bounds.py)
+        opt.min_lm_diagonal, opt.max_lm_diagonal, opt.max_num_iterations = 1e-6, 1e32, 12
+    return opt
+
+
+def _worker(rank, world, port, ls, n_cam, out, bounded=False):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -41,8 +57,9 @@ def _worker(rank, world, port, ls, n_cam, out):
 
     with solver.Problem(shard) as P:
         P.set_allreduce_host_staged(reduce_fn)
-        opt = solver.default_options()
-        opt.linear_solver = ls
+        if bounded:
+            P.set_iop_bounds(*_box(net))
+        opt = _options(ls, bounded)
         eop, xyz, iop, ap, sm, rows = P.solve(opt)
     gathered = [None] * world
     dist.all_gather_object(gathered, (sl.start, sl.stop, xyz))
@@ -55,15 +72,15 @@ def _worker(rank, world, port, ls, n_cam, out):
 
 
 # one camera: the fused single-camera border and the camera coarse space; three cameras: the general border
-@pytest.mark.parametrize("ls,n_cam", [(0, 1), (1, 1), (2, 1), (0, 3), (1, 3)])
-def test_two_ranks_match_oracle(ls, n_cam):
+@pytest.mark.parametrize("ls,n_cam,bounded", [(0, 1, False), (1, 1, False), (2, 1, False), (0, 3, False), (1, 3, False), (1, 1, True)])
+def test_two_ranks_match_oracle(ls, n_cam, bounded):
     from oracle import py_oracle as po
     from bundleadjustment_amd import capi
     from util import assert_solve_parity
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ls, n_cam, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ls, n_cam, q, bounded)) for r in range(2)]
     for p in procs:
         p.start()
     res = q.get(timeout=240)
@@ -71,8 +88,8 @@ def test_two_ranks_match_oracle(ls, n_cam):
         p.join(60)
         assert p.exitcode == 0
     net = _make_net(n_cam)
-    opt = capi.default_options(linear_solver=ls)
-    o = po.solve(net, opt, po.SCHUR_DENSE)
+    opt = _options(ls, bounded)
+    o = po.solve(net, opt, po.SCHUR_DENSE, iop_bounds=_box(net) if bounded else None)
     # the summary sizes of a shard count its own points only: compare costs, steps and parameters
     g = list(res)
     for k in ("num_residuals_reduced", "num_parameters_reduced", "num_effective_parameters_reduced", "num_parameters",
