@@ -129,6 +129,11 @@ struct ba_problem {
   int *d_col_cam = nullptr, *d_col_pos = nullptr;
   // state
   bool have_params = false;
+  // second stream: the numbers of the multilevel preconditioner are set up beside the camera border, both
+  // only depend on the station blocks of the reduced matrix
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_blocks = nullptr, ev_amg = nullptr;
+  bool amg_numbers_queued = false;
   bool boxed = false;        // ba_set_iop_bounds gave some camera a finite bound
   bool constrained = false;  // ... and that camera's IOP block is variable: the solve takes Ceres' bounds-constrained route
   // multi-GPU
@@ -432,6 +437,9 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
 
   trace.mark("point priors");
   HIP_OK(hipStreamCreate(&p->stream));
+  HIP_OK(hipStreamCreate(&p->stream2));
+  HIP_OK(hipEventCreateWithFlags(&p->ev_blocks, hipEventDisableTiming));
+  HIP_OK(hipEventCreateWithFlags(&p->ev_amg, hipEventDisableTiming));
   trace.mark("stream");
   BA_TRY(p->upload(&p->d_pt_start, pt_start));
   BA_TRY(p->upload(&p->d_obs_pt, obs_pt));
@@ -720,11 +728,22 @@ int build_reduced(ba_problem *p, bool explicit_blocks) {
   hipStream_t s = p->stream;
   const size_t ns = 6 * (size_t)p->S;
   if (explicit_blocks) {
+    // numbers queued for the previous matrix and never waited for (the solve took another route) still read it
+    if (p->amg_numbers_queued) HIP_OK(hipStreamWaitEvent(s, p->ev_amg, 0));
     HIP_OK(hipMemsetAsync(p->d_bsr_val, 0, 36 * (size_t)p->n_bsr * sizeof(double), s));
     launch_schur_blocks(s, p->n_ublk, p->d_ublk_cstart, p->d_ublk_dst, p->d_pairs, p->d_Y, p->d_bsr_val);
     BA_TRY(p->allreduce(p->d_bsr_val, 36 * (int64_t)p->n_bsr, 0));
     launch_bsr_add_diag(s, p->S, p->d_bsr_rowptr, p->d_Sdiag, p->d_bsr_val);
     launch_invert_blocks(s, p->S, p->d_bsr_val, p->d_bsr_rowptr, p->d_sta_used, p->d_Minv, p->d_flags);
+    if (p->amg) {
+      // the hierarchy exists (a multilevel PCG solve has run): refresh its numbers on the second stream while this
+      // one goes on with the camera border; solve_pcg_explicit waits for them
+      HIP_OK(hipEventRecord(p->ev_blocks, s));
+      HIP_OK(hipStreamWaitEvent(p->stream2, p->ev_blocks, 0));
+      amg_numeric(p->amg, p->stream2, p->d_bsr_val, p->d_Minv);
+      HIP_OK(hipEventRecord(p->ev_amg, p->stream2));
+      p->amg_numbers_queued = true;
+    }
   } else {
     launch_invert_blocks(s, p->S, p->d_Sdiag, nullptr, p->d_sta_used, p->d_Minv, p->d_flags);
   }
@@ -790,9 +809,12 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
         p->amg = nullptr;
         return rc;
       }
+    } else if (p->amg_numbers_queued) {
+      HIP_OK(hipStreamWaitEvent(s, p->ev_amg, 0));  // queued by build_reduced for this matrix
     } else {
       amg_numeric(p->amg, s, p->d_bsr_val, p->d_Minv);
     }
+    p->amg_numbers_queued = false;
     if (amg_levels(p->amg) < 2) use_amg = false;  // nothing to coarsen: plain block-Jacobi
   }
   // Camera coarse space: the few camera columns couple to every station, which a block-diagonal
@@ -1120,12 +1142,16 @@ int ba_create(const ba_dims *dims, const ba_inputs *in, ba_problem **out) {
 void ba_destroy(ba_problem *p) {
   if (!p) return;
   if (p->stream) hipStreamSynchronize(p->stream);
+  if (p->stream2) hipStreamSynchronize(p->stream2);
   if (p->comm) ncclCommDestroy(p->comm);
   if (p->cg_graph) hipGraphExecDestroy(p->cg_graph);
   if (p->amg) ba::amg_destroy(p->amg);
   for (void *q : p->allocs) hipFree(q);
   if (p->h_scal) hipHostFree(p->h_scal);
   if (p->h_cgscal) hipHostFree(p->h_cgscal);
+  if (p->ev_blocks) hipEventDestroy(p->ev_blocks);
+  if (p->ev_amg) hipEventDestroy(p->ev_amg);
+  if (p->stream2) hipStreamDestroy(p->stream2);
   if (p->stream) hipStreamDestroy(p->stream);
   delete p;
 }
