@@ -132,8 +132,9 @@ struct ba_problem {
   // second stream: the numbers of the multilevel preconditioner are set up beside the camera border, both
   // only depend on the station blocks of the reduced matrix
   hipStream_t stream2 = nullptr;
-  hipEvent_t ev_blocks = nullptr, ev_amg = nullptr;
+  hipEvent_t ev_blocks = nullptr, ev_amg = nullptr, ev_rows = nullptr, ev_schur = nullptr;
   bool amg_numbers_queued = false;
+  bool schur_queued = false;  // the off-diagonal blocks of this linearisation are being assembled on stream2
   bool boxed = false;        // ba_set_iop_bounds gave some camera a finite bound
   bool constrained = false;  // ... and that camera's IOP block is variable: the solve takes Ceres' bounds-constrained route
   // multi-GPU
@@ -440,6 +441,8 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   HIP_OK(hipStreamCreate(&p->stream2));
   HIP_OK(hipEventCreateWithFlags(&p->ev_blocks, hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&p->ev_amg, hipEventDisableTiming));
+  HIP_OK(hipEventCreateWithFlags(&p->ev_rows, hipEventDisableTiming));
+  HIP_OK(hipEventCreateWithFlags(&p->ev_schur, hipEventDisableTiming));
   trace.mark("stream");
   BA_TRY(p->upload(&p->d_pt_start, pt_start));
   BA_TRY(p->upload(&p->d_obs_pt, obs_pt));
@@ -636,6 +639,16 @@ int linearize(ba_problem *p, const LmState &st) {
   la.Jt = p->d_Jt;
   la.cam_partial = p->d_campart;
   launch_linearize(s, la);
+  if (st.reduced == 2) {
+    // the off-diagonal blocks only need the rows Y: assembled on the second stream while this one sweeps the stations
+    // (stream2 is in order, so numbers of the preconditioner still being set up from the old blocks finish first)
+    HIP_OK(hipEventRecord(p->ev_rows, s));
+    HIP_OK(hipStreamWaitEvent(p->stream2, p->ev_rows, 0));
+    HIP_OK(hipMemsetAsync(p->d_bsr_val, 0, 36 * (size_t)p->n_bsr * sizeof(double), p->stream2));
+    launch_schur_blocks(p->stream2, p->n_ublk, p->d_ublk_cstart, p->d_ublk_dst, p->d_pairs, p->d_Y, p->d_bsr_val);
+    HIP_OK(hipEventRecord(p->ev_schur, p->stream2));
+    p->schur_queued = true;
+  }
   launch_sum_partials(s, p->d_partial, linearize_blocks(p->P), p->d_scal, SC_COST);
   BA_TRY(p->allreduce(p->d_scal + SC_COST, 1, 0));
   launch_camera_prior_cost(s, p->C, p->d_cam, p->d_scal, SC_COST, SC_FIXED, nullptr);
@@ -728,10 +741,15 @@ int build_reduced(ba_problem *p, bool explicit_blocks) {
   hipStream_t s = p->stream;
   const size_t ns = 6 * (size_t)p->S;
   if (explicit_blocks) {
-    // numbers queued for the previous matrix and never waited for (the solve took another route) still read it
-    if (p->amg_numbers_queued) HIP_OK(hipStreamWaitEvent(s, p->ev_amg, 0));
-    HIP_OK(hipMemsetAsync(p->d_bsr_val, 0, 36 * (size_t)p->n_bsr * sizeof(double), s));
-    launch_schur_blocks(s, p->n_ublk, p->d_ublk_cstart, p->d_ublk_dst, p->d_pairs, p->d_Y, p->d_bsr_val);
+    if (p->schur_queued) {
+      HIP_OK(hipStreamWaitEvent(s, p->ev_schur, 0));  // queued by linearize right after the rows were written
+      p->schur_queued = false;
+    } else {
+      // numbers queued for the previous matrix and never waited for (the solve took another route) still read it
+      if (p->amg_numbers_queued) HIP_OK(hipStreamWaitEvent(s, p->ev_amg, 0));
+      HIP_OK(hipMemsetAsync(p->d_bsr_val, 0, 36 * (size_t)p->n_bsr * sizeof(double), s));
+      launch_schur_blocks(s, p->n_ublk, p->d_ublk_cstart, p->d_ublk_dst, p->d_pairs, p->d_Y, p->d_bsr_val);
+    }
     BA_TRY(p->allreduce(p->d_bsr_val, 36 * (int64_t)p->n_bsr, 0));
     launch_bsr_add_diag(s, p->S, p->d_bsr_rowptr, p->d_Sdiag, p->d_bsr_val);
     launch_invert_blocks(s, p->S, p->d_bsr_val, p->d_bsr_rowptr, p->d_sta_used, p->d_Minv, p->d_flags);
@@ -1151,6 +1169,8 @@ void ba_destroy(ba_problem *p) {
   if (p->h_cgscal) hipHostFree(p->h_cgscal);
   if (p->ev_blocks) hipEventDestroy(p->ev_blocks);
   if (p->ev_amg) hipEventDestroy(p->ev_amg);
+  if (p->ev_rows) hipEventDestroy(p->ev_rows);
+  if (p->ev_schur) hipEventDestroy(p->ev_schur);
   if (p->stream2) hipStreamDestroy(p->stream2);
   if (p->stream) hipStreamDestroy(p->stream);
   delete p;
