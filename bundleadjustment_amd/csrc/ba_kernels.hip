@@ -945,13 +945,16 @@ k_candidate(CandArgs a) {
       const double d = used ? a.alpha * (-a.y_cam[t] * a.scale_sta[t]) : 0.0;
       const double v = a.eop[t] + d;
       a.eop_c[t] = v;
-      if (used) { step2 += d * d; norm2 += v * v; }
+      // the step as Ceres measures it: x - candidate, not delta  [TrustRegionMinimizer::ParameterToleranceReached]
+      const double m = a.eop[t] - v;
+      if (used) { step2 += m * m; norm2 += v * v; }
     } else {
       const int64_t u = t - n_s;
       const double d = a.alpha * (-a.y_pt[u] * a.scale_pt[u]);
       const double v = a.xyz[u] + d;
       a.xyz_c[u] = v;
-      pstep2 += d * d;
+      const double m = a.xyz[u] - v;
+      pstep2 += m * m;
       pnorm2 += v * v;
     }
   }
@@ -963,7 +966,12 @@ k_candidate(CandArgs a) {
       for (int p = 0; p < BA_NCAMPAR; ++p) {
         if (r.mask & (1u << p)) {
           const double d = a.alpha * (-a.y_cam[n_s + r.off + pos] * r.scale[pos]);
-          if (p < 3) r.iop[p] += d; else { r.ap[p - 3] += d; step2 += d * d; }
+          if (p < 3) r.iop[p] += d;
+          else {
+            r.ap[p - 3] += d;
+            const double m = a.cam[c].ap[p - 3] - r.ap[p - 3];
+            step2 += m * m;
+          }
           ++pos;
         }
       }
