@@ -141,7 +141,15 @@ struct AmgTransfer {  // between a fine level and the next coarser one
 };
 // at most AMG_MAX_LEVELS levels; a level needs AMG_MIN_BLOCKS blocks, one beyond the third AMG_DEEP_BLOCKS
 // (more additive levels than that cost iterations instead of saving them)
-enum { AMG_MAX_LEVELS = 4, AMG_MIN_BLOCKS = 4, AMG_DEEP_BLOCKS = 48 };
+enum { AMG_MAX_LEVELS = 3, AMG_MIN_BLOCKS = 4, AMG_DEEP_BLOCKS = 48 };
+// Weights of the additive combination  z = D0^-1 r + w1 P0 (D1^-1 + w2 P1 D2^-1 P1^T) P0^T r.
+// Any positive weights keep the preconditioner symmetric positive definite; what they change is how much the levels'
+// overlapping corrections overshoot.  Measured on the 10M-observation network (PCG iterations per LM iteration):
+// (1, 1) 195, (0.65, 1) 188, (0.5, 1.5) 185, (0.4, 2) 187, (0.3, 1) 217, (1.7, 1) 220 -- flat around (0.5, 1.5).
+// A fourth level wants a weight near zero (50 000 stations: 234 iterations with it at this weight, 207 at 0.7 of it,
+// 198 at 0.2, 199 without the level and two launches fewer per iteration), hence three levels at most.
+#define AMG_COARSE_WEIGHT 0.5
+#define AMG_DEEP_WEIGHT 1.5
 struct AmgApplyArgs {
   int n_transfers;
   AmgTransfer t[AMG_MAX_LEVELS - 1];
@@ -284,24 +292,25 @@ __device__ __forceinline__ double prolong_row(const AmgTransfer &t, int i, int l
   return s;
 }
 
-// prolongation: yf += P yc ; 8 lanes per fine block row (whole waves stay converged for the shuffles)
+// prolongation: yf += tau P yc ; 8 lanes per fine block row (whole waves stay converged for the shuffles)
 __global__ void __launch_bounds__(256)
-k_amg_prolong(AmgTransfer t, double *__restrict__ yf) {
+k_amg_prolong(AmgTransfer t, double *__restrict__ yf, double tau) {
   const int i = blockIdx.x * 32 + (threadIdx.x >> 3), r = threadIdx.x & 7, lane = threadIdx.x & 63;
   const bool on = i < t.nb;
   const double s = prolong_row(t, on ? i : 0, lane);
-  if (on && r < 6) yf[6 * (int64_t)i + r] += s;
+  if (on && r < 6) yf[6 * (int64_t)i + r] += tau * s;
 }
 
 #define AMG_DEFL_NC 8
 
 // Last kernel of an iteration.  Every workgroup folds the partials of r.z = r.D0^-1 r + sum_l rc_l.y_l
-// in the same order (identical beta everywhere); z = D0^-1 r (already in cg.z) + P0 y1;
+// in the same order (identical beta everywhere), each level's share with its weight (sigma, then sigma tau; np0: where
+// the partials of the first level end); z = D0^-1 r (already in cg.z) + sigma P0 y1;
 // p = z + beta p (mode 1) or p = z (mode 0, start of the solve); 8 lanes per station.
 // Workgroup 0 publishes the scalars for the next iteration in the other parity slot.
 __global__ void __launch_bounds__(256)
 k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restrict__ part, int n_part, int n_part_rz,
-              int parity, int mode, double rtol) {
+              int parity, int mode, double rtol, double sigma, double tau, int np0) {
   __shared__ double lds[4];
   __shared__ double rzn_s;
   __shared__ double Ls[AMG_DEFL_NC * AMG_DEFL_NC], gr4[4][16], zcs[AMG_DEFL_NC], tcs[AMG_DEFL_NC], tot_s;
@@ -327,7 +336,7 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restr
   }
   double s = 0.0;
   for (int k = threadIdx.x; k < n_part_rz; k += blockDim.x) s += cg.part_rz[k];
-  for (int k = threadIdx.x; k < n_part; k += blockDim.x) s += part[k];
+  for (int k = threadIdx.x; k < n_part; k += blockDim.x) s += (k < np0 ? sigma : sigma * tau) * part[k];
   const double tot = block_sum(s, lds);  // has the barriers that publish Ls and gr4
   if (threadIdx.x == 0) tot_s = tot;
   if (defl && threadIdx.x < cg.ncam)  // t_c = r_c - G^T r_s
@@ -352,7 +361,7 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restr
   const bool on = i < cg.S;
   const double corr = has_coarse ? prolong_row(t, on ? i : 0, threadIdx.x & 63) : 0.0;
   if (on && r < 6) {
-    double z = cg.z[6 * (int64_t)i + r] + corr;
+    double z = cg.z[6 * (int64_t)i + r] + sigma * corr;
     if (defl) {
       const double *Gi = cg.G + (6 * (int64_t)i + r) * cg.ncam;
       for (int k = 0; k < cg.ncam; ++k) z -= Gi[k] * zcs[k];
@@ -752,9 +761,12 @@ static void amg_finish_iteration(hipStream_t s, const BsrCgArgs &cg, const Amg *
     off += nb;
   }
   for (int l = aa.n_transfers - 1; l >= 1; --l)
-    hipLaunchKernelGGL(k_amg_prolong, dim3(nblk(aa.t[l].nb, 32)), dim3(256), 0, s, aa.t[l], aa.t[l - 1].y);
+    hipLaunchKernelGGL(k_amg_prolong, dim3(nblk(aa.t[l].nb, 32)), dim3(256), 0, s, aa.t[l], aa.t[l - 1].y,
+                       AMG_DEEP_WEIGHT);
   hipLaunchKernelGGL(k_amg_update2, dim3(nblk(cg.S, 32) > 0 ? nblk(cg.S, 32) : 1), dim3(256), 0, s, cg, aa.t[0],
-                     aa.n_transfers > 0 ? 1 : 0, aa.part, aa.n_part, cg2_blocks_vec(cg.S), parity, mode, rtol);
+                     aa.n_transfers > 0 ? 1 : 0, aa.part, aa.n_part, cg2_blocks_vec(cg.S), parity, mode, rtol,
+                     AMG_COARSE_WEIGHT, AMG_DEEP_WEIGHT,
+                     aa.n_transfers > 0 ? nblk(aa.t[0].nc, 4) : 0);
 }
 
 void launch_amg_cg_init(hipStream_t s, const BsrCgArgs &cg, const Amg *a, double rtol) {
