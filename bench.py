@@ -266,14 +266,17 @@ def main():
                       f"{cg:.0f} PCG iterations per step, scaled linearly in observations to {full.n_obs}; "
                       f"Jacobian pass {obs_s:.3e} obs/s",
             "jacobian_obs_per_s": obs_s, "measured_iter_per_s_on_sample": it_s, "sample_observations": n_cpu}
-        from oracle import py_oracle as po
-        n_cpu, it_s, obs_s, cg = cpu_baseline(args.config, args.cpu_scale * args.scale, args.pcg_rtol, omp=True)
-        out["cpu_baseline_all_cores"] = {
-            "value": it_s * n_cpu / full.n_obs, "unit": "iter/s", "cores": po.omp_threads(), "kind": "port",
-            "sample": f"the same oracle built with OpenMP (loops over observations and points; OMP_NUM_THREADS as set), "
-                      f"same sample of {n_cpu} observations: {it_s:.3f} LM iter/s measured, scaled linearly to {full.n_obs}; "
-                      f"Jacobian pass {obs_s:.3e} obs/s",
-            "jacobian_obs_per_s": obs_s, "measured_iter_per_s_on_sample": it_s, "sample_observations": n_cpu}
+        try:  # a second, reported-only baseline: its absence must not cost the benchmark line
+            from oracle import py_oracle as po
+            n_cpu, it_s, obs_s, cg = cpu_baseline(args.config, args.cpu_scale * args.scale, args.pcg_rtol, omp=True)
+            out["cpu_baseline_all_cores"] = {
+                "value": it_s * n_cpu / full.n_obs, "unit": "iter/s", "cores": po.omp_threads(), "kind": "port",
+                "sample": f"the same oracle built with OpenMP (loops over observations and points; OMP_NUM_THREADS as set), "
+                          f"same sample of {n_cpu} observations: {it_s:.3f} LM iter/s measured, scaled linearly to {full.n_obs}; "
+                          f"Jacobian pass {obs_s:.3e} obs/s",
+                "jacobian_obs_per_s": obs_s, "measured_iter_per_s_on_sample": it_s, "sample_observations": n_cpu}
+        except (RuntimeError, OSError) as e:
+            out["cpu_baseline_all_cores"] = {"value": None, "error": str(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     P.close()
