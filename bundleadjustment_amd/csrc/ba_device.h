@@ -21,7 +21,7 @@
 #define BA_OBS_STRIDE 8
 #define BA_STA_STRIDE 24
 #define BA_REC_STRIDE 16
-#define BA_Y_STRIDE 24  // 6 rows x (3 + 1 pad) doubles = 192 B = three 64-B sectors
+#define BA_Y_STRIDE 18  // 6 rows x 3 doubles = 144 B, no padding: a record starts on a 16-byte boundary, its second half 8 bytes past one
 #define BA_NCAMPAR 19
 #define BA_NCAMPAR_BROWN 10  // xp yp c a1 a2 k1 k2 k3 p1 p2: the camera columns when no empirical term is in use
 #define BA_APSCALE 1000.0  // src/main.cpp:55

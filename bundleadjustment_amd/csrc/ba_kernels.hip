@@ -306,19 +306,18 @@ k_obs_rows(LinArgs a) {
       tile_store<3>(buf, mo, a.Mo + 3 * e0, lane, nvalid);
     }
     if (a.Y) {
-      // G = Jp L (2x3);  Y[r][m] = Js0[r] G0[m] + Js1[r] G1[m], rows padded to 4 doubles
+      // G = Jp L (2x3);  Y[r][m] = Js0[r] G0[m] + Js1[r] G1[m], row-major 6 x 3
       const double l00 = el[3], l10 = el[4], l20 = el[5], l11 = el[6], l21 = el[7], l22 = el[8];
       const double g00 = p0 * l00 + p1 * l10 + p2 * l20, g01 = p1 * l11 + p2 * l21, g02 = p2 * l22;
       const double g10 = p3 * l00 + p4 * l10 + p5 * l20, g11 = p4 * l11 + p5 * l21, g12 = p5 * l22;
-      double y[24];
+      double y[BA_Y_STRIDE];
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
-        y[4 * r] = Js[r] * g00 + Js[6 + r] * g10;
-        y[4 * r + 1] = Js[r] * g01 + Js[6 + r] * g11;
-        y[4 * r + 2] = Js[r] * g02 + Js[6 + r] * g12;
-        y[4 * r + 3] = 0.0;
+        y[3 * r] = Js[r] * g00 + Js[6 + r] * g10;
+        y[3 * r + 1] = Js[r] * g01 + Js[6 + r] * g11;
+        y[3 * r + 2] = Js[r] * g02 + Js[6 + r] * g12;
       }
-      tile_store<24>(buf, y, a.Y + (int64_t)BA_Y_STRIDE * e0, lane, nvalid);
+      tile_store<BA_Y_STRIDE>(buf, y, a.Y + (int64_t)BA_Y_STRIDE * e0, lane, nvalid);
     }
     if (CAM1) {
       {

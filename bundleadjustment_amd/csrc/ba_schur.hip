@@ -23,6 +23,21 @@ namespace ba {
 // One wave per upper-triangular block u (lo <= hi).  Four lanes share one observation pair (each
 // owns a 3x3 quadrant of Y_a Y_b^T), so sixteen pairs are in flight per wave and their row gathers
 // overlap; the sixteen partial blocks are folded with wave shuffles in a fixed order.
+// Rows 3h .. 3h+2 of one 6 x 3 record (18 doubles, 16-byte aligned): nine doubles that start on a 16-byte boundary
+// (h = 0) or 8 bytes past one (h = 1); either way four 16-byte loads and one 8-byte load
+__device__ __forceinline__ void load_half(const double *__restrict__ rec, int h, double (&v)[3][3]) {
+  const double *p = rec + 9 * h;
+  const double2 *p2 = reinterpret_cast<const double2 *>(p + h);
+  const double2 d0 = p2[0], d1 = p2[1], d2 = p2[2], d3 = p2[3];
+  const double s = p[h ? 0 : 8];
+  const double f[9] = {h ? s : d0.x, h ? d0.x : d0.y, h ? d0.y : d1.x, h ? d1.x : d1.y, h ? d1.y : d2.x,
+                       h ? d2.x : d2.y, h ? d2.y : d3.x, h ? d3.x : d3.y, h ? d3.y : s};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) v[i][j] = f[3 * i + j];
+}
+
 __global__ void __launch_bounds__(256)
 k_schur_blocks(int nu, const int *__restrict__ cstart, const int2 *__restrict__ dst, const int2 *__restrict__ pairs,
                const double *__restrict__ Y, double *__restrict__ val) {
@@ -38,15 +53,9 @@ k_schur_blocks(int nu, const int *__restrict__ cstart, const int2 *__restrict__ 
     for (int j = 0; j < 3; ++j) acc[i][j] = 0.0;
   for (int q = q0 + g; q < q1; q += 16) {
     const int2 pr = pairs[q];
-    const double2 *ya = reinterpret_cast<const double2 *>(Y + (int64_t)BA_Y_STRIDE * pr.x + 12 * qa);
-    const double2 *yb = reinterpret_cast<const double2 *>(Y + (int64_t)BA_Y_STRIDE * pr.y + 12 * qb);
     double av[3][3], bv[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const double2 a0 = ya[2 * i], a1 = ya[2 * i + 1], b0 = yb[2 * i], b1 = yb[2 * i + 1];
-      av[i][0] = a0.x; av[i][1] = a0.y; av[i][2] = a1.x;
-      bv[i][0] = b0.x; bv[i][1] = b0.y; bv[i][2] = b1.x;
-    }
+    load_half(Y + (int64_t)BA_Y_STRIDE * pr.x, qa, av);
+    load_half(Y + (int64_t)BA_Y_STRIDE * pr.y, qb, bv);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
