@@ -38,7 +38,7 @@ def measured_traffic(kernel, config, scale, world):
 
 
 def kernel_bytes(which, n_obs, n_pts, n_sta, n_blocks=0, n_pairs=0, ncam=0):
-    """Algorithmic bytes one launch must move (per-unit figures x units; written out in DESIGN.md).
+    """Algorithmic bytes one launch must move (per-unit figures x units).
     0 linearize      : per observation 56 (record) + 48 (station) + 24 (point) + 16 (residual) + 144 (coupling block W),
                        per point 72 (V, g), per station 216 (U, g).  It runs as two kernels (7 per point, 8 per
                        observation) that are also listed on their own; the record is read by both, which the
