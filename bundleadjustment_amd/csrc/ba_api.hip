@@ -64,6 +64,19 @@ enum Scal {
 
 }  // namespace
 
+namespace ba {
+// the same for the other translation units of the library
+int fail_msg(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+}  // namespace ba
+
 struct ba_problem {
   int N = 0, S = 0, P = 0, C = 0;
   int ncam = 0, ncmax = 0, nr = 0, n_chunks = 0;

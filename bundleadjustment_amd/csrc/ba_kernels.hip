@@ -36,7 +36,7 @@ __global__ void k_station_prep(int S, const double *__restrict__ eop, const doub
   o[9] = e[3]; o[10] = e[4]; o[11] = e[5];
   o[12] = sk; o[13] = ck;
 #pragma unroll
-  for (int k = 0; k < 6; ++k) o[14 + k] = scale_sta[6 * (int64_t)i + k];
+  for (int k = 0; k < 6; ++k) o[14 + k] = scale_sta ? scale_sta[6 * (int64_t)i + k] : 1.0;  // null: unscaled columns
   o[20] = __hiloint2double(0, sta_cam[i]);
   o[21] = o[22] = o[23] = 0.0;
 }

@@ -21,7 +21,8 @@ KERNEL_LINEARIZE, KERNEL_POINT_APPLY, KERNEL_STATION_GATHER, KERNEL_COST = 0, 1,
 EXPORTS = ("ba_default_options", "ba_create", "ba_destroy", "ba_set_parameters", "ba_get_parameters", "ba_set_corrections", "ba_covariance_cameras",
            "ba_set_iop_bounds", "ba_line_search_contract",
            "ba_solve_resident", "ba_solve", "ba_evaluate", "ba_covariance", "ba_sparsity", "ba_residual_jacobian", "ba_time_kernel",
-           "ba_set_allreduce", "ba_copy_to_host", "ba_copy_to_device", "ba_rccl_unique_id", "ba_use_rccl", "ba_last_error")
+           "ba_set_allreduce", "ba_copy_to_host", "ba_copy_to_device", "ba_rccl_unique_id", "ba_use_rccl", "ba_evaluate_noalloc",
+           "ba_last_error")
 
 
 def lib_path():
@@ -67,6 +68,7 @@ def lib():
         L.ba_copy_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.ba_rccl_unique_id.argtypes = [C.c_void_p]
         L.ba_use_rccl.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.ba_evaluate_noalloc.argtypes = [C.POINTER(BaDims), C.POINTER(BaInputs)] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 3
         _lib = L
     return _lib
 
@@ -233,6 +235,12 @@ class Problem:
     def use_rccl(self, n_ranks, rank, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, 128)
         _check(lib().ba_use_rccl(self._h, n_ranks, rank, buf))
+
+
+def evaluate_noalloc(dims, inputs, eop, xyz, iop, ap, apply_loss, cost, residuals=None, stream=None):
+    """ba_evaluate_noalloc: every pointer (those inside `inputs` too) is a device address, given as an int; cost [2] and
+    residuals are device outputs.  Queues kernels on `stream` (a hipStream_t as int, None = default) and returns."""
+    _check(lib().ba_evaluate_noalloc(C.byref(dims), C.byref(inputs), eop, xyz, iop, ap, int(bool(apply_loss)), cost, residuals, stream))
 
 
 def rccl_unique_id() -> bytes:

@@ -331,6 +331,27 @@ int ba_copy_to_device(double *device_dst, const void *host_src, int64_t count, v
 int ba_rccl_unique_id(void *unique_id_128);
 int ba_use_rccl(ba_problem *p, int32_t n_ranks, int32_t rank, const void *unique_id_128);
 
+/*
+ * ba_evaluate for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  No counterpart in the reference (its problem.Evaluate, src/main.cpp:4853, allocates freely).
+ * Same cost and residual vector as ba_evaluate, from arrays that are ALL in device memory: the arrays of *in
+ * (ap_free_mask / iop_free_mask are not read), the parameters eop [6*n_sta], xyz [3*n_pts], iop [3*n_cam],
+ * ap [16*n_cam], and the outputs cost [2] (cost[0] = the cost, cost[1] = number of rows skipped because an index or a
+ * sigma was out of range: ba_create would have refused such a problem) and residuals [2*n_obs + 3*n_pts + 3*n_cam]
+ * (may be NULL) in file order.  The kernels are queued on hip_stream (a hipStream_t, NULL = the default stream);
+ * the call does not synchronise, copies nothing to the host and calls no hipMalloc / hipFree or any other allocating
+ * routine.  Its work memory (station records, camera records, per-workgroup partial sums) is one fixed array in the
+ * library's device image, about 12.6 MB per GPU, held until the process ends: at most BA_NOALLOC_MAX_STATIONS
+ * stations and BA_NOALLOC_MAX_CAMERAS cameras (BA_ERR_UNSUPPORTED beyond; points and observations are not limited).
+ * All calls on one GPU share that array: calls on one stream are ordered and safe, calls that overlap in time on one
+ * GPU (two streams, two host threads) race.
+ */
+#define BA_NOALLOC_MAX_STATIONS 65536
+#define BA_NOALLOC_MAX_CAMERAS 64
+int ba_evaluate_noalloc(const ba_dims *dims, const ba_inputs *in, const double *eop, const double *xyz,
+                        const double *iop, const double *ap, int apply_loss, double *cost, double *residuals,
+                        void *hip_stream);
+
 const char *ba_last_error(void);
 
 #ifdef __cplusplus
