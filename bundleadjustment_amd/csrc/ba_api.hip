@@ -636,6 +636,19 @@ int camera_rows(ba_problem *p, int voff, double *out_cam) {
 
 int build_reduced(ba_problem *p, bool explicit_blocks);
 
+// max over the ranks of a few host values through the device-side reduction callback (the scalar block is free between
+// read_scal and the next phase)
+int host_max_over_ranks(ba_problem *p, std::vector<double> &v) {
+  if (!p->ar || v.empty()) return 0;
+  if (v.size() > 8) return fail(BA_ERR_INVALID, "host_max_over_ranks: vector too long");
+  double *buf = p->d_scal + SC_COUNT - 8;
+  HIP_OK(hipMemcpyAsync(buf, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  BA_TRY(p->allreduce(buf, (int64_t)v.size(), 1));
+  HIP_OK(hipMemcpyAsync(v.data(), buf, v.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIP_OK(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
 // Residuals, Jacobians, point elimination, station blocks, gradient, reduced right-hand side.
 // Leaves cost in h_scal[SC_COST] (+ SC_FIXED) and the max-norm of the gradient in h_scal[SC_GMAX].
 int linearize(ba_problem *p, const LmState &st) {
@@ -718,6 +731,13 @@ int linearize(ba_problem *p, const LmState &st) {
   p->h_scal[SC_GMAX] = std::max(p->h_scal[SC_GMAX], std::max(p->h_scal[SC_GMAX_P], p->h_scal[SC_GMAX_SC]));
   unsigned flags[4];
   HIP_OK(hipMemcpy(flags, p->d_flags, sizeof flags, hipMemcpyDeviceToHost));
+  if (p->ar) {
+    // a point block that is not positive definite shows on the rank that owns the point only: every rank must take
+    // the same branch below, or the others wait in the next collective for ever
+    std::vector<double> f(1, (double)flags[0]);
+    BA_TRY(host_max_over_ranks(p, f));
+    if (f[0] != 0.0 && !flags[0]) flags[0] = 1u;
+  }
   if (flags[0]) {
     HIP_OK(hipMemset(p->d_flags, 0, sizeof flags));
     return fail(BA_ERR_NUMERIC, "%s block is not positive definite", (flags[0] & 1) ? "a point" : "a station");
@@ -1354,7 +1374,10 @@ int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary,
   if (linear_solver == BA_SOLVER_AUTO) linear_solver = p->nr <= BA_AUTO_DENSE_ORDER ? BA_SOLVER_DENSE_SCHUR : BA_SOLVER_PCG_SCHUR;
   if (linear_solver != BA_SOLVER_DENSE_SCHUR && linear_solver != BA_SOLVER_PCG_SCHUR && linear_solver != BA_SOLVER_PCG_IMPLICIT)
     return fail(BA_ERR_UNSUPPORTED, "linear_solver %d", opt->linear_solver);
-  const bool use_explicit = p->explicit_ok && linear_solver != BA_SOLVER_PCG_IMPLICIT;
+  // The kernels of the explicit block-sparse PCG hold the camera columns in LDS arrays of fixed size: a network with
+  // more free camera parameters than they take (many cameras) runs the same PCG on the matrix-free operator instead.
+  const bool pcg_too_wide = linear_solver == BA_SOLVER_PCG_SCHUR && p->ncam > cg2_max_cam();
+  const bool use_explicit = p->explicit_ok && linear_solver != BA_SOLVER_PCG_IMPLICIT && !pcg_too_wide;
   if (!(opt->initial_trust_region_radius > 0.0)) return fail(BA_ERR_INVALID, "initial_trust_region_radius must be positive");
   const double t_begin = now_s();
   ba_summary sm;
@@ -1385,6 +1408,14 @@ int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary,
         for (int k = 0; k < 3; ++k) r.iop[k] = std::min(std::max(r.iop[k], r.lo[k]), r.hi[k]);
   }
   bool rows_hold_x = true;  // the per-observation rows and the gradient on the device belong to x (not to a trial point)
+  // Whatever way the solve ends, the host copy of the camera records follows the device: the next call uploads it
+  // (init_scaling), and a stale copy would put the cameras back while stations and points stay where they are.
+  struct CamSync {
+    ba_problem *p;
+    ~CamSync() {
+      if (p->C) (void)hipMemcpy(p->cam_h.data(), p->d_cam, p->cam_h.size() * sizeof(CamRec), hipMemcpyDeviceToHost);
+    }
+  } cam_sync{p};
 
   // ---- IterationZero ----
   double t0 = now_s();
@@ -1539,9 +1570,6 @@ int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary,
   sm.final_cost = min_iter_cost;
   sm.num_iterations = n_rows;
   sm.t_total_s = now_s() - t_begin;
-  if (p->C) {
-    HIP_OK(hipMemcpy(p->cam_h.data(), p->d_cam, p->cam_h.size() * sizeof(CamRec), hipMemcpyDeviceToHost));
-  }
   if (summary) *summary = sm;
   return 0;
 }
@@ -1627,6 +1655,9 @@ int ba_covariance_cameras(ba_problem *p, double *var_iop, double *var_ap) {
   if (!p->have_params) return fail(BA_ERR_INVALID, "ba_covariance_cameras: no parameters set");
   if (p->ncam > 0 && !p->explicit_ok)
     return fail(BA_ERR_UNSUPPORTED, "ba_covariance_cameras: needs the explicit block-sparse reduced system (pattern too dense for it)");
+  if (p->ncam > cg2_max_cam())
+    return fail(BA_ERR_UNSUPPORTED, "ba_covariance_cameras: %d free camera parameters, the block-sparse PCG takes at most %d (use ba_covariance)",
+                p->ncam, cg2_max_cam());
   hipStream_t s = p->stream;
   ba_options opt;
   ba_default_options(&opt);
@@ -1740,6 +1771,7 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
   ba.q = p->d_q; ba.scal = p->d_cg2scal; ba.part_pq = p->d_part_pq; ba.part_qc = p->d_part_qc; ba.part_rz = p->d_part_rz;
   ba.r2 = p->d_r2;
   if ((which == 4 || which == 5 || which == 6) && !p->explicit_ok) return fail(BA_ERR_INVALID, "ba_time_kernel: the block-sparse system was not built for this network");
+  if ((which == 5 || which == 6) && p->ncam > cg2_max_cam()) return fail(BA_ERR_UNSUPPORTED, "ba_time_kernel: too many free camera parameters for the block-sparse PCG");
   // the PCG iteration is timed with the preconditioner the last solve used (multilevel once it has been built)
   const bool with_amg = p->amg && amg_levels(p->amg) >= 2;
   if (which == 5 || which == 6) {

@@ -23,6 +23,9 @@ __device__ __forceinline__ double station_precond(const double *__restrict__ Min
 
 // per-workgroup partials of G^T r_s (thread i holds station i; 256 threads)
 #define DEFL_NC 8
+// Most free camera parameters (summed over the cameras) the kernels of the explicit block-sparse PCG hold in LDS;
+// networks with more take the matrix-free PCG (ba_solve_resident) or the dense solver.
+#define CG2_MAX_CAM 79
 __device__ __forceinline__ void defl_partials(const BsrCgArgs &a, const double *__restrict__ r, int i, int vblock) {
   __shared__ double lds_gr[4][DEFL_NC];
   double gr[DEFL_NC];
@@ -58,14 +61,14 @@ __device__ __forceinline__ void defl_partials(const BsrCgArgs &a, const double *
 // Workgroups with vblock >= 0 (n_vblocks of them, 256 threads, one thread per station) then do
 // x += alpha p, r_out = r_in - alpha q, z = D^-1 r_out and leave partials of r.z; the others return
 // with alpha only.  r_in == r_out updates the residual in place.
-__device__ __forceinline__ double cg2_update1_body(const BsrCgArgs &a, int parity, int nblk_spmv, const double *__restrict__ rin,
-                                                   double *__restrict__ rout, int vblock, int n_vblocks) {
+__device__ __forceinline__ double cg2_update1_body(const BsrCgArgs &a, int parity, int nblk_spmv, const double *rin,
+                                                   double *rout, int vblock, int n_vblocks) {
   __shared__ double lds[8];
-  __shared__ double red[80];   // [0] p.q over the station rows, [1 + k] camera row k of S p
-  __shared__ double pcs[80];   // camera part of p
+  __shared__ double red[CG2_MAX_CAM + 1];   // [0] p.q over the station rows, [1 + k] camera row k of S p
+  __shared__ double pcs[CG2_MAX_CAM + 1];   // camera part of p
   __shared__ double pq_s;
   __shared__ double fold4[4][8];
-  __shared__ double rcs[80];
+  __shared__ double rcs[CG2_MAX_CAM + 1];
   // Every workgroup folds the SpMV partials in the same order -> identical alpha everywhere.
   // Eight sums at a time: thread t takes sum (t & 7) and every 32nd partial from (t >> 3) on, so all
   // its loads are independent; then the 8 threads-classes are reduced across the wave and the waves.

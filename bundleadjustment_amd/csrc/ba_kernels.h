@@ -179,6 +179,7 @@ void launch_cg2_init(hipStream_t s, const BsrCgArgs &a, double rtol);
 void launch_cg2_iteration(hipStream_t s, const BsrCgArgs &a, int parity);
 void launch_bsr_spmv(hipStream_t s, const BsrCgArgs &a, int parity);
 int defl_max_cam();  // largest camera block the coarse space handles
+int cg2_max_cam();   // most free camera parameters the explicit block-sparse PCG handles
 void launch_defl_get_column(hipStream_t s, int S, int ncam, int k, const double *M, double *v);
 void launch_defl_set_column(hipStream_t s, int S, int ncam, int k, const double *v, double *M, double *MT);
 // E = (Scc - Ssc^T G - G^T Ssc + G^T S_ss G)^-1, Lcc its Cholesky factor before inversion; SG and part are work

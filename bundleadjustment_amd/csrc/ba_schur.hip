@@ -338,7 +338,7 @@ __global__ void k_border_general_corner(int ncam, const double *__restrict__ cor
 __global__ void __launch_bounds__(64 * SPMV_WAVES)
 k_bsr_spmv(BsrCgArgs a, int parity) {
   __shared__ double lds_pq[SPMV_WAVES];
-  __shared__ double lds_qc[SPMV_WAVES][80];
+  __shared__ double lds_qc[SPMV_WAVES][CG2_MAX_CAM + 1];
   if (a.scal[8 + parity] != 0.0) return;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double pq = 0.0;
@@ -691,6 +691,7 @@ k_defl_invert(int n, const double *__restrict__ L, double *__restrict__ Einv) {
 }
 
 int defl_max_cam() { return DEFL_NC; }
+int cg2_max_cam() { return CG2_MAX_CAM; }
 void launch_defl_get_column(hipStream_t s, int S, int ncam, int k, const double *M, double *v) {
   const int64_t n = 6 * (int64_t)S;
   if (n > 0) hipLaunchKernelGGL(k_defl_get_column, dim3(nblk(n, 256)), dim3(256), 0, s, n, ncam, k, M, v);

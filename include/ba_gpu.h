@@ -57,7 +57,8 @@ enum ba_stop_reason {
 enum ba_linear_solver {
   BA_SOLVER_DENSE_SCHUR = 0, /* point elimination + dense fp64 Cholesky of the reduced system */
   BA_SOLVER_PCG_SCHUR = 1,   /* point elimination + block-Jacobi PCG on the reduced system, held as 6x6
-                                blocks in block-sparse form (matrix-free when it is too dense for that) */
+                                blocks in block-sparse form (matrix-free when it is too dense for that, or when
+                                the cameras have more than 79 free parameters between them) */
   BA_SOLVER_PCG_IMPLICIT = 2, /* same PCG, always matrix-free: S p = Jc^T (I - Jp V^-1 Jp^T) Jc p */
   BA_SOLVER_AUTO = 3          /* the default: DENSE_SCHUR while the reduced system has at most
                                  BA_AUTO_DENSE_ORDER unknowns (6 per station + the free camera
@@ -134,7 +135,8 @@ typedef struct {
   int32_t iteration;
   int32_t step_is_successful;
   int32_t step_is_valid;
-  int32_t linear_iterations; /* PCG iterations (0 for the dense solver) */
+  int32_t linear_iterations; /* PCG iterations (0 for the dense solver); equal to ba_options.pcg_max_iters when the
+                                PCG stopped there without reaching pcg_rtol (the step is then used as it is) */
   double cost;
   double cost_change;
   double gradient_max_norm;

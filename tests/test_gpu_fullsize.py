@@ -52,3 +52,63 @@ def test_sparsity_counts_full_size(big):
     # checksum of checksums: every image row references its own station and point columns
     first = cols[rows[:2 * N:2]]
     assert np.array_equal(first, 6 * net.obs_sta)
+
+
+# ------------------------------------------------------------------------------------------------
+# the other networks of the benchmark definition at their full size
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.timeout(600)
+def test_cfg2_full_size_solve_parity():
+    # 4 cameras, 200 stations, 20 000 points, 1 000 000 observations, dense Cholesky of order 1248: every iteration's
+    # cost and the final parameters against the oracle (about half a minute of one CPU core)
+    from oracle import py_oracle as po
+    from util import assert_solve_parity
+    net = host.synth_config("cfg2").net
+    assert net.n_obs == 1000000 and net.n_sta == 200 and net.n_cam == 4
+    opt = solver.default_options()
+    with solver.Problem(net) as P:
+        g = P.solve(opt)
+    assert g[4]["linear_solver_used"] == capi.SOLVER_DENSE_SCHUR
+    o = po.solve(net, opt, po.SCHUR_DENSE)
+    assert o[4]["termination"] == capi.CONVERGENCE
+    assert_solve_parity(g, o)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name", ["cfg3", "cfg5"])
+def test_full_size_properties(name):
+    # cfg3: 1800 stations, 1M points, 5M observations, camera held constant.  cfg5: 50 000 stations, 10M points, 50M
+    # observations (about 35 GB on the device).  The oracle is too slow here: size-independent properties instead.
+    hn = host.synth_config(name, outlier_fraction=0.0)
+    net, t = hn.net, hn.net.truth
+    N, S, Pn = net.n_obs, net.n_sta, net.n_pts
+    assert (N, S, Pn) == {"cfg3": (5000000, 1800, 1000000), "cfg5": (50000000, 50000, 10000000)}[name]
+    with solver.Problem(net) as P:
+        c_start, _ = P.evaluate(residuals=False)
+        c_truth, res = P.evaluate(t["eop"], t["xyz"], t["iop"], t["ap"], apply_loss=False)
+        img = res[:2 * N]
+        assert abs(np.mean(img)) < 5e-3 and abs(np.std(img) - 1.0) < 5e-3   # the injected noise, in units of sigma
+        assert res.size == 2 * N + 3 * Pn + 3
+        del res, img
+        c2, _ = P.evaluate(t["eop"], t["xyz"], t["iop"], t["ap"], apply_loss=False, residuals=False)
+        assert c2 == c_truth                                                 # same bits twice
+        opt = solver.default_options()                                      # picks the PCG at these sizes
+        opt.max_num_iterations = 2
+        opt.pcg_rtol = 1e-10
+        P.set_parameters()
+        sm, rows = P.solve_resident(opt)
+        assert sm["linear_solver_used"] == capi.SOLVER_PCG_SCHUR
+        assert rows[0]["cost"] == pytest.approx(c_start, rel=1e-12)
+        assert all(r["step_is_successful"] for r in rows)
+        assert rows[-1]["cost"] < 0.12 * rows[0]["cost"] and rows[-1]["cost"] < 1.2 * c_truth
+        # the multilevel preconditioner keeps the iteration count flat in the network size
+        assert all(0 < r["linear_iterations"] < 400 for r in rows[1:]), [r["linear_iterations"] for r in rows]
+        free = 0 if name == "cfg3" else 7
+        assert sm["num_effective_parameters_reduced"] == 6 * S + 3 * Pn + free
+        eop, xyz, iop, ap = P.get_parameters()
+        assert np.sqrt(np.mean((xyz - t["xyz"]) ** 2)) < np.sqrt(np.mean((net.xyz - t["xyz"]) ** 2))
+        if name == "cfg3":
+            assert np.array_equal(iop, net.iop) and np.array_equal(ap, net.ap)  # constant blocks stay
+            nr, nc, rws, cols = P.sparsity()
+            assert nr == 2 * N + 3 * Pn + 3 and nc == 6 * S + 3 * Pn + 3 + 16
+            assert rws[-1] == 2 * N * (6 + 3) + 9 * Pn

@@ -393,3 +393,20 @@ def test_resident_solve_equals_in_place_solve():
         sm2, rows2 = P.solve_resident(opt)
         assert sm2["num_iterations"] <= 2
         assert rel(P.get_parameters()[1], b[1]) < 1e-12
+
+
+def test_many_camera_columns_through_the_pcg_solvers():
+    # 9 cameras x (xp yp c + a1 a2 k1 k2 k3 p1 p2) = 90 free camera columns: more than the block-sparse PCG kernels
+    # hold in shared memory, so PCG_SCHUR must take the matrix-free operator (and give the same answer)
+    net = host.synth(n_cam=9, n_sta=45, n_pts=1500, rays_per_point=8, ap_free_mask=host.AP_BROWN7, seed=21).net
+    assert sum(bin(int(m)).count("1") for m in net.ap_free_mask) + 3 * net.n_cam == 90
+    with solver.Problem(net) as P:
+        g = P.solve(options(capi.SOLVER_PCG_SCHUR, pcg_max_iters=6000))
+        with pytest.raises(solver.BaError) as e:
+            P.covariance_cameras()
+        assert e.value.code == capi.ERR_UNSUPPORTED
+    o = po.solve(net, options(capi.SOLVER_PCG_SCHUR, pcg_max_iters=6000), po.SCHUR_DENSE)
+    assert o[4]["termination"] == capi.CONVERGENCE
+    assert_solve_parity(g, o, par_rtol=1e-8)
+    d = gpu_solve(net, options(capi.SOLVER_DENSE_SCHUR))
+    assert_solve_parity(d, o, par_rtol=1e-8)

@@ -164,3 +164,23 @@ def test_openmp_build_of_the_oracle_agrees_with_the_checker():
     for x, y in zip(a[:4], b[:4]):
         assert np.max(np.abs(x - y)) <= 1e-9 * max(1.0, np.max(np.abs(x)))
     assert abs(po.linearize_once(net) - po.linearize_once(net, omp=True)) <= 1e-11 * abs(po.linearize_once(net))
+
+
+def test_all_sixteen_additional_parameters_are_not_solvable_with_the_reference_options():
+    # The 1M-observation benchmark network is defined with all 16 AP free.  With the reference's options (LM diagonal
+    # clamped to 1e-150, src/main.cpp:4712-4713: Gauss-Newton) the thirteen radial monomials rr .. rr^13 of
+    # src/main.cpp:1371-1376 are numerically collinear: the Cholesky factorisation of the normal matrix breaks down,
+    # every step is invalid and the solve ends as a FAILURE after max_num_consecutive_invalid_steps.  That is why the
+    # network frees Brown 7 + ep1 + ep4 instead (host.CONFIGS["cfg2"]).  Shown on a 2.5 % copy of the network (the
+    # camera columns are the same at any size) in the Schur mode; the literal full normal equations give up one step earlier.
+    all16 = host.synth_config("cfg2", scale=0.025, ap_free_mask=host.AP_ALL16).net
+    opt = capi.default_options(capi.SOLVER_DENSE_SCHUR)
+    o = po.solve(all16, opt, po.SCHUR_DENSE)
+    assert o[4]["termination"] == capi.FAILURE and o[4]["stop_reason_name"] == "invalid_steps"
+    n_bad = opt.max_num_consecutive_invalid_steps - 1  # the last invalid step ends the solve before it is logged
+    assert o[4]["num_unsuccessful_steps"] == n_bad
+    assert all(r["step_is_valid"] == 0 for r in o[5][-n_bad:])
+    chosen = host.synth_config("cfg2", scale=0.025).net
+    assert int(chosen.ap_free_mask[0]) == host.AP_BROWN7_EP14
+    o = po.solve(chosen, opt, po.SCHUR_DENSE)
+    assert o[4]["termination"] == capi.CONVERGENCE and o[4]["num_unsuccessful_steps"] == 0
