@@ -214,8 +214,9 @@ __device__ __forceinline__ double restrict_column(const AmgTransfer &t, int c, c
 
 // restriction: rc = P^T v, y = Dc^-1 rc ; one wave per coarse block; per-workgroup partials of rc . y
 __global__ void __launch_bounds__(256)
-k_amg_restrict(AmgTransfer t, const double *__restrict__ v, double *__restrict__ part) {
+k_amg_restrict(AmgTransfer t, const double *__restrict__ v, double *__restrict__ part, unsigned long long *trace) {
   __shared__ double lds[4];
+  pcg_mark(trace, 2, 0, blockIdx.x);
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int r = lane & 7;
   double dot = 0.0;
@@ -229,8 +230,10 @@ k_amg_restrict(AmgTransfer t, const double *__restrict__ v, double *__restrict__
       dot = d;
     }
   }
+  pcg_mark(trace, 2, 1, blockIdx.x);
   const double tot = block_sum(dot, lds);
   if (threadIdx.x == 0) part[blockIdx.x] = tot;
+  pcg_mark(trace, 2, 2, blockIdx.x);
 }
 
 // Second kernel of a multilevel PCG iteration: the vector update and the first restriction in one
@@ -240,6 +243,7 @@ k_amg_restrict(AmgTransfer t, const double *__restrict__ v, double *__restrict__
 __global__ void __launch_bounds__(256)
 k_amg_update1_restrict(BsrCgArgs a, AmgTransfer t, int parity, int nblk_spmv, int nbv, double *__restrict__ part) {
   __shared__ double lds[4];
+  pcg_mark(a.trace, 1, 0, blockIdx.x);
   if (a.scal[8 + parity] != 0.0) return;
   const double *rin = parity ? a.r2 : a.r;
   double *rout = parity ? a.r : a.r2;
@@ -259,8 +263,10 @@ k_amg_update1_restrict(BsrCgArgs a, AmgTransfer t, int parity, int nblk_spmv, in
       dot = d;
     }
   }
+  pcg_mark(a.trace, 1, 3, blockIdx.x);
   const double tot = block_sum(dot, lds);
   if (threadIdx.x == 0) part[cb] = tot;
+  pcg_mark(a.trace, 1, 4, blockIdx.x);
 }
 
 // (P yc)[i][r] for the 8 lanes of a group (r = lane & 7 < 6): column indices of up to 8 blocks come
@@ -294,11 +300,14 @@ __device__ __forceinline__ double prolong_row(const AmgTransfer &t, int i, int l
 
 // prolongation: yf += tau P yc ; 8 lanes per fine block row (whole waves stay converged for the shuffles)
 __global__ void __launch_bounds__(256)
-k_amg_prolong(AmgTransfer t, double *__restrict__ yf, double tau) {
+k_amg_prolong(AmgTransfer t, double *__restrict__ yf, double tau, unsigned long long *trace) {
+  pcg_mark(trace, 3, 0, blockIdx.x);
   const int i = blockIdx.x * 32 + (threadIdx.x >> 3), r = threadIdx.x & 7, lane = threadIdx.x & 63;
   const bool on = i < t.nb;
   const double s = prolong_row(t, on ? i : 0, lane);
+  pcg_mark(trace, 3, 1, blockIdx.x);
   if (on && r < 6) yf[6 * (int64_t)i + r] += tau * s;
+  pcg_mark(trace, 3, 2, blockIdx.x);
 }
 
 #define AMG_DEFL_NC 8
@@ -314,6 +323,7 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restr
   __shared__ double lds[4];
   __shared__ double rzn_s;
   __shared__ double Ls[AMG_DEFL_NC * AMG_DEFL_NC], gr4[4][16], zcs[AMG_DEFL_NC], tcs[AMG_DEFL_NC], tot_s;
+  pcg_mark(cg.trace, 4, 0, blockIdx.x);
   if (mode == 1) {
     const double done = cg.scal[8 + parity];
     if (done != 0.0) {
@@ -321,6 +331,7 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restr
       return;
     }
   }
+  pcg_mark(cg.trace, 4, 1, blockIdx.x);
   const int64_t o = 6 * (int64_t)cg.S;
   const bool defl = cg.G != nullptr;  // then ncam <= AMG_DEFL_NC
   if (defl) {
@@ -357,9 +368,11 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restr
   __syncthreads();
   const double rzn = rzn_s;
   const double beta = (mode == 1) ? rzn / cg.scal[parity] : 0.0;
+  pcg_mark(cg.trace, 4, 2, blockIdx.x);
   const int i = blockIdx.x * 32 + (threadIdx.x >> 3), r = threadIdx.x & 7;
   const bool on = i < cg.S;
   const double corr = has_coarse ? prolong_row(t, on ? i : 0, threadIdx.x & 63) : 0.0;
+  pcg_mark(cg.trace, 4, 3, blockIdx.x);
   if (on && r < 6) {
     double z = cg.z[6 * (int64_t)i + r] + sigma * corr;
     if (defl) {
@@ -390,6 +403,7 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restr
       cg.scal[8 + (parity ^ 1)] = nd;
     }
   }
+  pcg_mark(cg.trace, 4, 4, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -757,12 +771,12 @@ static void amg_finish_iteration(hipStream_t s, const BsrCgArgs &cg, const Amg *
       off += nb;
       continue;
     }
-    hipLaunchKernelGGL(k_amg_restrict, dim3(nb), dim3(256), 0, s, aa.t[l], l == 0 ? cg.r : aa.t[l - 1].rc, aa.part + off);
+    hipLaunchKernelGGL(k_amg_restrict, dim3(nb), dim3(256), 0, s, aa.t[l], l == 0 ? cg.r : aa.t[l - 1].rc, aa.part + off, cg.trace);
     off += nb;
   }
   for (int l = aa.n_transfers - 1; l >= 1; --l)
     hipLaunchKernelGGL(k_amg_prolong, dim3(nblk(aa.t[l].nb, 32)), dim3(256), 0, s, aa.t[l], aa.t[l - 1].y,
-                       AMG_DEEP_WEIGHT);
+                       AMG_DEEP_WEIGHT, cg.trace);
   hipLaunchKernelGGL(k_amg_update2, dim3(nblk(cg.S, 32) > 0 ? nblk(cg.S, 32) : 1), dim3(256), 0, s, cg, aa.t[0],
                      aa.n_transfers > 0 ? 1 : 0, aa.part, aa.n_part, cg2_blocks_vec(cg.S), parity, mode, rtol,
                      AMG_COARSE_WEIGHT, AMG_DEEP_WEIGHT,

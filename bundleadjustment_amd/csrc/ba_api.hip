@@ -1807,6 +1807,44 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
       default: break;
     }
   };
+  if (which == 9) {
+    // one PCG iteration with time stamps at the phase marks of its kernels, table on stderr
+    if (!p->explicit_ok || !with_amg) return fail(BA_ERR_INVALID, "ba_time_kernel: the traced iteration needs the multilevel PCG (solve once first)");
+    const size_t nt = (size_t)PCG_TRACE_KERNELS * PCG_TRACE_MAXWG * PCG_TRACE_SLOTS;
+    unsigned long long *d_tr = nullptr;
+    HIP_OK(hipMalloc((void **)&d_tr, nt * sizeof(unsigned long long)));
+    amg_numeric(p->amg, s, p->d_bsr_val, p->d_Minv);
+    launch_amg_cg_init(s, ba, p->amg, 0.0);
+    for (int k = 0; k < 2 * repeats; ++k) launch_amg_cg_iteration(s, ba, p->amg, k & 1);
+    HIP_OK(hipMemsetAsync(d_tr, 0, nt * sizeof(unsigned long long), s));
+    HIP_OK(hipStreamSynchronize(s));
+    BsrCgArgs bt = ba;
+    bt.trace = d_tr;
+    launch_amg_cg_iteration(s, bt, p->amg, 0);
+    launch_amg_cg_iteration(s, ba, p->amg, 1);
+    HIP_OK(hipStreamSynchronize(s));
+    std::vector<unsigned long long> tr(nt);
+    HIP_OK(hipMemcpy(tr.data(), d_tr, nt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    (void)hipFree(d_tr);
+    unsigned long long t0 = ~0ULL;
+    for (size_t k = 0; k < nt; ++k)
+      if (tr[k] && tr[k] < t0) t0 = tr[k];
+    static const char *names[PCG_TRACE_KERNELS] = {"spmv", "update1_restrict", "restrict", "prolong", "update2"};
+    fprintf(stderr, "PCG iteration trace (us since the first stamp; min / median / max over workgroups)\n");
+    for (int kk = 0; kk < PCG_TRACE_KERNELS; ++kk)
+      for (int m = 0; m < PCG_TRACE_SLOTS; ++m) {
+        std::vector<double> v;
+        for (int w = 0; w < PCG_TRACE_MAXWG; ++w) {
+          const unsigned long long x = tr[((size_t)kk * PCG_TRACE_MAXWG + w) * PCG_TRACE_SLOTS + m];
+          if (x) v.push_back(0.01 * (double)(x - t0));
+        }
+        if (v.empty()) continue;
+        std::sort(v.begin(), v.end());
+        fprintf(stderr, "  %-18s mark %d  n=%4zu  %7.2f %7.2f %7.2f\n", names[kk], m, v.size(), v.front(), v[v.size() / 2], v.back());
+      }
+    *seconds_per_launch = 0.0;
+    return p->check_kernels();
+  }
   if (which < 0 || which > 8) return fail(BA_ERR_INVALID, "ba_time_kernel: unknown kernel %d", which);
   run();  // warm-up
   HIP_OK(hipEventRecord(e0, s));

@@ -6,6 +6,14 @@
 
 namespace ba {
 
+// time stamp of a phase mark (tracing only: the wait makes the stamp mean "everything before it has arrived")
+__device__ __forceinline__ void pcg_mark(unsigned long long *tr, int kernel, int mark, int wg) {
+  if (tr) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && wg < PCG_TRACE_MAXWG) tr[((size_t)kernel * PCG_TRACE_MAXWG + wg) * PCG_TRACE_SLOTS + mark] = wall_clock64();
+  }
+}
+
 // thread per station: z_i = Minv_i r_i; returns r_i . z_i
 __device__ __forceinline__ double station_precond(const double *__restrict__ Minv, const double *__restrict__ r,
                                                   double *__restrict__ z, int i) {
@@ -74,6 +82,7 @@ __device__ __forceinline__ double cg2_update1_body(const BsrCgArgs &a, int parit
   // its loads are independent; then the 8 threads-classes are reduced across the wave and the waves.
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t o = 6 * (int64_t)a.S;
+  pcg_mark(a.trace, 1, 1, blockIdx.x);
   for (int k = threadIdx.x; k < a.ncam; k += blockDim.x) pcs[k] = a.p[o + k];
   for (int q0 = 0; q0 < 1 + a.ncam; q0 += 8) {
     const int qn = q0 + (threadIdx.x & 7);
@@ -122,6 +131,7 @@ __device__ __forceinline__ double cg2_update1_body(const BsrCgArgs &a, int parit
   const double pq = pq_s;
   const double rz = a.scal[parity];
   const double alpha = rz / pq;
+  pcg_mark(a.trace, 1, 2, blockIdx.x);
   if (vblock < 0) return alpha;
   const int i = vblock * blockDim.x + threadIdx.x;
   double dot = 0.0;
@@ -153,8 +163,10 @@ __device__ __forceinline__ double cg2_update1_body(const BsrCgArgs &a, int parit
     }
     if (threadIdx.x == 0) a.scal[4] = pq;
   }
+  pcg_mark(a.trace, 1, 3, blockIdx.x);
   const double t = block_sum(dot, lds);
   if (threadIdx.x == 0) a.part_rz[vblock] = t;
+  pcg_mark(a.trace, 1, 4, blockIdx.x);
   return alpha;
 }
 

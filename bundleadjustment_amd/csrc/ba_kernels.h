@@ -149,7 +149,11 @@ struct BsrCgArgs {
   // approximation of S_ss^-1 S_sc; Lcc is then the INVERSE of Q^T S Q, Q = [-G; I]
   const double *G, *GT;  // by rows and by columns
   double *part_gr;       // per-workgroup partials of G^T r_s
+  // null, or PCG_TRACE_KERNELS x PCG_TRACE_MAXWG x PCG_TRACE_SLOTS time stamps (100 MHz counter) that thread 0 of every
+  // workgroup leaves at the phase marks of the iteration's kernels (ba_time_kernel, which = 9)
+  unsigned long long *trace;
 };
+enum { PCG_TRACE_KERNELS = 5, PCG_TRACE_MAXWG = 2048, PCG_TRACE_SLOTS = 8 };
 void launch_schur_blocks(hipStream_t s, int nu, const int *cstart, const int2 *dst, const int2 *pairs, const double *Y, double *val);
 void launch_bsr_add_diag(hipStream_t s, int S, const int *rowptr, const double *Sdiag, double *val);
 void launch_bsr_to_dense(hipStream_t s, int S, int ncam, const int *rowptr, const int *col, const double *val, const double *Ssc,

@@ -339,7 +339,9 @@ __global__ void __launch_bounds__(64 * SPMV_WAVES)
 k_bsr_spmv(BsrCgArgs a, int parity) {
   __shared__ double lds_pq[SPMV_WAVES];
   __shared__ double lds_qc[SPMV_WAVES][CG2_MAX_CAM + 1];
+  pcg_mark(a.trace, 0, 0, blockIdx.x);
   if (a.scal[8 + parity] != 0.0) return;
+  pcg_mark(a.trace, 0, 1, blockIdx.x);
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double pq = 0.0;
   double tcam0 = 0.0, tcam1 = 0.0;  // camera-row partials of this lane: columns lane and lane + 64
@@ -390,6 +392,7 @@ k_bsr_spmv(BsrCgArgs a, int parity) {
       for (int rr = 0; rr < 6; ++rr) tcam1 += a.Ssc[(6 * (int64_t)i + rr) * a.ncam + lane + 64] * pi[rr];
     }
   }
+  pcg_mark(a.trace, 0, 2, blockIdx.x);
   pq = wave_sum(pq);
   if (lane == 0) lds_pq[w] = pq;
   if (lane < a.ncam) lds_qc[w][lane] = tcam0;
@@ -407,6 +410,7 @@ k_bsr_spmv(BsrCgArgs a, int parity) {
     for (int m = 0; m < SPMV_WAVES; ++m) t += lds_qc[m][k];
     a.part_qc[(int64_t)blockIdx.x * a.ncam + k] = t;
   }
+  pcg_mark(a.trace, 0, 3, blockIdx.x);
 }
 
 // x = 0, r = b, z = M^-1 r, p = z; per-workgroup partials of r.z
