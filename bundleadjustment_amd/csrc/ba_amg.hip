@@ -136,12 +136,19 @@ struct AmgTransfer {  // between a fine level and the next coarser one
   const int *P_rowptr, *P_col;
   const double *P_val;
   const int *Pt_ptr, *Pt_blk, *Pt_row;  // blocks of P by column
+  // the same lists padded to a fixed width, so that a lane finds its entry without reading a pointer array first
+  // (one dependent load fewer per kernel): the first AMG_PT_ELL blocks of column c as (block, row) at Pt_ell[c * AMG_PT_ELL + k],
+  // the columns of the first AMG_P_ELL blocks of row i at P_col_ell[i * AMG_P_ELL + k]; -1 = no entry.  Longer lists
+  // continue in the pointer-based arrays.
+  const int2 *Pt_ell;
+  const int *P_col_ell;
   const double *Dinv_c;                 // inverse diagonal blocks of the coarse matrix
   double *rc, *y;                       // coarse vectors: restricted residual, correction
 };
 // at most AMG_MAX_LEVELS levels; a level needs AMG_MIN_BLOCKS blocks, one beyond the third AMG_DEEP_BLOCKS
 // (more additive levels than that cost iterations instead of saving them)
 enum { AMG_MAX_LEVELS = 3, AMG_MIN_BLOCKS = 4, AMG_DEEP_BLOCKS = 48 };
+enum { AMG_PT_ELL = 64, AMG_P_ELL = 8 };
 // Weights of the additive combination  z = D0^-1 r + w1 P0 (D1^-1 + w2 P1 D2^-1 P1^T) P0^T r.
 // Any positive weights keep the preconditioner symmetric positive definite; what they change is how much the levels'
 // overlapping corrections overshoot.  Measured on the 10M-observation network (PCG iterations per LM iteration):
@@ -157,59 +164,84 @@ struct AmgApplyArgs {
   int n_part;
 };
 
+// The kernels below are bounded by the latency of dependent loads (index list -> values), not by bytes: each issues
+// every load that does not depend on a scalar of the iteration before it waits for anything.
+
+// row r (= lane & 7, < 6) of the inverse diagonal block of coarse block c
+__device__ __forceinline__ void load_dinv_row(const double *__restrict__ D, int r, double (&d)[6]) {
+  const double2 *p = reinterpret_cast<const double2 *>(D + 6 * (r < 6 ? r : 0));
+  const double2 a = p[0], b = p[1], c = p[2];
+  d[0] = a.x; d[1] = a.y; d[2] = b.x; d[3] = b.y; d[4] = c.x; d[5] = c.y;
+}
 // lanes 0..5 of a group of 8 get y = Dinv rc (rc[k] sits in lane base + k of the same group);
 // returns rc[r] * y[r] of this lane (0 for r >= 6)
-__device__ __forceinline__ double coarse_jacobi(const double *__restrict__ D, double s, int lane, int r, double *y_out) {
+__device__ __forceinline__ double coarse_jacobi(const double (&d)[6], double s, int lane, int r, double *y_out) {
   const int base = lane & ~7;
   double y = 0.0;
 #pragma unroll
-  for (int m = 0; m < 6; ++m) y += D[6 * (r < 6 ? r : 0) + m] * __shfl(s, base + m, 64);
+  for (int m = 0; m < 6; ++m) y += d[m] * __shfl(s, base + m, 64);
   *y_out = y;
   return r < 6 ? s * y : 0.0;
 }
 
-// rc[c] = sum over the blocks of column c of P^T v ; result (per r = lane & 7 < 6) in every group of
-// 8 lanes of the wave.  The indices of up to 64 blocks are fetched with one coalesced load and
-// handed round by shuffles, so that all value loads of a pass are independent of each other.
-// With q != null the vector is v - alpha q, formed on the fly.
-__device__ __forceinline__ double restrict_column(const AmgTransfer &t, int c, const double *__restrict__ v, int lane,
-                                                  const double *__restrict__ q = nullptr, double alpha = 0.0) {
-  const int g = lane >> 3, r = lane & 7, rr = r < 6 ? r : 0;
-  const int k0 = t.Pt_ptr[c], k1 = t.Pt_ptr[c + 1];
-  double s = 0.0;
-  for (int kb = k0; kb < k1; kb += 64) {
-    const int n = min(64, k1 - kb);
-    const int my_blk = lane < n ? t.Pt_blk[kb + lane] : 0, my_row = lane < n ? t.Pt_row[kb + lane] : 0;
+// sv = (P^T v)[c][r] (and sq likewise for a second vector q when WITHQ) in every lane with lane & 7 == r < 6.
+// One wave per coarse block c.  Lane (g, r) = (lane >> 3, lane & 7) takes block g, g + 8, ... of the column and of each
+// its row r: three 16-byte loads of P and one entry of v (and q); P[r][m] v[r] is summed per m in registers and the
+// twelve sums are folded over the wave at the end (one transposing reduction).
+template <bool WITHQ>
+__device__ __forceinline__ void restrict_column(const AmgTransfer &t, int c, const double *__restrict__ v, const double *__restrict__ q,
+                                                int lane, double &sv, double &sq) {
+  const int g = lane >> 3, r = lane & 7;
+  const bool rl = r < 6;
+  const int2 ent0 = t.Pt_ell[(int64_t)c * AMG_PT_ELL + lane];
+  const int k0 = t.Pt_ptr[c], k1 = t.Pt_ptr[c + 1];  // only for columns longer than AMG_PT_ELL
+  double av[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, aq[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  int my_blk = ent0.x, my_row = ent0.y;
+  for (int kb = k0;;) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      double pv[4][6], vv[4][6];
+      double2 pv[4][3];
+      double vv[4], qv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int e = g + 8 * (4 * h + u);
         const int blk = __shfl(my_blk, e, 64), row = __shfl(my_row, e, 64);
-        const bool on = e < n;
-        const double *P = t.P_val + 36 * (int64_t)blk + rr, *vi = v + 6 * (int64_t)row;
+        const bool on = blk >= 0 && rl;
+        const double2 *P = reinterpret_cast<const double2 *>(t.P_val + 36 * (int64_t)(on ? blk : 0) + 6 * (rl ? r : 0));
 #pragma unroll
-        for (int m = 0; m < 6; ++m) {
-          pv[u][m] = on ? P[6 * m] : 0.0;
-          vv[u][m] = on ? vi[m] : 0.0;
-        }
-        if (q) {
-          const double *qi = q + 6 * (int64_t)row;
-#pragma unroll
-          for (int m = 0; m < 6; ++m) vv[u][m] -= on ? alpha * qi[m] : 0.0;
-        }
+        for (int m = 0; m < 3; ++m) pv[u][m] = on ? P[m] : make_double2(0.0, 0.0);
+        vv[u] = on ? v[6 * (int64_t)row + r] : 0.0;
+        if (WITHQ) qv[u] = on ? q[6 * (int64_t)row + r] : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int m = 0; m < 6; ++m) s += pv[u][m] * vv[u][m];
+        for (int m = 0; m < 3; ++m) {
+          av[2 * m] += pv[u][m].x * vv[u];
+          av[2 * m + 1] += pv[u][m].y * vv[u];
+          if (WITHQ) {
+            aq[2 * m] += pv[u][m].x * qv[u];
+            aq[2 * m + 1] += pv[u][m].y * qv[u];
+          }
+        }
     }
+    kb += 64;
+    if (kb >= k1) break;  // uniform over the wave
+    const int n = min(64, k1 - kb);
+    my_blk = lane < n ? t.Pt_blk[kb + lane] : -1;
+    my_row = lane < n ? t.Pt_row[kb + lane] : 0;
   }
-  s += __shfl_xor(s, 8, 64);
-  s += __shfl_xor(s, 16, 64);
-  s += __shfl_xor(s, 32, 64);
-  return s;
+  double w[16];
+#pragma unroll
+  for (int m = 0; m < 6; ++m) {
+    w[m] = av[m];
+    w[6 + m] = WITHQ ? aq[m] : 0.0;
+  }
+  w[12] = w[13] = w[14] = w[15] = 0.0;
+  const double tot = wave_sum16(w, lane);  // the total of value k sits in the lanes whose bits 5..2 spell k backwards
+  const int kv = rl ? r : 0, kq = 6 + kv;
+  sv = __shfl(tot, 32 * ((kv >> 3) & 1) + 16 * ((kv >> 2) & 1) + 8 * ((kv >> 1) & 1) + 4 * (kv & 1), 64);
+  sq = WITHQ ? __shfl(tot, 32 * ((kq >> 3) & 1) + 16 * ((kq >> 2) & 1) + 8 * ((kq >> 1) & 1) + 4 * (kq & 1), 64) : 0.0;
 }
 
 // restriction: rc = P^T v, y = Dc^-1 rc ; one wave per coarse block; per-workgroup partials of rc . y
@@ -221,13 +253,15 @@ k_amg_restrict(AmgTransfer t, const double *__restrict__ v, double *__restrict__
   const int r = lane & 7;
   double dot = 0.0;
   if (c < t.nc) {
-    const double s = restrict_column(t, c, v, lane);
+    double d[6], s, unused;
+    load_dinv_row(t.Dinv_c + 36 * (int64_t)c, r, d);
+    restrict_column<false>(t, c, v, nullptr, lane, s, unused);
     double y;
-    const double d = coarse_jacobi(t.Dinv_c + 36 * (int64_t)c, s, lane, r, &y);
+    const double dd = coarse_jacobi(d, s, lane, r, &y);
     if (lane < 6) {
       t.rc[6 * (int64_t)c + lane] = s;
       t.y[6 * (int64_t)c + lane] = y;
-      dot = d;
+      dot = dd;
     }
   }
   pcg_mark(trace, 2, 1, blockIdx.x);
@@ -238,62 +272,84 @@ k_amg_restrict(AmgTransfer t, const double *__restrict__ v, double *__restrict__
 
 // Second kernel of a multilevel PCG iteration: the vector update and the first restriction in one
 // launch.  Workgroups [0, nbv) update x, r, z (thread per station); the others restrict the NEW residual
-// r_in - alpha q, formed on the fly, so they need not wait for the first group.  The residual is double
-// buffered by iteration parity because the two groups run concurrently.
-__global__ void __launch_bounds__(256)
+// r_in - alpha q: P^T r_in and P^T q are summed before alpha is known, so nothing but arithmetic waits for the fold.
+// The residual is double buffered by iteration parity because the two groups run concurrently.
+__global__ void __launch_bounds__(256, 2)
 k_amg_update1_restrict(BsrCgArgs a, AmgTransfer t, int parity, int nblk_spmv, int nbv, double *__restrict__ part) {
-  __shared__ double lds[4];
+  __shared__ Cg2Shared sh;
   pcg_mark(a.trace, 1, 0, blockIdx.x);
-  if (a.scal[8 + parity] != 0.0) return;
+  const double done = a.scal[8 + parity], rz = a.scal[parity];
   const double *rin = parity ? a.r2 : a.r;
   double *rout = parity ? a.r : a.r2;
-  const bool vec = (int)blockIdx.x < nbv;
-  const double alpha = cg2_update1_body(a, parity, nblk_spmv, rin, rout, vec ? (int)blockIdx.x : -1, nbv);
-  if (vec) return;
+  FoldLoads f;
+  fold_issue(a, nblk_spmv, 0, f);
+  if ((int)blockIdx.x < nbv) {
+    VecLoads v;
+    vec_issue(a, rin, blockIdx.x, nbv, v);
+    if (done != 0.0) return;
+    pcg_mark(a.trace, 1, 1, blockIdx.x);
+    const double alpha = cg2_alpha(a, rz, nblk_spmv, f, sh);
+    pcg_mark(a.trace, 1, 2, blockIdx.x);
+    vec_finish(a, alpha, rout, blockIdx.x, nbv, v, sh);
+    return;
+  }
   const int cb = blockIdx.x - nbv;
   const int c = cb * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, r = lane & 7;
+  double d[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, sv = 0.0, sq = 0.0;
+  if (c < t.nc) {
+    load_dinv_row(t.Dinv_c + 36 * (int64_t)c, r, d);
+    restrict_column<true>(t, c, rin, a.q, lane, sv, sq);
+  }
+  if (done != 0.0) return;
+  pcg_mark(a.trace, 1, 1, blockIdx.x);
+  const double alpha = cg2_alpha(a, rz, nblk_spmv, f, sh);
+  pcg_mark(a.trace, 1, 2, blockIdx.x);
   double dot = 0.0;
   if (c < t.nc) {
-    const double s = restrict_column(t, c, rin, lane, a.q, alpha);
+    const double s = sv - alpha * sq;
     double y;
-    const double d = coarse_jacobi(t.Dinv_c + 36 * (int64_t)c, s, lane, r, &y);
+    const double dd = coarse_jacobi(d, s, lane, r, &y);
     if (lane < 6) {
       t.rc[6 * (int64_t)c + lane] = s;
       t.y[6 * (int64_t)c + lane] = y;
-      dot = d;
+      dot = dd;
     }
   }
   pcg_mark(a.trace, 1, 3, blockIdx.x);
-  const double tot = block_sum(dot, lds);
+  const double tot = block_sum(dot, sh.lds);
   if (threadIdx.x == 0) part[cb] = tot;
   pcg_mark(a.trace, 1, 4, blockIdx.x);
 }
 
-// (P yc)[i][r] for the 8 lanes of a group (r = lane & 7 < 6): column indices of up to 8 blocks come
-// from one load and shuffles, so the value loads do not wait for one another
+// (P yc)[i][r] for the 8 lanes of a group (r = lane & 7 < 6): the column indices of the row's first AMG_P_ELL blocks
+// come from the padded list (no pointer needed), so they travel together with the row pointer; the value loads follow
 __device__ __forceinline__ double prolong_row(const AmgTransfer &t, int i, int lane) {
   const int r = lane & 7, rr = r < 6 ? r : 0, base = lane & ~7;
+  int my_col = t.P_col_ell[(int64_t)i * AMG_P_ELL + r];
   const int k0 = t.P_rowptr[i], k1 = t.P_rowptr[i + 1];
   double s = 0.0;
-  for (int kb = k0; kb < k1; kb += 8) {
-    const int n = min(8, k1 - kb);
-    const int my_col = r < n ? t.P_col[kb + r] : 0;
-    double pv[8][6], yv[8][6];
+  for (int kb = k0;;) {
+    double2 pv[8][3], yv[8][3];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int col = __shfl(my_col, base + u, 64);
-      const bool on = u < n;
-      const double *P = t.P_val + 36 * (int64_t)(kb + (on ? u : 0)) + 6 * rr, *yc = t.y + 6 * (int64_t)col;
+      const bool on = col >= 0;
+      const double2 *P = reinterpret_cast<const double2 *>(t.P_val + 36 * (int64_t)(on ? kb + u : k0) + 6 * rr);
+      const double2 *yc = reinterpret_cast<const double2 *>(t.y + 6 * (int64_t)(on ? col : 0));
 #pragma unroll
-      for (int m = 0; m < 6; ++m) {
-        pv[u][m] = on ? P[m] : 0.0;
-        yv[u][m] = on ? yc[m] : 0.0;
+      for (int m = 0; m < 3; ++m) {
+        pv[u][m] = on ? P[m] : make_double2(0.0, 0.0);
+        yv[u][m] = on ? yc[m] : make_double2(0.0, 0.0);
       }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
 #pragma unroll
-      for (int m = 0; m < 6; ++m) s += pv[u][m] * yv[u][m];
+      for (int m = 0; m < 3; ++m) s += pv[u][m].x * yv[u][m].x + pv[u][m].y * yv[u][m].y;
+    kb += 8;
+    if (kb >= k1) break;  // not uniform over the wave: the shuffles below only read lanes of the own group
+    const int n = min(8, k1 - kb);
+    my_col = r < n ? t.P_col[kb + r] : -1;
   }
   return s;
 }
@@ -304,9 +360,10 @@ k_amg_prolong(AmgTransfer t, double *__restrict__ yf, double tau, unsigned long 
   pcg_mark(trace, 3, 0, blockIdx.x);
   const int i = blockIdx.x * 32 + (threadIdx.x >> 3), r = threadIdx.x & 7, lane = threadIdx.x & 63;
   const bool on = i < t.nb;
+  const double y0 = (on && r < 6) ? yf[6 * (int64_t)i + r] : 0.0;
   const double s = prolong_row(t, on ? i : 0, lane);
   pcg_mark(trace, 3, 1, blockIdx.x);
-  if (on && r < 6) yf[6 * (int64_t)i + r] += tau * s;
+  if (on && r < 6) yf[6 * (int64_t)i + r] = y0 + tau * s;
   pcg_mark(trace, 3, 2, blockIdx.x);
 }
 
@@ -324,34 +381,48 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restr
   __shared__ double rzn_s;
   __shared__ double Ls[AMG_DEFL_NC * AMG_DEFL_NC], gr4[4][16], zcs[AMG_DEFL_NC], tcs[AMG_DEFL_NC], tot_s;
   pcg_mark(cg.trace, 4, 0, blockIdx.x);
-  if (mode == 1) {
-    const double done = cg.scal[8 + parity];
-    if (done != 0.0) {
-      if (blockIdx.x == 0 && threadIdx.x == 0) cg.scal[8 + (parity ^ 1)] = done;
-      return;
-    }
-  }
-  pcg_mark(cg.trace, 4, 1, blockIdx.x);
+  // ---- loads: none of them depends on beta
+  const double done = (mode == 1) ? cg.scal[8 + parity] : 0.0;
+  const double rz_old = (mode == 1) ? cg.scal[parity] : 1.0;
+  const double it_old = cg.scal[3], pq_last = cg.scal[4], target = cg.scal[6];
   const int64_t o = 6 * (int64_t)cg.S;
   const bool defl = cg.G != nullptr;  // then ncam <= AMG_DEFL_NC
+  const int i = blockIdx.x * 32 + (threadIdx.x >> 3), r = threadIdx.x & 7;
+  const bool on = i < cg.S, mine = on && r < 6;
+  const double z0 = mine ? cg.z[6 * (int64_t)i + r] : 0.0;
+  const double p0 = (mine && mode == 1) ? cg.p[6 * (int64_t)i + r] : 0.0;
+  double gi[AMG_DEFL_NC];
+#pragma unroll
+  for (int k = 0; k < AMG_DEFL_NC; ++k) gi[k] = (defl && mine && k < cg.ncam) ? cg.G[(6 * (int64_t)i + r) * cg.ncam + k] : 0.0;
+  const double lsv = (defl && (int)threadIdx.x < cg.ncam * cg.ncam) ? cg.Lcc[threadIdx.x] : 0.0;
+  const double rcv = (defl && (int)threadIdx.x < cg.ncam) ? ((mode == 1 && !parity) ? cg.r2 : cg.r)[o + threadIdx.x] : 0.0;
+  double g = 0.0;
   if (defl) {
-    for (int k = threadIdx.x; k < cg.ncam * cg.ncam; k += blockDim.x) Ls[k] = cg.Lcc[k];
     // G^T r_s: 16 lanes per sum, the partials dealt round-robin; then across the wave and the waves
     const int k = threadIdx.x & 15, j = threadIdx.x >> 4;
-    double g = 0.0;
     if (k < cg.ncam)
       for (int m = j; m < n_part_rz; m += 16) g += cg.part_gr[(int64_t)m * cg.ncam + k];
-    g += __shfl_xor(g, 16, 64);
-    g += __shfl_xor(g, 32, 64);
-    if ((threadIdx.x & 63) < 16) gr4[threadIdx.x >> 6][k] = g;
   }
   double s = 0.0;
   for (int k = threadIdx.x; k < n_part_rz; k += blockDim.x) s += cg.part_rz[k];
   for (int k = threadIdx.x; k < n_part; k += blockDim.x) s += (k < np0 ? sigma : sigma * tau) * part[k];
+  const double corr = has_coarse ? prolong_row(t, on ? i : 0, threadIdx.x & 63) : 0.0;
+  if (done != 0.0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) cg.scal[8 + (parity ^ 1)] = done;  // keep both slots set
+    return;
+  }
+  pcg_mark(cg.trace, 4, 1, blockIdx.x);
+  // ---- scalars
+  if (defl) {
+    if ((int)threadIdx.x < cg.ncam * cg.ncam) Ls[threadIdx.x] = lsv;
+    g += __shfl_xor(g, 16, 64);
+    g += __shfl_xor(g, 32, 64);
+    if ((threadIdx.x & 63) < 16) gr4[threadIdx.x >> 6][threadIdx.x & 15] = g;
+  }
   const double tot = block_sum(s, lds);  // has the barriers that publish Ls and gr4
   if (threadIdx.x == 0) tot_s = tot;
   if (defl && threadIdx.x < cg.ncam)  // t_c = r_c - G^T r_s
-    tcs[threadIdx.x] = ((mode == 1 && !parity) ? cg.r2 : cg.r)[o + threadIdx.x] - ((gr4[0][threadIdx.x] + gr4[1][threadIdx.x]) + (gr4[2][threadIdx.x] + gr4[3][threadIdx.x]));
+    tcs[threadIdx.x] = rcv - ((gr4[0][threadIdx.x] + gr4[1][threadIdx.x]) + (gr4[2][threadIdx.x] + gr4[3][threadIdx.x]));
   __syncthreads();
   if (defl && threadIdx.x < cg.ncam) {  // z_c = (Q^T S Q)^-1 t_c with the explicit inverse
     double zc = 0.0;
@@ -367,23 +438,20 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restr
   }
   __syncthreads();
   const double rzn = rzn_s;
-  const double beta = (mode == 1) ? rzn / cg.scal[parity] : 0.0;
+  const double beta = (mode == 1) ? rzn / rz_old : 0.0;
   pcg_mark(cg.trace, 4, 2, blockIdx.x);
-  const int i = blockIdx.x * 32 + (threadIdx.x >> 3), r = threadIdx.x & 7;
-  const bool on = i < cg.S;
-  const double corr = has_coarse ? prolong_row(t, on ? i : 0, threadIdx.x & 63) : 0.0;
-  pcg_mark(cg.trace, 4, 3, blockIdx.x);
-  if (on && r < 6) {
-    double z = cg.z[6 * (int64_t)i + r] + sigma * corr;
+  if (mine) {
+    double z = z0 + sigma * corr;
     if (defl) {
-      const double *Gi = cg.G + (6 * (int64_t)i + r) * cg.ncam;
-      for (int k = 0; k < cg.ncam; ++k) z -= Gi[k] * zcs[k];
+#pragma unroll
+      for (int k = 0; k < AMG_DEFL_NC; ++k)
+        if (k < cg.ncam) z -= gi[k] * zcs[k];
     }
-    cg.p[6 * (int64_t)i + r] = (mode == 1) ? z + beta * cg.p[6 * (int64_t)i + r] : z;
+    cg.p[6 * (int64_t)i + r] = (mode == 1) ? z + beta * p0 : z;
   }
+  pcg_mark(cg.trace, 4, 3, blockIdx.x);
   if (defl && blockIdx.x == 0 && threadIdx.x < cg.ncam) cg.z[o + threadIdx.x] = zcs[threadIdx.x];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    const int64_t o = 6 * (int64_t)cg.S;
     for (int k = 0; k < cg.ncam; ++k) {
       const double zc = defl ? zcs[k] : cg.z[o + k];
       cg.p[o + k] = (mode == 1) ? zc + beta * cg.p[o + k] : zc;
@@ -395,11 +463,10 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restr
       cg.scal[8] = cg.scal[9] = (rzn > 0.0) ? 0.0 : 1.0;
     } else {
       cg.scal[parity ^ 1] = rzn;
-      cg.scal[3] += 1.0;
-      const double pq = cg.scal[4];
+      cg.scal[3] = it_old + 1.0;
       double nd = 0.0;
-      if (!(pq > 0.0) || !(rzn == rzn)) nd = 2.0;
-      else if (sqrt(fmax(rzn, 0.0)) <= cg.scal[6]) nd = 1.0;
+      if (!(pq_last > 0.0) || !(rzn == rzn)) nd = 2.0;
+      else if (sqrt(fmax(rzn, 0.0)) <= target) nd = 1.0;
       cg.scal[8 + (parity ^ 1)] = nd;
     }
   }
@@ -427,7 +494,8 @@ struct Level {  // transfer from level l to level l + 1 and everything the numer
   // owned device arrays
   int *P_rowptr = nullptr, *P_col = nullptr, *P_row = nullptr, *P_own = nullptr, *Pa_ptr = nullptr, *Pa_idx = nullptr;
   int *AP_ptr = nullptr, *AP_la = nullptr, *AP_lb = nullptr, *Ac_ptr = nullptr, *Ac_la = nullptr, *Ac_lb = nullptr;
-  int *Pt_ptr = nullptr, *Pt_blk = nullptr, *Pt_row = nullptr;
+  int *Pt_ptr = nullptr, *Pt_blk = nullptr, *Pt_row = nullptr, *P_col_ell = nullptr;
+  int2 *Pt_ell = nullptr;
   int *Ac_rowptr = nullptr, *Ac_col = nullptr, *Ac_diag = nullptr, *used_c = nullptr;
   double *P_val = nullptr, *AP_val = nullptr, *Ac_val = nullptr, *Dinv_c = nullptr, *rc = nullptr, *y = nullptr;
 };
@@ -531,7 +599,8 @@ struct Symbolic {
   std::vector<int> P_rowptr, P_col, P_row, P_own, Pa_ptr, Pa_idx;
   std::vector<int> AP_rowptr, AP_col, AP_ptr, AP_la, AP_lb;
   std::vector<int> Ac_ptr, Ac_la, Ac_lb, Ac_diag;
-  std::vector<int> Pt_ptr, Pt_blk, Pt_row, used_c;
+  std::vector<int> Pt_ptr, Pt_blk, Pt_row, used_c, P_col_ell;
+  std::vector<int2> Pt_ell;
   Pattern Ac;
 };
 
@@ -620,6 +689,15 @@ void symbolic(const Pattern &A, const std::vector<int> &agg, int nc, const std::
     sy.Pt_blk[k] = t;
     sy.Pt_row[k] = sy.P_row[t];
   }
+  // the padded copies the kernels of the iteration start from
+  sy.Pt_ell.assign((size_t)nc * AMG_PT_ELL, make_int2(-1, 0));
+  for (int c = 0; c < nc; ++c)
+    for (int k = sy.Pt_ptr[c]; k < sy.Pt_ptr[c + 1] && k - sy.Pt_ptr[c] < AMG_PT_ELL; ++k)
+      sy.Pt_ell[(size_t)c * AMG_PT_ELL + (k - sy.Pt_ptr[c])] = make_int2(sy.Pt_blk[k], sy.Pt_row[k]);
+  sy.P_col_ell.assign((size_t)nb * AMG_P_ELL, -1);
+  for (int i = 0; i < nb; ++i)
+    for (int k = sy.P_rowptr[i]; k < sy.P_rowptr[i + 1] && k - sy.P_rowptr[i] < AMG_P_ELL; ++k)
+      sy.P_col_ell[(size_t)i * AMG_P_ELL + (k - sy.P_rowptr[i])] = sy.P_col[k];
   sy.used_c.assign(nc, 0);
   for (int i = 0; i < nb; ++i)
     if (used[i]) sy.used_c[agg[i]] = 1;
@@ -696,6 +774,7 @@ int amg_build(Amg *a, hipStream_t s, int nb0, const std::vector<int> &rowptr, co
               a->upload(&L.AP_ptr, sy.AP_ptr) && a->upload(&L.AP_la, sy.AP_la) && a->upload(&L.AP_lb, sy.AP_lb) &&
               a->upload(&L.Ac_ptr, sy.Ac_ptr) && a->upload(&L.Ac_la, sy.Ac_la) && a->upload(&L.Ac_lb, sy.Ac_lb) &&
               a->upload(&L.Pt_ptr, sy.Pt_ptr) && a->upload(&L.Pt_blk, sy.Pt_blk) && a->upload(&L.Pt_row, sy.Pt_row) &&
+              a->upload(&L.Pt_ell, sy.Pt_ell) && a->upload(&L.P_col_ell, sy.P_col_ell) &&
               a->upload(&L.Ac_rowptr, sy.Ac.rowptr) && a->upload(&L.Ac_col, sy.Ac.col) && a->upload(&L.Ac_diag, sy.Ac_diag) &&
               a->upload(&L.used_c, sy.used_c) && a->dalloc(&L.P_val, 36 * (size_t)L.nP) &&
               a->dalloc(&L.AP_val, 36 * (size_t)L.nAP) && a->dalloc(&L.Ac_val, 36 * (size_t)L.nAc) &&
@@ -753,6 +832,7 @@ static AmgApplyArgs apply_args(const Amg *a) {
     AmgTransfer &t = aa.t[l];
     t.nb = L.nb; t.nc = L.nc; t.P_rowptr = L.P_rowptr; t.P_col = L.P_col; t.P_val = L.P_val; t.Pt_ptr = L.Pt_ptr;
     t.Pt_blk = L.Pt_blk; t.Pt_row = L.Pt_row; t.Dinv_c = L.Dinv_c; t.rc = L.rc; t.y = L.y;
+    t.Pt_ell = L.Pt_ell; t.P_col_ell = L.P_col_ell;
   }
   aa.part = a->d_part;
   aa.n_part = a->n_part;

@@ -34,22 +34,20 @@ __device__ __forceinline__ double station_precond(const double *__restrict__ Min
 // Most free camera parameters (summed over the cameras) the kernels of the explicit block-sparse PCG hold in LDS;
 // networks with more take the matrix-free PCG (ba_solve_resident) or the dense solver.
 #define CG2_MAX_CAM 79
-__device__ __forceinline__ void defl_partials(const BsrCgArgs &a, const double *__restrict__ r, int i, int vblock) {
+__device__ __forceinline__ void defl_partials(const BsrCgArgs &a, const double (&ri)[6], int i, int vblock) {
   __shared__ double lds_gr[4][DEFL_NC];
   double gr[DEFL_NC];
 #pragma unroll
   for (int k = 0; k < DEFL_NC; ++k) gr[k] = 0.0;
   if (i < a.S) {
     // GT is G by columns: the six entries of a station are contiguous, neighbouring threads adjoin
-    const double *ri = r + 6 * (int64_t)i;
-    const double r0 = ri[0], r1 = ri[1], r2 = ri[2], r3 = ri[3], r4 = ri[4], r5 = ri[5];
     const int64_t ld = 6 * (int64_t)a.S;
 #pragma unroll
     for (int k = 0; k < DEFL_NC; ++k)
       if (k < a.ncam) {
         const double2 *g = reinterpret_cast<const double2 *>(a.GT + k * ld + 6 * (int64_t)i);
         const double2 g0 = g[0], g1 = g[1], g2 = g[2];
-        gr[k] = g0.x * r0 + g0.y * r1 + g1.x * r2 + g1.y * r3 + g2.x * r4 + g2.y * r5;
+        gr[k] = g0.x * ri[0] + g0.y * ri[1] + g1.x * ri[2] + g1.y * ri[3] + g2.x * ri[4] + g2.y * ri[5];
       }
   }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -64,111 +62,183 @@ __device__ __forceinline__ void defl_partials(const BsrCgArgs &a, const double *
         (lds_gr[0][threadIdx.x] + lds_gr[1][threadIdx.x]) + (lds_gr[2][threadIdx.x] + lds_gr[3][threadIdx.x]);
 }
 
-// Second kernel of a PCG iteration, as a function so that the multilevel variant can run the first
-// restriction in the same launch.  Every workgroup folds the SpMV partials to alpha = r.z / p.Sp.
-// Workgroups with vblock >= 0 (n_vblocks of them, 256 threads, one thread per station) then do
-// x += alpha p, r_out = r_in - alpha q, z = D^-1 r_out and leave partials of r.z; the others return
-// with alpha only.  r_in == r_out updates the residual in place.
-__device__ __forceinline__ double cg2_update1_body(const BsrCgArgs &a, int parity, int nblk_spmv, const double *rin,
-                                                   double *rout, int vblock, int n_vblocks) {
-  __shared__ double lds[8];
-  __shared__ double red[CG2_MAX_CAM + 1];   // [0] p.q over the station rows, [1 + k] camera row k of S p
-  __shared__ double pcs[CG2_MAX_CAM + 1];   // camera part of p
-  __shared__ double pq_s;
-  __shared__ double fold4[4][8];
-  __shared__ double rcs[CG2_MAX_CAM + 1];
-  // Every workgroup folds the SpMV partials in the same order -> identical alpha everywhere.
-  // Eight sums at a time: thread t takes sum (t & 7) and every 32nd partial from (t >> 3) on, so all
-  // its loads are independent; then the 8 threads-classes are reduced across the wave and the waves.
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t o = 6 * (int64_t)a.S;
-  pcg_mark(a.trace, 1, 1, blockIdx.x);
-  for (int k = threadIdx.x; k < a.ncam; k += blockDim.x) pcs[k] = a.p[o + k];
-  for (int q0 = 0; q0 < 1 + a.ncam; q0 += 8) {
-    const int qn = q0 + (threadIdx.x & 7);
-    double s = 0.0;
-    if (qn < 1 + a.ncam) {
-      const double *src = (qn == 0) ? a.part_pq : a.part_qc + (qn - 1);
-      const int64_t st = (qn == 0) ? 1 : a.ncam;
-      // at most 1024 partials (cg2_blocks_spmv): 32 independent loads per thread, summed in a fixed tree
-      double v[32];
+// ---- second kernel of a PCG iteration ---------------------------------------------------------------------------
+// Every workgroup folds the per-workgroup partials of the SpMV (p.q over the station rows and the camera rows of
+// S p) in the same fixed order, so alpha = r.z / p.Sp is identical everywhere; the vector workgroups (one thread per
+// station) then do x += alpha p, r_out = r_in - alpha q, z = D^-1 r_out and leave partials of r.z.
+// The kernels are bounded by the latency of dependent loads, not by bytes, so the work is cut into an ISSUE half that
+// only loads (nothing in it depends on alpha) and a FINISH half that only computes and stores: a kernel issues all
+// its halves first and the loads of the fold, of the vector update and of a restriction travel together.
+struct Cg2Shared {
+  double lds[8];
+  double red[CG2_MAX_CAM + 1];  // [0] p.q over the station rows, [1 + k] camera row k of S p
+  double pcs[CG2_MAX_CAM + 1];  // camera part of p
+  double rcs[CG2_MAX_CAM + 1];
+  double fold4[4][8];
+  double pq;
+};
+
+// Eight sums at a time (q0 .. q0 + 7 of the 1 + ncam): thread t takes sum (t & 7) and every 32nd partial from
+// (t >> 3) on; at most CG2_MAX_SPMV_BLOCKS partials (cg2_blocks_spmv).
+#define CG2_FOLD_LOADS 24
+#define CG2_MAX_SPMV_BLOCKS (32 * CG2_FOLD_LOADS)
+struct FoldLoads {
+  double v[CG2_FOLD_LOADS];
+  double pc;        // camera entry threadIdx.x of p
+  double scc[8];    // row threadIdx.x of Scc when ncam <= 8
+};
+__device__ __forceinline__ void fold_issue(const BsrCgArgs &a, int nblk_spmv, int q0, FoldLoads &f) {
+  const int qn = q0 + (threadIdx.x & 7);
+  const bool on = qn < 1 + a.ncam;
+  const double *src = (qn == 0) ? a.part_pq : a.part_qc + (qn - 1);
+  const int64_t st = (qn == 0) ? 1 : a.ncam;
 #pragma unroll
-      for (int j = 0; j < 32; ++j) {
-        const int m = (threadIdx.x >> 3) + 32 * j;
-        v[j] = (m < nblk_spmv) ? src[st * m] : 0.0;
-      }
+  for (int j = 0; j < CG2_FOLD_LOADS; ++j) {
+    const int m = (threadIdx.x >> 3) + 32 * j;
+    f.v[j] = (on && m < nblk_spmv) ? src[st * m] : 0.0;
+  }
+  if (q0 == 0) {
+    const int t = threadIdx.x;
+    f.pc = (t < a.ncam) ? a.p[6 * (int64_t)a.S + t] : 0.0;
+    if (a.ncam <= 8) {
 #pragma unroll
-      for (int w2 = 16; w2 >= 1; w2 >>= 1)
-#pragma unroll
-        for (int j = 0; j < w2; ++j) v[j] += v[j + w2];
-      s = v[0];
+      for (int m = 0; m < 8; ++m) f.scc[m] = (t < a.ncam && m < a.ncam) ? a.Scc[t * a.ncam + m] : 0.0;
     }
+  }
+}
+
+// alpha from the loads of fold_issue(q0 = 0) (further rounds of eight sums are loaded here); leaves red, pcs, pq in sh
+__device__ __forceinline__ double cg2_alpha(const BsrCgArgs &a, double rz, int nblk_spmv, FoldLoads &f, Cg2Shared &sh) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x < a.ncam) sh.pcs[threadIdx.x] = f.pc;
+  for (int q0 = 0; q0 < 1 + a.ncam; q0 += 8) {
+    if (q0 > 0) fold_issue(a, nblk_spmv, q0, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] += f.v[j + 8] + f.v[j + 16];  // fixed order
+#pragma unroll
+    for (int w2 = 4; w2 >= 1; w2 >>= 1)
+#pragma unroll
+      for (int j = 0; j < w2; ++j) f.v[j] += f.v[j + w2];
+    double s = f.v[0];
     s += __shfl_xor(s, 8, 64);
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
     __syncthreads();
-    if (lane < 8) fold4[w][lane] = s;
+    if (lane < 8) sh.fold4[w][lane] = s;
     __syncthreads();
     if (threadIdx.x < 8 && q0 + threadIdx.x < 1 + a.ncam)
-      red[q0 + threadIdx.x] = (fold4[0][threadIdx.x] + fold4[1][threadIdx.x]) + (fold4[2][threadIdx.x] + fold4[3][threadIdx.x]);
+      sh.red[q0 + threadIdx.x] = (sh.fold4[0][threadIdx.x] + sh.fold4[1][threadIdx.x]) + (sh.fold4[2][threadIdx.x] + sh.fold4[3][threadIdx.x]);
   }
   __syncthreads();
   // camera rows: add the corner, S_cc p_c
   double qk = 0.0;
   if (threadIdx.x < a.ncam) {
-    qk = red[1 + threadIdx.x];
-    for (int m = 0; m < a.ncam; ++m) qk += a.Scc[threadIdx.x * a.ncam + m] * pcs[m];
+    qk = sh.red[1 + threadIdx.x];
+    if (a.ncam <= 8) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+        if (m < a.ncam) qk += f.scc[m] * sh.pcs[m];
+    } else {
+      for (int m = 0; m < a.ncam; ++m) qk += a.Scc[threadIdx.x * a.ncam + m] * sh.pcs[m];
+    }
   }
   __syncthreads();
-  if (threadIdx.x < a.ncam) red[1 + threadIdx.x] = qk;
+  if (threadIdx.x < a.ncam) sh.red[1 + threadIdx.x] = qk;
   __syncthreads();
   if (threadIdx.x == 0) {
-    double pq = red[0];
-    for (int k = 0; k < a.ncam; ++k) pq += red[1 + k] * pcs[k];
-    pq_s = pq;
+    double pq = sh.red[0];
+    for (int k = 0; k < a.ncam; ++k) pq += sh.red[1 + k] * sh.pcs[k];
+    sh.pq = pq;
   }
   __syncthreads();
-  const double pq = pq_s;
-  const double rz = a.scal[parity];
-  const double alpha = rz / pq;
-  pcg_mark(a.trace, 1, 2, blockIdx.x);
-  if (vblock < 0) return alpha;
+  return rz / sh.pq;
+}
+
+// vector update of station i = vblock * 256 + threadIdx.x.  u = D^-1 r_in and w = D^-1 q are formed while alpha is
+// still unknown (the 36 entries of the block are dead again before the fold starts); z = u - alpha w afterwards.
+struct VecLoads {
+  double2 x[3], p[3];
+  double r[6], q[6], u[6], w[6];
+  double rc;  // camera entry threadIdx.x of r_in (last vector workgroup)
+};
+__device__ __forceinline__ void vec_issue(const BsrCgArgs &a, const double *rin, int vblock, int n_vblocks, VecLoads &v) {
   const int i = vblock * blockDim.x + threadIdx.x;
-  double dot = 0.0;
   if (i < a.S) {
+    const double2 *x = reinterpret_cast<const double2 *>(a.x + 6 * (int64_t)i), *p = reinterpret_cast<const double2 *>(a.p + 6 * (int64_t)i);
+    const double2 *r = reinterpret_cast<const double2 *>(rin + 6 * (int64_t)i), *q = reinterpret_cast<const double2 *>(a.q + 6 * (int64_t)i);
+    const double2 *m = reinterpret_cast<const double2 *>(a.Minv + 36 * (int64_t)i);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      v.x[k] = x[k];
+      v.p[k] = p[k];
+      const double2 rr = r[k], qq = q[k];
+      v.r[2 * k] = rr.x; v.r[2 * k + 1] = rr.y;
+      v.q[2 * k] = qq.x; v.q[2 * k + 1] = qq.y;
+    }
+    // the block in two halves of three rows: 36 registers in flight instead of 72
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      double2 mm[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) mm[k] = m[9 * h + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double2 m0 = mm[3 * k], m1 = mm[3 * k + 1], m2 = mm[3 * k + 2];
+        v.u[3 * h + k] = m0.x * v.r[0] + m0.y * v.r[1] + m1.x * v.r[2] + m1.y * v.r[3] + m2.x * v.r[4] + m2.y * v.r[5];
+        v.w[3 * h + k] = m0.x * v.q[0] + m0.y * v.q[1] + m1.x * v.q[2] + m1.y * v.q[3] + m2.x * v.q[4] + m2.y * v.q[5];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  v.rc = (vblock == n_vblocks - 1 && threadIdx.x < a.ncam) ? rin[6 * (int64_t)a.S + threadIdx.x] : 0.0;
+}
+__device__ __forceinline__ void vec_finish(const BsrCgArgs &a, double alpha, double *rout, int vblock, int n_vblocks, const VecLoads &v,
+                                           Cg2Shared &sh) {
+  const int i = vblock * blockDim.x + threadIdx.x;
+  const int64_t o = 6 * (int64_t)a.S;
+  double dot = 0.0;
+  double r[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (i < a.S) {
+    double z[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      a.x[6 * (int64_t)i + k] += alpha * a.p[6 * (int64_t)i + k];
-      rout[6 * (int64_t)i + k] = rin[6 * (int64_t)i + k] - alpha * a.q[6 * (int64_t)i + k];
+      r[k] = v.r[k] - alpha * v.q[k];
+      z[k] = v.u[k] - alpha * v.w[k];
+      dot += z[k] * r[k];
     }
-    dot = station_precond(a.Minv, rout, a.z, i);
+    double2 *xo = reinterpret_cast<double2 *>(a.x + 6 * (int64_t)i), *ro = reinterpret_cast<double2 *>(rout + 6 * (int64_t)i);
+    double2 *zo = reinterpret_cast<double2 *>(a.z + 6 * (int64_t)i);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      xo[k] = make_double2(v.x[k].x + alpha * v.p[k].x, v.x[k].y + alpha * v.p[k].y);
+      ro[k] = make_double2(r[2 * k], r[2 * k + 1]);
+      zo[k] = make_double2(z[2 * k], z[2 * k + 1]);
+    }
   }
-  if (a.G) defl_partials(a, rout, i, vblock);
+  if (a.G) defl_partials(a, r, i, vblock);
   if (vblock == n_vblocks - 1) {
-    // the last workgroup is the least loaded one: it also carries the camera entries (ncam <= 80).
+    // the last workgroup is the least loaded one: it also carries the camera entries (ncam <= CG2_MAX_CAM).
     // z_c = Scc^-1 r_c with the explicit inverse, one thread per row; with the camera coarse space only
     // x and r here, the camera part of z follows in the last kernel.
     if (threadIdx.x < a.ncam) {
-      a.x[o + threadIdx.x] += alpha * pcs[threadIdx.x];
-      const double rk = rin[o + threadIdx.x] - alpha * red[1 + threadIdx.x];
+      a.x[o + threadIdx.x] += alpha * sh.pcs[threadIdx.x];
+      const double rk = v.rc - alpha * sh.red[1 + threadIdx.x];
       rout[o + threadIdx.x] = rk;
-      rcs[threadIdx.x] = rk;
+      sh.rcs[threadIdx.x] = rk;
     }
     __syncthreads();
     if (!a.G && threadIdx.x < a.ncam) {
       double z = 0.0;
-      for (int m = 0; m < a.ncam; ++m) z += a.Lcc[threadIdx.x * a.ncam + m] * rcs[m];
+      for (int m = 0; m < a.ncam; ++m) z += a.Lcc[threadIdx.x * a.ncam + m] * sh.rcs[m];
       a.z[o + threadIdx.x] = z;
-      dot += rcs[threadIdx.x] * z;
+      dot += sh.rcs[threadIdx.x] * z;
     }
-    if (threadIdx.x == 0) a.scal[4] = pq;
+    if (threadIdx.x == 0) a.scal[4] = sh.pq;
   }
   pcg_mark(a.trace, 1, 3, blockIdx.x);
-  const double t = block_sum(dot, lds);
+  const double t = block_sum(dot, sh.lds);
   if (threadIdx.x == 0) a.part_rz[vblock] = t;
   pcg_mark(a.trace, 1, 4, blockIdx.x);
-  return alpha;
 }
-
 
 }  // namespace ba

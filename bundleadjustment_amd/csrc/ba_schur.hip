@@ -429,7 +429,13 @@ k_cg2_init(BsrCgArgs a) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) a.p[6 * (int64_t)i + k] = a.z[6 * (int64_t)i + k];
   }
-  if (a.G) defl_partials(a, a.r, i, blockIdx.x);
+  if (a.G) {
+    double ri[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (i < a.S)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ri[k] = a.b[6 * (int64_t)i + k];
+    defl_partials(a, ri, i, blockIdx.x);
+  }
   if (blockIdx.x == 0 && a.ncam > 0) {
     // camera entries: x = 0, r = b and (without the coarse space) z = Scc^-1 r with the explicit inverse,
     // one thread per row.  With the coarse space the camera part of z needs G^T r_s: the last kernel does it.
@@ -473,8 +479,15 @@ k_cg2_init_finish(BsrCgArgs a, int nblk, double rtol) {
 // alpha = r.z / p.Sp; x += alpha p; r -= alpha q; z = M^-1 r; partials of the new r.z
 __global__ void __launch_bounds__(256)
 k_cg2_update1(BsrCgArgs a, int parity, int nblk_spmv) {
-  if (a.scal[8 + parity] != 0.0) return;
-  (void)cg2_update1_body(a, parity, nblk_spmv, a.r, a.r, blockIdx.x, gridDim.x);
+  __shared__ Cg2Shared sh;
+  const double done = a.scal[8 + parity], rz = a.scal[parity];
+  FoldLoads f;
+  VecLoads v;
+  fold_issue(a, nblk_spmv, 0, f);
+  vec_issue(a, a.r, blockIdx.x, gridDim.x, v);
+  if (done != 0.0) return;
+  const double alpha = cg2_alpha(a, rz, nblk_spmv, f, sh);
+  vec_finish(a, alpha, a.r, blockIdx.x, gridDim.x, v, sh);
 }
 
 // beta = r.z(new) / r.z(old); p = z + beta p; stopping test for the next iteration
@@ -653,16 +666,16 @@ void launch_border_corner(hipStream_t s, int ncam, const double *corner, const d
   hipLaunchKernelGGL(k_border_corner, dim3(1), dim3(1), 0, s, ncam, corner, camdiag, Scc);
 }
 int cg2_blocks_spmv(int S) {
-  // one resident round of workgroups; also bounds the partials the vector kernel folds (32 loads per thread)
+  // one resident round of workgroups; also bounds the partials the vector kernel folds
   const int nb = nblk(S, SPMV_WAVES);
   // as many workgroups as the device holds at once (three per CU on MI355X: 768; a fourth hundred would wait for a
-  // second round and costs 10 %), at most the 1024 partials the fold takes
+  // second round and costs 10 %), at most the partials the fold takes
   static int cap = 0;
   if (!cap) {
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bsr_spmv, 64 * SPMV_WAVES, 0) == hipSuccess && cus > 0 && per_cu > 0)
-      cap = std::min(1024, cus * per_cu);
+      cap = std::min((int)CG2_MAX_SPMV_BLOCKS, cus * per_cu);
     else
       cap = 512;
     (void)hipGetLastError();
