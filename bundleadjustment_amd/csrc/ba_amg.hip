@@ -188,16 +188,27 @@ __device__ __forceinline__ double coarse_jacobi(const double (&d)[6], double s, 
 // One wave per coarse block c.  Lane (g, r) = (lane >> 3, lane & 7) takes block g, g + 8, ... of the column and of each
 // its row r: three 16-byte loads of P and one entry of v (and q); P[r][m] v[r] is summed per m in registers and the
 // twelve sums are folded over the wave at the end (one transposing reduction).
+struct RestrictIdx {
+  int blk, row, k0, k1;
+};
+__device__ __forceinline__ RestrictIdx restrict_issue(const AmgTransfer &t, int c, int lane) {
+  const int2 e = t.Pt_ell[(int64_t)c * AMG_PT_ELL + lane];
+  RestrictIdx x;
+  x.blk = e.x;
+  x.row = e.y;
+  x.k0 = t.Pt_ptr[c];      // only for columns longer than AMG_PT_ELL
+  x.k1 = t.Pt_ptr[c + 1];
+  return x;
+}
 template <bool WITHQ>
-__device__ __forceinline__ void restrict_column(const AmgTransfer &t, int c, const double *__restrict__ v, const double *__restrict__ q,
+__device__ __forceinline__ void restrict_finish(const AmgTransfer &t, RestrictIdx x, const double *__restrict__ v, const double *__restrict__ q,
                                                 int lane, double &sv, double &sq) {
   const int g = lane >> 3, r = lane & 7;
   const bool rl = r < 6;
-  const int2 ent0 = t.Pt_ell[(int64_t)c * AMG_PT_ELL + lane];
-  const int k0 = t.Pt_ptr[c], k1 = t.Pt_ptr[c + 1];  // only for columns longer than AMG_PT_ELL
+  const int k1 = x.k1;
   double av[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, aq[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  int my_blk = ent0.x, my_row = ent0.y;
-  for (int kb = k0;;) {
+  int my_blk = x.blk, my_row = x.row;
+  for (int kb = x.k0;;) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       double2 pv[4][3];
@@ -255,7 +266,7 @@ k_amg_restrict(AmgTransfer t, const double *__restrict__ v, double *__restrict__
   if (c < t.nc) {
     double d[6], s, unused;
     load_dinv_row(t.Dinv_c + 36 * (int64_t)c, r, d);
-    restrict_column<false>(t, c, v, nullptr, lane, s, unused);
+    restrict_finish<false>(t, restrict_issue(t, c, lane), v, nullptr, lane, s, unused);
     double y;
     const double dd = coarse_jacobi(d, s, lane, r, &y);
     if (lane < 6) {
@@ -284,9 +295,9 @@ k_amg_update1_restrict(BsrCgArgs a, AmgTransfer t, int parity, int nblk_spmv, in
   FoldLoads f;
   fold_issue(a, nblk_spmv, 0, f);
   if ((int)blockIdx.x < nbv) {
+    if (done != 0.0) return;  // waits for the flag alone: the loads above stay in flight
     VecLoads v;
     vec_issue(a, rin, blockIdx.x, nbv, v);
-    if (done != 0.0) return;
     pcg_mark(a.trace, 1, 1, blockIdx.x);
     const double alpha = cg2_alpha(a, rz, nblk_spmv, f, sh);
     pcg_mark(a.trace, 1, 2, blockIdx.x);
@@ -296,11 +307,13 @@ k_amg_update1_restrict(BsrCgArgs a, AmgTransfer t, int parity, int nblk_spmv, in
   const int cb = blockIdx.x - nbv;
   const int c = cb * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, r = lane & 7;
   double d[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, sv = 0.0, sq = 0.0;
+  RestrictIdx ri{-1, 0, 0, 0};
   if (c < t.nc) {
     load_dinv_row(t.Dinv_c + 36 * (int64_t)c, r, d);
-    restrict_column<true>(t, c, rin, a.q, lane, sv, sq);
+    ri = restrict_issue(t, c, lane);
   }
-  if (done != 0.0) return;
+  if (done != 0.0) return;  // an iteration after convergence costs one trip, not the whole kernel
+  if (c < t.nc) restrict_finish<true>(t, ri, rin, a.q, lane, sv, sq);
   pcg_mark(a.trace, 1, 1, blockIdx.x);
   const double alpha = cg2_alpha(a, rz, nblk_spmv, f, sh);
   pcg_mark(a.trace, 1, 2, blockIdx.x);
@@ -322,11 +335,22 @@ k_amg_update1_restrict(BsrCgArgs a, AmgTransfer t, int parity, int nblk_spmv, in
 }
 
 // (P yc)[i][r] for the 8 lanes of a group (r = lane & 7 < 6): the column indices of the row's first AMG_P_ELL blocks
-// come from the padded list (no pointer needed), so they travel together with the row pointer; the value loads follow
-__device__ __forceinline__ double prolong_row(const AmgTransfer &t, int i, int lane) {
+// come from the padded list (no pointer needed), so they travel together with the row pointer (prolong_issue); the
+// value loads follow (prolong_finish)
+struct ProlongIdx {
+  int col, k0, k1;
+};
+__device__ __forceinline__ ProlongIdx prolong_issue(const AmgTransfer &t, int i, int lane) {
+  ProlongIdx x;
+  x.col = t.P_col_ell[(int64_t)i * AMG_P_ELL + (lane & 7)];
+  x.k0 = t.P_rowptr[i];
+  x.k1 = t.P_rowptr[i + 1];
+  return x;
+}
+__device__ __forceinline__ double prolong_finish(const AmgTransfer &t, ProlongIdx x, int lane) {
   const int r = lane & 7, rr = r < 6 ? r : 0, base = lane & ~7;
-  int my_col = t.P_col_ell[(int64_t)i * AMG_P_ELL + r];
-  const int k0 = t.P_rowptr[i], k1 = t.P_rowptr[i + 1];
+  int my_col = x.col;
+  const int k0 = x.k0, k1 = x.k1;
   double s = 0.0;
   for (int kb = k0;;) {
     double2 pv[8][3], yv[8][3];
@@ -347,7 +371,7 @@ __device__ __forceinline__ double prolong_row(const AmgTransfer &t, int i, int l
 #pragma unroll
       for (int m = 0; m < 3; ++m) s += pv[u][m].x * yv[u][m].x + pv[u][m].y * yv[u][m].y;
     kb += 8;
-    if (kb >= k1) break;  // not uniform over the wave: the shuffles below only read lanes of the own group
+    if (kb >= k1) break;  // not uniform over the wave: the shuffles only read lanes of the own group
     const int n = min(8, k1 - kb);
     my_col = r < n ? t.P_col[kb + r] : -1;
   }
@@ -361,7 +385,7 @@ k_amg_prolong(AmgTransfer t, double *__restrict__ yf, double tau, unsigned long 
   const int i = blockIdx.x * 32 + (threadIdx.x >> 3), r = threadIdx.x & 7, lane = threadIdx.x & 63;
   const bool on = i < t.nb;
   const double y0 = (on && r < 6) ? yf[6 * (int64_t)i + r] : 0.0;
-  const double s = prolong_row(t, on ? i : 0, lane);
+  const double s = prolong_finish(t, prolong_issue(t, on ? i : 0, lane), lane);
   pcg_mark(trace, 3, 1, blockIdx.x);
   if (on && r < 6) yf[6 * (int64_t)i + r] = y0 + tau * s;
   pcg_mark(trace, 3, 2, blockIdx.x);
@@ -396,6 +420,12 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restr
   for (int k = 0; k < AMG_DEFL_NC; ++k) gi[k] = (defl && mine && k < cg.ncam) ? cg.G[(6 * (int64_t)i + r) * cg.ncam + k] : 0.0;
   const double lsv = (defl && (int)threadIdx.x < cg.ncam * cg.ncam) ? cg.Lcc[threadIdx.x] : 0.0;
   const double rcv = (defl && (int)threadIdx.x < cg.ncam) ? ((mode == 1 && !parity) ? cg.r2 : cg.r)[o + threadIdx.x] : 0.0;
+  ProlongIdx pi{-1, 0, 0};
+  if (has_coarse) pi = prolong_issue(t, on ? i : 0, threadIdx.x & 63);
+  if (done != 0.0) {  // waits for the flag alone; an iteration after convergence costs one trip
+    if (blockIdx.x == 0 && threadIdx.x == 0) cg.scal[8 + (parity ^ 1)] = done;  // keep both slots set
+    return;
+  }
   double g = 0.0;
   if (defl) {
     // G^T r_s: 16 lanes per sum, the partials dealt round-robin; then across the wave and the waves
@@ -406,11 +436,7 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restr
   double s = 0.0;
   for (int k = threadIdx.x; k < n_part_rz; k += blockDim.x) s += cg.part_rz[k];
   for (int k = threadIdx.x; k < n_part; k += blockDim.x) s += (k < np0 ? sigma : sigma * tau) * part[k];
-  const double corr = has_coarse ? prolong_row(t, on ? i : 0, threadIdx.x & 63) : 0.0;
-  if (done != 0.0) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) cg.scal[8 + (parity ^ 1)] = done;  // keep both slots set
-    return;
-  }
+  const double corr = has_coarse ? prolong_finish(t, pi, threadIdx.x & 63) : 0.0;
   pcg_mark(cg.trace, 4, 1, blockIdx.x);
   // ---- scalars
   if (defl) {

@@ -130,6 +130,8 @@ struct ba_problem {
   std::vector<int> ub_lo_h, ub_hi_h, bsr_rowptr_h, bsr_col_h;  // host copies of the block structure
   std::vector<int> cam_used_h;
   hipGraphExec_t cg_graph = nullptr;  // one batch of PCG iterations, captured once
+  hipGraphExec_t cg_graph_tail = nullptr;  // a short batch for the end of a solve
+  int last_pcg_iters = 0;                  // iterations the previous solve of this problem took (0: none yet)
   bool cg_graph_failed = false;
   int cg_graph_precond = -1;          // preconditioner the captured batch was recorded with
   ba::Amg *amg = nullptr;             // multilevel preconditioner (built at the first PCG solve)
@@ -918,43 +920,59 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
   };
   if (use_amg) launch_amg_cg_init(s, a, p->amg, opt->pcg_rtol);
   else launch_cg2_init(s, a, opt->pcg_rtol);
-  const int batch = 32;  // even, so that the parity pattern of a batch repeats
+  // Batches of iterations between two looks at the stopping flag (both sizes even, so that the parity pattern of a
+  // batch repeats).  An iteration that runs after convergence still costs its launches and one load each, so the long
+  // batch is only used while the previous solve of this problem says that it will be used up; the rest goes in short
+  // batches (successive solves of one adjustment need almost the same number of iterations).
+  const int batch = 32, tail = 8;
   if (p->cg_graph && p->cg_graph_precond != precond) {
     hipGraphExecDestroy(p->cg_graph);
-    p->cg_graph = nullptr;
+    if (p->cg_graph_tail) hipGraphExecDestroy(p->cg_graph_tail);
+    p->cg_graph = p->cg_graph_tail = nullptr;
   }
   if (!p->cg_graph && !p->cg_graph_failed) {
     p->cg_graph_precond = precond;
     // the launch sequence of a batch never changes for this problem: capture it into a graph once
-    hipGraph_t graph = nullptr;
-    bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
-    if (ok) {
-      for (int k = 0; k < batch; ++k) iteration(k & 1);
-      ok = hipStreamEndCapture(s, &graph) == hipSuccess && graph != nullptr;
-    }
-    if (ok) ok = hipGraphInstantiate(&p->cg_graph, graph, nullptr, nullptr, 0) == hipSuccess;
-    if (graph) hipGraphDestroy(graph);
-    if (!ok) {
-      p->cg_graph = nullptr;
+    auto capture = [&](int n, hipGraphExec_t *exec) {
+      hipGraph_t graph = nullptr;
+      bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      if (ok) {
+        for (int k = 0; k < n; ++k) iteration(k & 1);
+        ok = hipStreamEndCapture(s, &graph) == hipSuccess && graph != nullptr;
+      }
+      if (ok) ok = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (graph) hipGraphDestroy(graph);
+      if (!ok) *exec = nullptr;
+      return ok;
+    };
+    if (!capture(batch, &p->cg_graph) || !capture(tail, &p->cg_graph_tail)) {
+      if (p->cg_graph) hipGraphExecDestroy(p->cg_graph);
+      if (p->cg_graph_tail) hipGraphExecDestroy(p->cg_graph_tail);
+      p->cg_graph = p->cg_graph_tail = nullptr;
       p->cg_graph_failed = true;
       (void)hipGetLastError();
     }
   }
   int it = 0;
   double done = 0.0;
+  const int expect = p->last_pcg_iters;
   for (;;) {
     HIP_OK(hipMemcpyAsync(p->h_cgscal, p->d_cg2scal, 10 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     it = (int)p->h_cgscal[3];
     done = std::max(p->h_cgscal[8], p->h_cgscal[9]);
     if (done != 0.0 || it >= opt->pcg_max_iters) break;
-    const int n = std::min(batch, opt->pcg_max_iters - it);
+    const bool long_batch = expect <= 0 || it + batch <= expect - tail / 2;
+    const int n = std::min(long_batch ? batch : tail, opt->pcg_max_iters - it);
     if (p->cg_graph && n == batch && (it & 1) == 0) {
       HIP_OK(hipGraphLaunch(p->cg_graph, s));
+    } else if (p->cg_graph_tail && n == tail && (it & 1) == 0) {
+      HIP_OK(hipGraphLaunch(p->cg_graph_tail, s));
     } else {
       for (int k = 0; k < n; ++k) iteration((it + k) & 1);
     }
   }
+  p->last_pcg_iters = it;
   *iters = it;
   BA_TRY(p->check_kernels());
   if (done == 2.0) return fail(BA_ERR_NUMERIC, "PCG breakdown at iteration %d (p.Sp = %g)", it, p->h_cgscal[4]);
@@ -1196,6 +1214,7 @@ void ba_destroy(ba_problem *p) {
   if (p->stream2) hipStreamSynchronize(p->stream2);
   if (p->comm) ncclCommDestroy(p->comm);
   if (p->cg_graph) hipGraphExecDestroy(p->cg_graph);
+  if (p->cg_graph_tail) hipGraphExecDestroy(p->cg_graph_tail);
   if (p->amg) ba::amg_destroy(p->amg);
   for (void *q : p->allocs) hipFree(q);
   if (p->h_scal) hipHostFree(p->h_scal);
@@ -2009,7 +2028,8 @@ static int sync_shards(ba_problem *p) {
   BA_TRY(p->dalloc(&p->d_bsr_val, 36 * (size_t)p->n_bsr));
   if (p->cg_graph) {
     hipGraphExecDestroy(p->cg_graph);
-    p->cg_graph = nullptr;
+    if (p->cg_graph_tail) hipGraphExecDestroy(p->cg_graph_tail);
+    p->cg_graph = p->cg_graph_tail = nullptr;
   }
   if (p->amg) {  // built on the old pattern
     amg_destroy(p->amg);

@@ -484,8 +484,8 @@ k_cg2_update1(BsrCgArgs a, int parity, int nblk_spmv) {
   FoldLoads f;
   VecLoads v;
   fold_issue(a, nblk_spmv, 0, f);
-  vec_issue(a, a.r, blockIdx.x, gridDim.x, v);
   if (done != 0.0) return;
+  vec_issue(a, a.r, blockIdx.x, gridDim.x, v);
   const double alpha = cg2_alpha(a, rz, nblk_spmv, f, sh);
   vec_finish(a, alpha, a.r, blockIdx.x, gridDim.x, v, sh);
 }
