@@ -118,7 +118,9 @@ struct ba_problem {
   // device: reduced system
   double *d_g = nullptr, *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_p = nullptr, *d_q = nullptr;
   double *d_Minv = nullptr, *d_Ssc = nullptr, *d_Scc = nullptr, *d_Lcc = nullptr, *d_Sccinv = nullptr, *d_cgscal = nullptr, *h_cgscal = nullptr;
-  double *d_Sdense = nullptr;
+  double *d_Sdense = nullptr, *d_cholW = nullptr;  // dense reduced matrix (leading dimension dense_ld), inverted diagonal blocks
+  int dense_ld = 0;
+  bool dense_blocked = false;  // order >= chol_blocked_min_order(): the blocked factorisation on the matrix cores
   // explicit block-sparse reduced system (null / 0 when the network is too dense for it)
   bool explicit_ok = false;
   int n_ublk = 0, n_bsr = 0;
@@ -1025,24 +1027,42 @@ int build_dense(ba_problem *p, bool explicit_blocks) {
   hipStream_t s = p->stream;
   const size_t nr = (size_t)p->nr;
   if (!p->d_Sdense) {
-    if ((double)nr * nr * 8.0 > 64e9) return fail(BA_ERR_INVALID, "dense reduced system of order %zu does not fit; use the PCG solver", nr);
-    BA_TRY(p->dalloc(&p->d_Sdense, nr * nr));
+    p->dense_blocked = p->nr >= chol_blocked_min_order();
+    p->dense_ld = p->dense_blocked ? chol_blocked_ld(p->nr) : p->nr;
+    const size_t ld = (size_t)p->dense_ld;
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    if ((double)nr * ld * 8.0 > 0.9 * (double)free_b)
+      return fail(BA_ERR_INVALID, "dense reduced system of order %zu (%.1f GB) does not fit the device memory that is free (%.1f GB); use the PCG solver",
+                  nr, (double)nr * ld * 8e-9, (double)free_b * 1e-9);
+    BA_TRY(p->dalloc(&p->d_Sdense, nr * ld));
+    if (p->dense_blocked) BA_TRY(p->dalloc(&p->d_cholW, chol_blocked_workspace(p->nr)));
   }
+  const size_t ld = (size_t)p->dense_ld;
   if (explicit_blocks) {
-    HIP_OK(hipMemsetAsync(p->d_Sdense, 0, nr * nr * sizeof(double), s));
-    launch_bsr_to_dense(s, p->S, p->ncam, p->d_bsr_rowptr, p->d_bsr_col, p->d_bsr_val, p->d_Ssc, p->d_Scc, p->d_Sdense);
+    HIP_OK(hipMemsetAsync(p->d_Sdense, 0, nr * ld * sizeof(double), s));
+    launch_bsr_to_dense(s, p->S, p->ncam, p->d_bsr_rowptr, p->d_bsr_col, p->d_bsr_val, p->d_Ssc, p->d_Scc, p->d_Sdense, p->dense_ld);
   } else {
-    for (size_t k = 0; k < nr; ++k) BA_TRY(probe_column(p, (int64_t)k, p->d_Sdense + k * nr));
+    if (ld != nr) HIP_OK(hipMemsetAsync(p->d_Sdense, 0, nr * ld * sizeof(double), s));  // zeros in the padding
+    for (size_t k = 0; k < nr; ++k) BA_TRY(probe_column(p, (int64_t)k, p->d_Sdense + k * ld));
   }
+  return 0;
+}
+
+// Cholesky of the dense reduced matrix in place; info != 0: not positive definite
+int factor_dense(ba_problem *p) {
+  if (p->dense_blocked) launch_cholesky_blocked(p->stream, p->d_Sdense, p->nr, p->dense_ld, p->d_cholW, p->d_info);
+  else launch_cholesky(p->stream, p->d_Sdense, p->nr, p->d_info);
   return 0;
 }
 
 int solve_dense(ba_problem *p, bool explicit_blocks) {
   hipStream_t s = p->stream;
   BA_TRY(build_dense(p, explicit_blocks));
-  launch_cholesky(s, p->d_Sdense, p->nr, p->d_info);
+  BA_TRY(factor_dense(p));
   launch_copy(s, p->nr, p->d_b, p->d_x);
-  launch_chol_solve(s, p->d_Sdense, p->nr, p->d_x);
+  if (p->dense_blocked) launch_chol_solve_blocked(s, p->d_Sdense, p->nr, p->dense_ld, p->d_cholW, p->d_x);
+  else launch_chol_solve(s, p->d_Sdense, p->nr, p->d_x);
   int info = 0;
   HIP_OK(hipMemcpyAsync(&info, p->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
@@ -1604,7 +1624,17 @@ int ba_covariance(ba_problem *p, double *var_eop, double *var_xyz, double *var_i
   if (!p) return fail(BA_ERR_INVALID, "ba_covariance: null problem");
   if (!p->have_params) return fail(BA_ERR_INVALID, "ba_covariance: no parameters set");
   const int n = p->nr;
-  if (n > 8192) return fail(BA_ERR_UNSUPPORTED, "ba_covariance: reduced system of order %d (limit 8192: dense inverse)", n);
+  // the dense reduced matrix, a work matrix of the same size for the inverse, and the per-point work array must fit
+  {
+    const double ld = n >= chol_blocked_min_order() ? chol_blocked_ld(n) : n;
+    const double need = 2.0 * n * ld * 8.0 + (double)p->P * p->ncam * 24.0 + 1e9;
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    const double have = (double)free_b + (p->d_Sdense ? (double)n * ld * 8.0 : 0.0);
+    if (need > have)
+      return fail(BA_ERR_UNSUPPORTED, "ba_covariance: reduced system of order %d: the dense inverse needs %.1f GB, %.1f GB are free "
+                  "(ba_covariance_cameras gives the camera parameters at any size)", n, need * 1e-9, have * 1e-9);
+  }
   hipStream_t s = p->stream;
   ba_options opt;
   ba_default_options(&opt);
@@ -1616,32 +1646,41 @@ int ba_covariance(ba_problem *p, double *var_eop, double *var_xyz, double *var_i
   std::vector<double> cs((size_t)std::max(n, 1), 0.0), vx(3 * (size_t)std::max(p->P, 1), 0.0);
   if (n > 0) {
     BA_TRY(build_dense(p, use_explicit));
-    launch_dense_fix_unused(s, p->S, n, p->d_sta_used, p->d_Sdense);
-    launch_cholesky(s, p->d_Sdense, n, p->d_info);
+    launch_dense_fix_unused(s, p->S, p->dense_ld, p->d_sta_used, p->d_Sdense);
+    BA_TRY(factor_dense(p));
     int info = 0;
     HIP_OK(hipMemcpyAsync(&info, p->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     if (info) return fail(BA_ERR_NUMERIC, "ba_covariance: the reduced normal matrix is rank deficient (column %d of %d)", info - 1, n);
   }
-  double *d_inv = nullptr, *d_tc = nullptr, *d_vx = nullptr, *d_cs = nullptr;
+  double *d_inv = nullptr, *d_tc = nullptr, *d_vx = nullptr, *d_cs = nullptr, *d_T = nullptr;
   auto cleanup = [&]() {
     if (d_inv) (void)hipFree(d_inv);
     if (d_tc) (void)hipFree(d_tc);
     if (d_vx) (void)hipFree(d_vx);
     if (d_cs) (void)hipFree(d_cs);
+    if (d_T) (void)hipFree(d_T);
   };
-  const size_t nn = (size_t)std::max(n, 1);
-  if (hipMalloc((void **)&d_inv, nn * nn * sizeof(double)) != hipSuccess ||
+  const size_t nn = (size_t)std::max(n, 1), ld = (size_t)std::max(p->dense_ld, 1);
+  if (hipMalloc((void **)&d_inv, nn * ld * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&d_tc, std::max<size_t>((size_t)p->P * p->ncam * 3, 1) * sizeof(double)) != hipSuccess ||
-      hipMalloc((void **)&d_vx, vx.size() * sizeof(double)) != hipSuccess || hipMalloc((void **)&d_cs, nn * sizeof(double)) != hipSuccess) {
+      hipMalloc((void **)&d_vx, vx.size() * sizeof(double)) != hipSuccess || hipMalloc((void **)&d_cs, nn * sizeof(double)) != hipSuccess ||
+      (p->dense_blocked && hipMalloc((void **)&d_T, 128 * ld * sizeof(double)) != hipSuccess)) {
     cleanup();
     return fail(BA_ERR_DEVICE, "ba_covariance: out of device memory");
   }
-  launch_chol_inverse(s, p->d_Sdense, n, d_inv);
+  const double *d_Sinv = d_inv;
+  if (n > 0 && p->dense_blocked) {
+    // the inverse replaces the factor in place; d_inv is the work matrix U = L^-T
+    launch_chol_inverse_blocked(s, p->d_Sdense, n, p->dense_ld, p->d_cholW, d_inv, d_T);
+    d_Sinv = p->d_Sdense;
+  } else {
+    launch_chol_inverse(s, p->d_Sdense, n, d_inv);
+  }
   CovArgs ca{};
-  ca.P = p->P; ca.S = p->S; ca.n = n; ca.ncmax = p->ncmax;
+  ca.P = p->P; ca.S = p->S; ca.n = n; ca.ncmax = p->ncmax; ca.ld = p->dense_ld;
   ca.pt_start = p->d_pt_start; ca.obs_sta = p->d_obs_sta; ca.sta_cam = p->d_sta_cam; ca.sta_used = p->d_sta_used; ca.pt_file = p->d_pt_file;
-  ca.rec = p->d_rec; ca.Jp = p->d_Jp; ca.Jc = p->d_Jc; ca.Vinv = p->d_Vinv; ca.Sinv = d_inv;
+  ca.rec = p->d_rec; ca.Jp = p->d_Jp; ca.Jc = p->d_Jc; ca.Vinv = p->d_Vinv; ca.Sinv = d_Sinv;
   ca.scale_pt = p->d_scale_pt; ca.scale_sta = p->d_scale_sta; ca.scale_cam = p->d_scale_cam; ca.cam = p->d_cam;
   ca.Tc = d_tc; ca.var_xyz = d_vx; ca.var_cs = d_cs;
   launch_cov(s, ca);
@@ -1826,6 +1865,33 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
       default: break;
     }
   };
+  if (which == 10 || which == 11) {
+    // 10: Cholesky factorisation of the dense reduced matrix alone; 11: factorisation and the two triangular solves.
+    // The factorisation is in place, so the matrix is rebuilt (untimed) before every repeat.
+    double total_ms = 0.0;
+    hipEvent_t f0, f1;
+    HIP_OK(hipEventCreate(&f0));
+    HIP_OK(hipEventCreate(&f1));
+    for (int k = 0; k < repeats + 1; ++k) {
+      BA_TRY(build_dense(p, p->explicit_ok));
+      HIP_OK(hipEventRecord(f0, s));
+      BA_TRY(factor_dense(p));
+      if (which == 11) {
+        launch_copy(s, p->nr, p->d_b, p->d_x);
+        if (p->dense_blocked) launch_chol_solve_blocked(s, p->d_Sdense, p->nr, p->dense_ld, p->d_cholW, p->d_x);
+        else launch_chol_solve(s, p->d_Sdense, p->nr, p->d_x);
+      }
+      HIP_OK(hipEventRecord(f1, s));
+      HIP_OK(hipEventSynchronize(f1));
+      float ms = 0.f;
+      HIP_OK(hipEventElapsedTime(&ms, f0, f1));
+      if (k > 0) total_ms += ms;  // the first pass warms up
+    }
+    hipEventDestroy(f0);
+    hipEventDestroy(f1);
+    *seconds_per_launch = 1e-3 * total_ms / repeats;
+    return p->check_kernels();
+  }
   if (which == 9) {
     // one PCG iteration with time stamps at the phase marks of its kernels, table on stderr
     if (!p->explicit_ok || !with_amg) return fail(BA_ERR_INVALID, "ba_time_kernel: the traced iteration needs the multilevel PCG (solve once first)");

@@ -157,7 +157,7 @@ enum { PCG_TRACE_KERNELS = 5, PCG_TRACE_MAXWG = 2048, PCG_TRACE_SLOTS = 8 };
 void launch_schur_blocks(hipStream_t s, int nu, const int *cstart, const int2 *dst, const int2 *pairs, const double *Y, double *val);
 void launch_bsr_add_diag(hipStream_t s, int S, const int *rowptr, const double *Sdiag, double *val);
 void launch_bsr_to_dense(hipStream_t s, int S, int ncam, const int *rowptr, const int *col, const double *val, const double *Ssc,
-                         const double *Scc, double *A);
+                         const double *Scc, double *A, int ld);
 void launch_store_border_col(hipStream_t s, int S, int ncam, int k, const double *v, double *Ssc, double *Scc);
 int border_ncb();   // largest number of free camera parameters the explicit border kernels handle
 int border_nacc();  // partial sums per chunk of the border station sweep
@@ -211,12 +211,23 @@ void launch_amg_cg_iteration(hipStream_t s, const BsrCgArgs &cg, const Amg *a, i
 // solve L L^T x = b (b overwritten).  info[0] != 0 after the factorisation when a pivot was
 // not positive.
 void launch_cholesky(hipStream_t s, double *A, int n, int *info);
+// ba_chol_blocked.hip: the same for matrices of order >= chol_blocked_min_order(), row-major with the even leading
+// dimension chol_blocked_ld(n) and zeros in the padding; W (chol_blocked_workspace(n) doubles) receives the inverted
+// diagonal blocks, which the solves and the inverse use
+int chol_blocked_min_order();
+int chol_blocked_ld(int n);
+size_t chol_blocked_workspace(int n);
+void launch_cholesky_blocked(hipStream_t s, double *A, int n, int ld, double *W, int *info);
+void launch_chol_solve_blocked(hipStream_t s, const double *L, int n, int ld, const double *W, double *b);
+// A: the factor on entry, (L L^T)^-1 as a full symmetric matrix on return; U: n x ld work matrix, T: 128 x ld
+void launch_chol_inverse_blocked(hipStream_t s, double *A, int n, int ld, const double *W, double *U, double *T);
 void launch_chol_solve(hipStream_t s, const double *L, int n, double *b);
 void launch_chol_inverse(hipStream_t s, const double *L, int n, double *B);  // B = (L L^T)^-1, n x n
 
 // covariance of the parameters from the inverse of the dense reduced matrix
 struct CovArgs {
   int P, S, n, ncmax;
+  int ld;  // leading dimension of Sinv
   const int *pt_start, *obs_sta, *sta_cam, *sta_used, *pt_file;
   const double *rec, *Jp, *Jc, *Vinv, *Sinv, *scale_pt, *scale_sta, *scale_cam;
   const CamRec *cam;
@@ -225,6 +236,6 @@ struct CovArgs {
   double *var_cs;   // [n]: stations then camera columns
 };
 void launch_cov(hipStream_t s, const CovArgs &a);
-void launch_dense_fix_unused(hipStream_t s, int S, int n, const int *sta_used, double *A);
+void launch_dense_fix_unused(hipStream_t s, int S, int ld, const int *sta_used, double *A);
 
 }  // namespace ba

@@ -1255,7 +1255,7 @@ k_resjac_dense(CostArgs a, double *__restrict__ r_out, double *__restrict__ J_ou
 __global__ void k_cov_camside(CovArgs a) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= a.n) return;
-  const double v = a.Sinv[(int64_t)t * a.n + t];
+  const double v = a.Sinv[(int64_t)t * a.ld + t];
   const int ns = 6 * a.S;
   double sc;
   if (t < ns) sc = a.sta_used[t / 6] ? a.scale_sta[t] : 0.0;
@@ -1295,7 +1295,7 @@ k_cov_points(CovArgs a) {
       station_part(eb, Tb, Qb);
       const int ib = a.obs_sta[eb];
       for (int r = 0; r < 6; ++r) {
-        const double *row = a.Sinv + (int64_t)(6 * ia + r) * a.n + 6 * ib;
+        const double *row = a.Sinv + (int64_t)(6 * ia + r) * a.ld + 6 * ib;
         double u[3] = {0, 0, 0};  // row r of Sinv[ia, ib] times T_b
         for (int q = 0; q < 6; ++q)
           for (int m = 0; m < 3; ++m) u[m] += row[q] * Tb[q][m];
@@ -1310,7 +1310,7 @@ k_cov_points(CovArgs a) {
     station_part(ea, Ta, Qa);
     const int ia = a.obs_sta[ea];
     for (int r = 0; r < 6; ++r) {
-      const double *row = a.Sinv + (int64_t)(6 * ia + r) * a.n + ns;
+      const double *row = a.Sinv + (int64_t)(6 * ia + r) * a.ld + ns;
       double u[3] = {0, 0, 0};
       for (int k = 0; k < ncam; ++k)
         for (int m = 0; m < 3; ++m) u[m] += row[k] * Tc[3 * k + m];
@@ -1319,7 +1319,7 @@ k_cov_points(CovArgs a) {
     }
   }
   for (int k = 0; k < ncam; ++k) {
-    const double *row = a.Sinv + (int64_t)(ns + k) * a.n + ns;
+    const double *row = a.Sinv + (int64_t)(ns + k) * a.ld + ns;
     double u[3] = {0, 0, 0};
     for (int q = 0; q < ncam; ++q)
       for (int m = 0; m < 3; ++m) u[m] += row[q] * Tc[3 * q + m];
@@ -1334,9 +1334,9 @@ k_cov_points(CovArgs a) {
 }
 
 // stations without observations are not part of the program: unit diagonal keeps the factorisation defined
-__global__ void k_dense_fix_unused(int S, int n, const int *__restrict__ sta_used, double *__restrict__ A) {
+__global__ void k_dense_fix_unused(int S, int ld, const int *__restrict__ sta_used, double *__restrict__ A) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < 6 * S && !sta_used[t / 6]) A[(int64_t)t * n + t] = 1.0;
+  if (t < 6 * S && !sta_used[t / 6]) A[(int64_t)t * ld + t] = 1.0;
 }
 
 static inline int nblk(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
@@ -1348,8 +1348,8 @@ void launch_cov(hipStream_t s, const CovArgs &a) {
   if (a.n > 0) hipLaunchKernelGGL(k_cov_camside, dim3(nblk(a.n, 256)), dim3(256), 0, s, a);
   if (a.P > 0) hipLaunchKernelGGL(k_cov_points, dim3(nblk(a.P, 64)), dim3(64), 0, s, a);
 }
-void launch_dense_fix_unused(hipStream_t s, int S, int n, const int *sta_used, double *A) {
-  if (S > 0) hipLaunchKernelGGL(k_dense_fix_unused, dim3(nblk(6 * (int64_t)S, 256)), dim3(256), 0, s, S, n, sta_used, A);
+void launch_dense_fix_unused(hipStream_t s, int S, int ld, const int *sta_used, double *A) {
+  if (S > 0) hipLaunchKernelGGL(k_dense_fix_unused, dim3(nblk(6 * (int64_t)S, 256)), dim3(256), 0, s, S, ld, sta_used, A);
 }
 int linearize_blocks(int P) { return nblk(P, 256); }
 int obs_rows_blocks(int64_t N) {

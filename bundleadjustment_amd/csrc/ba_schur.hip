@@ -93,12 +93,12 @@ __global__ void k_bsr_add_diag(int S, const int *__restrict__ rowptr, const doub
   val[36 * (int64_t)rowptr[i] + k] += Sdiag[t];
 }
 
-// dense copy of the explicit system for the Cholesky path: A is nr x nr, row-major
+// dense copy of the explicit system for the Cholesky path: A is nr x nr, row-major with leading dimension ld
 __global__ void k_bsr_to_dense(int S, int ncam, const int *__restrict__ rowptr, const int *__restrict__ col,
                                const double *__restrict__ val, const double *__restrict__ Ssc, const double *__restrict__ Scc,
-                               double *__restrict__ A) {
+                               double *__restrict__ A, int ld) {
   const int i = blockIdx.x;
-  const int64_t nr = 6 * (int64_t)S + ncam;
+  const int64_t nr = ld;
   if (i < S) {
     for (int b = rowptr[i]; b < rowptr[i + 1]; ++b) {
       const int j = col[b];
@@ -634,8 +634,8 @@ void launch_bsr_add_diag(hipStream_t s, int S, const int *rowptr, const double *
   if (S > 0) hipLaunchKernelGGL(k_bsr_add_diag, dim3(nblk(36 * (int64_t)S, 256)), dim3(256), 0, s, S, rowptr, Sdiag, val);
 }
 void launch_bsr_to_dense(hipStream_t s, int S, int ncam, const int *rowptr, const int *col, const double *val, const double *Ssc,
-                         const double *Scc, double *A) {
-  hipLaunchKernelGGL(k_bsr_to_dense, dim3(S + 1), dim3(64), 0, s, S, ncam, rowptr, col, val, Ssc, Scc, A);
+                         const double *Scc, double *A, int ld) {
+  hipLaunchKernelGGL(k_bsr_to_dense, dim3(S + 1), dim3(64), 0, s, S, ncam, rowptr, col, val, Ssc, Scc, A, ld);
 }
 void launch_store_border_col(hipStream_t s, int S, int ncam, int k, const double *v, double *Ssc, double *Scc) {
   hipLaunchKernelGGL(k_store_border_col, dim3(nblk(6 * (int64_t)S + ncam, 256)), dim3(256), 0, s, S, ncam, k, v, Ssc, Scc);

@@ -303,6 +303,9 @@ int ba_residual_jacobian(ba_problem *p, double *r, double *J);
  *   6  the block-sparse matrix-vector product of that iteration alone
  *   7  per-point kernel of 0: first evaluation, V, its gradient, the camera coupling, V^-1
  *   8  per-observation kernel of 0: second evaluation, all per-observation rows written once
+ *   9  one PCG iteration with time stamps at the phase marks of its kernels, printed to stderr (returns 0)
+ *  10  Cholesky factorisation of the dense reduced system (n^3 / 3 multiply-adds, n = 6 n_sta + free camera parameters)
+ *  11  the same with the two triangular solves
  * No counterpart in the reference (its timers are wall-clock prints, src/main.cpp:3027, 4703).
  */
 int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *seconds_per_launch);

@@ -225,23 +225,51 @@ def test_camera_variances_by_iterative_solves_equal_the_dense_inverse(which):
         assert np.all(np.abs(g[nz] - w[nz]) <= 1e-6 * w[nz]), np.max(np.abs(g[nz] - w[nz]) / w[nz])
 
 
-def test_camera_variances_of_a_network_too_large_for_the_dense_inverse():
+def test_variances_of_a_network_beyond_the_old_dense_limit():
+    # 8407 reduced unknowns: blocked Cholesky and inverse on the matrix cores.  The dense inverse and the iterative
+    # route (one PCG solve per camera column) must agree on the camera parameters.
     net = host.synth(n_cam=1, n_sta=1400, n_pts=6000, rays_per_point=4, seed=1, ap_free_mask=host.AP_K1K2P1P2).net
     with solver.Problem(net) as P:
         P.set_parameters()
         P.solve_resident(options(capi.SOLVER_PCG_SCHUR))
-        with pytest.raises(solver.BaError):
-            P.covariance()
+        ve, vx, di, da = P.covariance()
         vi, va = P.covariance_cameras()
     free = [2, 3, 5, 6]  # k1 k2 p1 p2
     assert np.all(vi > 0.0) and np.all(va[0, free] > 0.0)
     assert np.all(np.delete(va[0], free) == 0.0)
     # the posterior is tighter than the prior (sigma 10, 10, 1000 on xp, yp, c: src/main.cpp:4612-4623)
     assert np.all(np.sqrt(vi[0]) < np.array([10.0, 10.0, 1000.0]))
+    assert np.all(np.abs(di - vi) <= 1e-6 * vi) and np.all(np.abs(da[0, free] - va[0, free]) <= 1e-6 * va[0, free])
+    used = np.bincount(net.obs_sta, minlength=net.n_sta) > 0
+    assert np.all(ve[used] > 0.0) and np.all(ve[~used] == 0.0) and np.all(vx > 0.0)
+    # a point is known no worse than its prior says
+    assert np.all(vx <= net.pt_sigma ** 2 * (1 + 1e-9))
+
+
+@pytest.mark.parametrize("n_sta", [60, 130])
+def test_blocked_cholesky_solve_and_covariance_against_the_oracle(n_sta):
+    # reduced systems of order 367 and 787: the blocked factorisation (panels of 128, a ragged last panel), its
+    # triangular solves and its inverse, against the oracle's solve and its inverse of the full normal matrix
+    net = host.synth(n_cam=1, n_sta=n_sta, n_pts=400 if n_sta == 60 else 700, rays_per_point=6, seed=3, control_every=6).net
+    assert 6 * net.n_sta + 7 >= 256
+    opt = options(capi.SOLVER_DENSE_SCHUR)
+    with solver.Problem(net) as P:
+        g = P.solve(opt)
+        P.set_parameters(*g[:4])
+        got = P.covariance()
+    o = po.solve(net, opt, po.SCHUR_DENSE)
+    assert o[4]["termination"] == capi.CONVERGENCE
+    assert_solve_parity(g, o)
+    want = po.covariance(net, *g[:4])
+    for a, w, name in zip(got, want, ("eop", "xyz", "iop", "ap")):
+        assert np.array_equal(a == 0.0, w == 0.0), name
+        nz = w != 0.0
+        assert np.all(np.abs(a[nz] - w[nz]) <= 1e-7 * w[nz]), (name, np.max(np.abs(a[nz] - w[nz]) / w[nz]))
 
 
 def test_covariance_too_large_is_refused():
-    net = host.synth(n_cam=1, n_sta=1400, n_pts=3000, rays_per_point=3, seed=1).net
+    # 50 000 stations: the dense inverse would need 2 x 720 GB
+    net = host.synth(n_cam=1, n_sta=50000, n_pts=60000, rays_per_point=3, seed=1).net
     with solver.Problem(net) as P:
         P.set_parameters()
         with pytest.raises(solver.BaError) as e:
