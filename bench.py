@@ -198,9 +198,12 @@ def main():
         P.use_rccl(world, rank, ids[0])
     P.set_parameters()
 
+    free_cam = int(sum(bin(int(a)).count("1") + bin(int(b) & 7).count("1") for a, b in zip(full.ap_free_mask, full.iop_free_mask)))
+    dense = 6 * full.n_sta + free_cam <= capi.AUTO_DENSE_ORDER  # what BA_SOLVER_AUTO picks: the two small networks
+
     def options(iters):
         o = solver.default_options()
-        o.linear_solver = capi.SOLVER_PCG_SCHUR
+        o.linear_solver = capi.SOLVER_DENSE_SCHUR if dense else capi.SOLVER_PCG_SCHUR
         o.pcg_rtol = args.pcg_rtol
         o.pcg_max_iters = 20000
         o.max_num_iterations = iters
@@ -231,6 +234,28 @@ def main():
     steps_done = sm["num_iterations"] - 1
     if steps_done != args.steps:
         sys.exit(f"solver ran {steps_done} iterations instead of {args.steps}: {sm}")
+
+    if dense:
+        # the reduced system is factored on the matrix cores: report that kernel chain against the fp64 MFMA peak
+        n_red = 6 * full.n_sta + free_cam
+        t_fac, t_lin = P.time_kernel(10, 5), P.time_kernel(0, 10)
+        flops = n_red ** 3 / 3.0
+        out = {"metric": "LM iter/s", "value": args.steps / elapsed, "unit": "iter/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"{args.config}: {full.n_cam} camera(s), {full.n_sta} stations, {full.n_pts} points, {full.n_obs} "
+                                      f"observations, point elimination + dense Cholesky of order {n_red} on the matrix cores",
+                          "scale": args.scale, "sharding": f"points/{world}"},
+               "jacobian_obs_per_s": full.n_obs / t_lin, "final_cost": sm["final_cost"],
+               "roofline": {"bound": "mfma", "kernel": "dense Cholesky (k_chol_diag + k_gemm_nt<TRSM> + k_gemm_nt<SYRK>)",
+                            "achieved": flops / t_fac / 1e12, "peak": 78.6, "unit": "TFLOP/s", "frac": flops / t_fac / 78.6e12,
+                            "traffic": None, "ms": 1e3 * t_fac, "flops": flops}}
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        P.close()
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     # per-kernel timing with HIP events on the solver's stream (live, same process)
     which_all = (0, 7, 8, 4, 6, 5, 3)

@@ -86,6 +86,7 @@ struct GemmArgs {
   double *T;        // inverse: work row of tiles, CB x ld
   int n, ld, k0, kw;  // current panel: first column, width
   int ib;             // inverse: current block row
+  int part;           // trailing update: 0 all tiles, 1 the first block column only, 2 all but the first block column
 };
 
 // tile (ti, tj), tj <= ti, of a lower triangle from a linear index
@@ -122,7 +123,16 @@ k_gemm_nt(GemmArgs g) {
     cmax = g.kw;
   } else if (MODE == GEMM_SYRK) {
     int ti, tj;
-    tri_tile(blockIdx.x, ti, tj);
+    if (g.part == 1) {
+      ti = blockIdx.x;
+      tj = 0;
+    } else {
+      tri_tile(blockIdx.x, ti, tj);
+      if (g.part == 2) {
+        ++ti;
+        ++tj;
+      }
+    }
     const int t0 = g.k0 + g.kw;
     r0 = t0 + CB * ti;
     c0 = t0 + CB * tj;
@@ -200,9 +210,16 @@ __device__ __forceinline__ void chol8(const double *D, double (&L)[SB][SB], doub
     for (int k = 0; k < SB; ++k)
       if (k < j) d -= L[j][k] * L[j][k];
     if (!(d > 0.0) && bad < 0) bad = j;
-    const double l = sqrt(d);
-    il[j] = 1.0 / l;
-    L[j][j] = l;
+    // 1 / sqrt(d) from the hardware estimate and two Newton steps (nine dependent operations; the IEEE square root
+    // and division of the compiler are five times as long, and this chain of 128 pivots is the kernel's critical path)
+    double y = __builtin_amdgcn_rsq(d);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const double e = fma(-(d * y), y, 1.0);
+      y = fma(0.5 * y, e, y);
+    }
+    il[j] = y;
+    L[j][j] = d * y;
 #pragma unroll
     for (int i = 0; i < SB; ++i)
       if (i > j) {
@@ -226,9 +243,26 @@ k_chol_diag(double *__restrict__ A, int n, int ld, int k0, double *__restrict__ 
   double *invd = Cb + (CB - SB) * SB;  // CB: reciprocals of the diagonal of the factor
   const int kw = min(CB, n - k0);
   const int t = threadIdx.x;
-  for (int q = t; q < CB * CB; q += 256) {
-    const int r = q / CB, c = q - r * CB;
-    Tm[r * TS + c] = (r < kw && c <= r) ? A[(int64_t)(k0 + r) * ld + k0 + c] : (r == c ? 1.0 : 0.0);
+  {
+    // half a row per thread, eight 16-byte loads in flight at a time (a loop of single guarded loads would wait for
+    // every one of them in turn)
+    const int r = t >> 1, cb = 64 * (t & 1);
+    const double *src = A + (int64_t)(k0 + r) * ld + k0 + cb;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      double2 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = cb + 16 * b + 2 * i;
+        v[i] = (r < kw && c <= r) ? *reinterpret_cast<const double2 *>(src + 16 * b + 2 * i) : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = cb + 16 * b + 2 * i;
+        Tm[r * TS + c] = (r < kw && c <= r) ? v[i].x : (r == c ? 1.0 : 0.0);
+        Tm[r * TS + c + 1] = (r < kw && c + 1 <= r) ? v[i].y : (r == c + 1 ? 1.0 : 0.0);
+      }
+    }
   }
   __syncthreads();
   const int rp = t >> 2, q = t & 3;   // four threads per pair of rows
@@ -495,8 +529,23 @@ void launch_cholesky_blocked(hipStream_t s, double *A, int n, int ld, double *W,
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  // Look-ahead: the diagonal block of panel k + 1 (one workgroup, a chain of 128 pivots) only needs the first block
+  // column of the trailing update of panel k, so the rest of that update runs on a side stream beside it.
+  static thread_local hipStream_t side = nullptr;
+  static thread_local hipEvent_t ev_panel = nullptr, ev_rest = nullptr;
+  const int nb = (n + CB - 1) / CB;
+  bool ahead = nb >= 6;
+  if (ahead && !side) {
+    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_panel, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ev_rest, hipEventDisableTiming) != hipSuccess) {
+      side = nullptr;
+      (void)hipGetLastError();
+    }
+  }
+  if (!side) ahead = false;
   GemmArgs g{};
   g.A = A; g.n = n; g.ld = ld;
+  bool rest_pending = false;
   for (int k0 = 0, kb = 0; k0 < n; k0 += CB, ++kb) {
     const int kw = (n - k0 < CB) ? n - k0 : CB;
     double *Wk = W + (size_t)kb * CB * CB;
@@ -505,9 +554,27 @@ void launch_cholesky_blocked(hipStream_t s, double *A, int n, int ld, double *W,
     if (rem <= 0) break;
     g.W = Wk; g.k0 = k0; g.kw = kw;
     const int T = (rem + CB - 1) / CB;
+    g.part = 0;
     hipLaunchKernelGGL(k_gemm_nt<GEMM_TRSM>, dim3(T), dim3(256), 0, s, g);
-    hipLaunchKernelGGL(k_gemm_nt<GEMM_SYRK>, dim3(T * (T + 1) / 2), dim3(256), 0, s, g);
+    if (!ahead || T < 2) {
+      if (rest_pending) {
+        (void)hipStreamWaitEvent(s, ev_rest, 0);
+        rest_pending = false;
+      }
+      hipLaunchKernelGGL(k_gemm_nt<GEMM_SYRK>, dim3(T * (T + 1) / 2), dim3(256), 0, s, g);
+      continue;
+    }
+    (void)hipEventRecord(ev_panel, s);  // the panel is final: the side stream may read it
+    if (rest_pending) (void)hipStreamWaitEvent(s, ev_rest, 0);  // the first block column also takes the previous panel's update
+    g.part = 1;
+    hipLaunchKernelGGL(k_gemm_nt<GEMM_SYRK>, dim3(T), dim3(256), 0, s, g);
+    (void)hipStreamWaitEvent(side, ev_panel, 0);
+    g.part = 2;
+    hipLaunchKernelGGL(k_gemm_nt<GEMM_SYRK>, dim3((T - 1) * T / 2), dim3(256), 0, side, g);
+    (void)hipEventRecord(ev_rest, side);
+    rest_pending = true;
   }
+  if (rest_pending) (void)hipStreamWaitEvent(s, ev_rest, 0);
 }
 
 void launch_chol_solve_blocked(hipStream_t s, const double *L, int n, int ld, const double *W, double *b) {
