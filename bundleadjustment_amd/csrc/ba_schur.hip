@@ -41,8 +41,13 @@ __device__ __forceinline__ void load_half(const double *__restrict__ rec, int h,
 __global__ void __launch_bounds__(256)
 k_schur_blocks(int nu, const int *__restrict__ cstart, const int2 *__restrict__ dst, const int2 *__restrict__ pairs,
                const double *__restrict__ Y, double *__restrict__ val) {
-  const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (u >= nu) return;
+  // Workgroups are dealt round-robin over the eight XCDs, each with an L2 of its own.  The blocks are ordered by row,
+  // and the blocks of one row read the same station's records: give every XCD one contiguous eighth of the list, so
+  // that a record fetched for one block of a row is still in that L2 for the next.
+  const int nwg = gridDim.x, per = (nwg + 7) >> 3;
+  const int wg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int u = wg * 4 + (threadIdx.x >> 6);
+  if (wg >= nwg || u >= nu) return;
   const int lane = threadIdx.x & 63;
   const int g = lane >> 2, qa = (lane >> 1) & 1, qb = lane & 1;
   const int q0 = cstart[u], q1 = cstart[u + 1];
@@ -628,7 +633,7 @@ k_defl_corner(int ncam, int nparts, const double *__restrict__ part, const doubl
 static inline int nblk(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
 
 void launch_schur_blocks(hipStream_t s, int nu, const int *cstart, const int2 *dst, const int2 *pairs, const double *Y, double *val) {
-  if (nu > 0) hipLaunchKernelGGL(k_schur_blocks, dim3(nblk(nu, 4)), dim3(256), 0, s, nu, cstart, dst, pairs, Y, val);
+  if (nu > 0) hipLaunchKernelGGL(k_schur_blocks, dim3((nblk(nu, 4) + 7) / 8 * 8), dim3(256), 0, s, nu, cstart, dst, pairs, Y, val);
 }
 void launch_bsr_add_diag(hipStream_t s, int S, const int *rowptr, const double *Sdiag, double *val) {
   if (S > 0) hipLaunchKernelGGL(k_bsr_add_diag, dim3(nblk(36 * (int64_t)S, 256)), dim3(256), 0, s, S, rowptr, Sdiag, val);
