@@ -146,6 +146,9 @@ struct ba_problem {
   int *d_col_cam = nullptr, *d_col_pos = nullptr;
   // state
   bool have_params = false;
+  bool rows_lean = false;  // the last linearisation did not write the rows Jp and Jc (the back substitution works from Y)
+  double lin_radius = 1.0; // trust-region radius that linearisation carried
+  double *d_zero = nullptr, *d_ytSy = nullptr;
   // second stream: the numbers of the multilevel preconditioner are set up beside the camera border, both
   // only depend on the station blocks of the reduced matrix
   hipStream_t stream2 = nullptr;
@@ -550,6 +553,9 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   BA_TRY(p->dalloc(&p->d_partial, (size_t)p->n_partial));
   BA_TRY(p->dalloc(&p->d_scal, (size_t)SC_COUNT));
   BA_TRY(p->dalloc(&p->d_cgscal, 8));
+  BA_TRY(p->dalloc(&p->d_zero, 16));
+  BA_TRY(p->dalloc(&p->d_ytSy, 2));
+  HIP_OK(hipMemsetAsync(p->d_zero, 0, 16 * sizeof(double), p->stream));
   HIP_OK(hipHostMalloc((void **)&p->h_scal, SC_COUNT * sizeof(double)));
   HIP_OK(hipHostMalloc((void **)&p->h_cgscal, 16 * sizeof(double)));
   const size_t nr = (size_t)p->nr;
@@ -608,6 +614,7 @@ struct LmState {
   bool need_norms;  // column norms of the camera block are only needed when they are not clamped away
   int reduced = 0;  // what to build after the elimination: 0 nothing, 1 preconditioner + border (implicit operator),
                     // 2 explicit block-sparse system + border
+  bool full_rows = false;  // write the rows Jp and Jc even where the solve itself does not read them (covariance, timing)
 };
 
 StationArgs station_args(ba_problem *p, int voff, int stride) {
@@ -668,6 +675,11 @@ int linearize(ba_problem *p, const LmState &st) {
   la.Y = (st.reduced == 2) ? p->d_Y : nullptr;
   la.Jt = p->d_Jt;
   la.cam_partial = p->d_campart;
+  // With the explicit block-sparse system and the border from the projected camera rows, nothing after this kernel
+  // reads Jp or Jc: the back substitution and the model cost change work from Y and the elimination records.
+  la.lean = (st.reduced == 2 && !st.full_rows && !st.need_norms && (p->d_Jt != nullptr || p->ncam == 0) && p->ncam <= cg2_max_cam()) ? 1 : 0;
+  p->rows_lean = la.lean != 0;
+  p->lin_radius = st.radius;
   launch_linearize(s, la);
   if (st.reduced == 2) {
     // the off-diagonal blocks only need the rows Y: assembled on the second stream while this one sweeps the stations
@@ -1076,6 +1088,22 @@ int make_candidate(ba_problem *p, double alpha);
 // y_p = V^-1 (g_p - W^T y_c); model cost change; candidate = x - y*scale; norms.  Reads d_x.
 int step_and_candidate(ba_problem *p) {
   hipStream_t s = p->stream;
+  if (p->rows_lean) {
+    PointArgs pa = point_args(p, p->d_x);
+    pa.Y = p->d_Y; pa.elim = p->d_elim; pa.diag_pt = p->d_diag_pt; pa.radius = p->lin_radius; pa.ncam = p->ncam;
+    launch_backsub_y(s, pa);
+    launch_sum_partials(s, p->d_partial, linearize_blocks(p->P), p->d_scal, SC_MCC);
+    BA_TRY(p->allreduce(p->d_scal + SC_MCC, 1, 0));
+    // y_c^T S y_c with the kernels of the PCG (the system is replicated on every rank)
+    BsrCgArgs a{};
+    a.S = p->S; a.ncam = p->ncam; a.rowptr = p->d_bsr_rowptr; a.col = p->d_bsr_col; a.val = p->d_bsr_val; a.Ssc = p->d_Ssc;
+    a.Scc = p->d_Scc; a.p = p->d_x; a.q = p->d_q; a.scal = p->d_zero; a.part_pq = p->d_part_pq; a.part_qc = p->d_part_qc;
+    launch_quadratic_form(s, a, p->d_ytSy);
+    const size_t ns = 6 * (size_t)p->S;
+    launch_mcc_reduced(s, (int64_t)ns, p->d_g, p->d_x, p->d_d2_sta, p->d_ytSy, p->d_scal, SC_MCC);
+    if (p->ncam > 0) launch_mcc_reduced(s, p->ncam, p->d_g + ns, p->d_x + ns, p->d_d2_cam, nullptr, p->d_scal, SC_MCC);
+    return make_candidate(p, 1.0);
+  }
   PointArgs pa = point_args(p, p->d_x);
   launch_point_pass(s, pa, MODE_BACKSUB, p->ncam > 0);
   launch_sum_partials(s, p->d_partial, linearize_blocks(p->P), p->d_scal, SC_MCC);
@@ -1642,6 +1670,7 @@ int ba_covariance(ba_problem *p, double *var_eop, double *var_xyz, double *var_i
   BA_TRY(init_scaling(p, &opt));
   const bool use_explicit = p->explicit_ok;
   LmState st{1e300, opt.min_lm_diagonal, opt.max_lm_diagonal, false, false, use_explicit ? 2 : 1};
+  st.full_rows = true;  // the point variances are formed from the rows
   BA_TRY(linearize(p, st));
   std::vector<double> cs((size_t)std::max(n, 1), 0.0), vx(3 * (size_t)std::max(p->P, 1), 0.0);
   if (n > 0) {
@@ -1811,6 +1840,7 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
   // a valid linearisation (scales, station records, Jacobians) for the kernels to run on
   BA_TRY(init_scaling(p, &opt));
   LmState st{opt.initial_trust_region_radius, opt.min_lm_diagonal, opt.max_lm_diagonal, false, false, p->explicit_ok ? 2 : 1};
+  st.full_rows = true;  // the kernels of the matrix-free operator read all rows
   BA_TRY(linearize(p, st));
   launch_copy(s, p->nr, p->d_b, p->d_p);
   LinArgs la{};
@@ -1823,6 +1853,8 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
   la.Y = p->explicit_ok ? p->d_Y : nullptr;
   la.Jt = p->d_Jt;
   la.cam_partial = p->d_campart;
+  // timed as a solve runs it: without the rows that nothing reads
+  la.lean = (p->explicit_ok && (p->d_Jt != nullptr || p->ncam == 0) && p->ncam <= cg2_max_cam()) ? 1 : 0;
   BsrCgArgs ba{};
   ba.S = p->S; ba.ncam = p->ncam; ba.rowptr = p->d_bsr_rowptr; ba.col = p->d_bsr_col; ba.val = p->d_bsr_val; ba.Ssc = p->d_Ssc;
   ba.Scc = p->d_Scc; ba.Lcc = p->d_Sccinv; ba.Minv = p->d_Minv; ba.b = p->d_b; ba.x = p->d_x; ba.r = p->d_r; ba.z = p->d_z; ba.p = p->d_p;

@@ -30,6 +30,7 @@ struct LinArgs {
   int reuse_diag;
   int model;  // projection, 0..7 (ba_inputs.model)
   int emp;    // 0: no camera has an empirical term AP[7..15] that is free or non-zero (kernels then skip them)
+  int lean;   // 1: the rows Jp and Jc are not written (nothing reads them: the back substitution works from Y)
 };
 
 struct PointArgs {
@@ -41,6 +42,10 @@ struct PointArgs {
   // back substitution only
   const double *g_pt, *xyz, *pt_prior, *pt_isig, *scale_pt;
   double *y_pt, *partial;
+  // back substitution from the whitened coupling blocks (launch_backsub_y)
+  const double *Y, *elim, *diag_pt;
+  double radius;
+  int ncam;  // free camera parameters (single camera, at most lin_ncb()) whose Z columns the elimination records hold
 };
 
 struct StationArgs {
@@ -107,6 +112,9 @@ void launch_camera_rows_fold(hipStream_t s, const double *cam_partial, int nbloc
 int lin_npart();
 void launch_camera_corner_fold(hipStream_t s, const double *cam_partial, int nblocks, double *corner);
 void launch_point_pass(hipStream_t s, const PointArgs &a, int mode, bool withcam);
+void launch_backsub_y(hipStream_t s, const PointArgs &a);
+// out[slot] += g.y - (ytSy - sum d2 y^2) / 2 over the nr camera-side unknowns (one workgroup)
+void launch_mcc_reduced(hipStream_t s, int64_t nr, const double *g, const double *y, const double *d2, const double *ytSy, double *out, int slot);
 void launch_station_pass(hipStream_t s, const StationArgs &a, int smode);
 void launch_station_fold(hipStream_t s, int S, const int *sta_chunk0, const double *part, int stride, int ncols, double *out);
 void launch_camera_fold(hipStream_t s, int C, int n_chunks, const int *chunk_sta, const int *sta_cam, const CamRec *cam,
@@ -182,6 +190,7 @@ int cg2_blocks_vec(int S);
 void launch_cg2_init(hipStream_t s, const BsrCgArgs &a, double rtol);
 void launch_cg2_iteration(hipStream_t s, const BsrCgArgs &a, int parity);
 void launch_bsr_spmv(hipStream_t s, const BsrCgArgs &a, int parity);
+void launch_quadratic_form(hipStream_t s, const BsrCgArgs &a, double *out);
 int defl_max_cam();  // largest camera block the coarse space handles
 int cg2_max_cam();   // most free camera parameters the explicit block-sparse PCG handles
 void launch_defl_get_column(hipStream_t s, int S, int ncam, int k, const double *M, double *v);

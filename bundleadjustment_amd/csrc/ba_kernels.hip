@@ -257,13 +257,15 @@ k_obs_rows(LinArgs a) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      double *gj = a.Jc + (int64_t)R * e0;
-      // q / R by a multiplication: exact for q < 64 * 38 with this constant (R is not known at compile time, and a
-      // vector division per element would cost more than the rest of the copy)
-      const unsigned magic = 0xFFFFFFFFu / (unsigned)R + 1u;
-      for (int q = lane; q < nvalid * R; q += 64) {
-        const int rec = (int)__umulhi((unsigned)q, magic);
-        gj[q] = buf[rec * (R + 1) + (q - rec * R)];
+      if (!a.lean) {
+        double *gj = a.Jc + (int64_t)R * e0;
+        // q / R by a multiplication: exact for q < 64 * 38 with this constant (R is not known at compile time, and a
+        // vector division per element would cost more than the rest of the copy)
+        const unsigned magic = 0xFFFFFFFFu / (unsigned)R + 1u;
+        for (int q = lane; q < nvalid * R; q += 64) {
+          const int rec = (int)__umulhi((unsigned)q, magic);
+          gj[q] = buf[rec * (R + 1) + (q - rec * R)];
+        }
       }
       if (CAM1) {
 #pragma unroll
@@ -298,7 +300,7 @@ k_obs_rows(LinArgs a) {
     }
     {
       const double jp[6] = {p0, p1, p2, p3, p4, p5};
-      tile_store<6>(buf, jp, a.Jp + 6 * e0, lane, nvalid);
+      if (!a.lean) tile_store<6>(buf, jp, a.Jp + 6 * e0, lane, nvalid);
       double t0, t1, t2, w0, w1, w2;
       sym3_mul(Vi, p0, p1, p2, t0, t1, t2);
       sym3_mul(Vi, p3, p4, p5, w0, w1, w2);
@@ -543,6 +545,95 @@ k_backsub_tiles(PointArgs a) {
   }
   const double t = block_sum(acc, lds);
   if (threadIdx.x == 0) a.partial[blockIdx.x] = t;
+}
+
+// Back substitution from the whitened coupling blocks alone.  With V^-1 = L L^T and Y_e = Js_e^T Jp_e L (what the block
+// assembly reads as well), V^-1 Jp_e^T Js_e y_i = L Y_e^T y_i, so
+//     y_p = u - L sum_e Y_e^T y_{i(e)} - Z y_c,     u = V^-1 g,  Z = V^-1 B^T  (both in the elimination record):
+// no row of the Jacobian is read.  A wave owns 64 consecutive points = one contiguous run of observations, one lane per
+// observation forms Y_e^T y_i, the three sums of an observation go to the lane that owns its point through LDS.
+// The model cost change follows without the rows too (launch_mcc_reduced): with H = J^T J and y_p from the exact
+// elimination,  y^T H y = y_c^T S y_c - y_c^T D_c^2 y_c + g_p^T u - y_p^T D_p^2 y_p  for ANY y_c (also an inexact PCG
+// solution).  This kernel leaves the point part: partial sums of  (g_p.u - y_p.D_p^2 y_p) / 2 - g_p.y_p.
+__global__ void __launch_bounds__(256)
+k_backsub_y(PointArgs a) {
+  __shared__ double lds[8];
+  __shared__ double lds_c[4][64 * 3];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int jj0 = (blockIdx.x * 4 + w) * 64;
+  const int jj = jj0 + lane;
+  const bool has_pt = jj < a.P;
+  double acc = 0.0;
+  if (jj0 < a.P) {  // whole waves only
+    const int jend = min(jj0 + 64, a.P);
+    const int eb = a.pt_start[jj0], ee = a.pt_start[jend];
+    const int e0 = has_pt ? a.pt_start[jj] : ee, e1 = has_pt ? a.pt_start[jj + 1] : ee;
+    double t0 = 0, t1 = 0, t2 = 0;
+    for (int base = eb; base < ee; base += 64) {
+      const int e = base + lane;
+      double c0 = 0, c1 = 0, c2 = 0;
+      if (e < ee) {
+        const int sta = a.obs_sta[e];
+        const double2 *pv = reinterpret_cast<const double2 *>(a.vec + 6 * (int64_t)sta);
+        const double2 *py = reinterpret_cast<const double2 *>(a.Y + (int64_t)BA_Y_STRIDE * e);
+        const double2 v0 = pv[0], v1 = pv[1], v2 = pv[2];
+        const double2 y0 = py[0], y1 = py[1], y2 = py[2], y3 = py[3], y4 = py[4], y5 = py[5], y6 = py[6], y7 = py[7], y8 = py[8];
+        // Y row-major 6 x 3: row r at 3 r
+        c0 = y0.x * v0.x + y1.y * v0.y + y3.x * v1.x + y4.y * v1.y + y6.x * v2.x + y7.y * v2.y;
+        c1 = y0.y * v0.x + y2.x * v0.y + y3.y * v1.x + y5.x * v1.y + y6.y * v2.x + y8.x * v2.y;
+        c2 = y1.x * v0.x + y2.y * v0.y + y4.x * v1.x + y5.y * v1.y + y7.x * v2.x + y8.y * v2.y;
+      }
+      lds_c[w][3 * lane] = c0;
+      lds_c[w][3 * lane + 1] = c1;
+      lds_c[w][3 * lane + 2] = c2;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int q_lo = max(e0, base), q_hi = min(e1, base + 64);
+      for (int q = q_lo; q < q_hi; ++q) {  // this point's observations of the chunk, in order
+        t0 += lds_c[w][3 * (q - base)];
+        t1 += lds_c[w][3 * (q - base) + 1];
+        t2 += lds_c[w][3 * (q - base) + 2];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (has_pt) {
+      const double *el = a.elim + (int64_t)ELIM_STRIDE * jj;
+      const double u0 = el[0], u1 = el[1], u2 = el[2];
+      const double l00 = el[3], l10 = el[4], l20 = el[5], l11 = el[6], l21 = el[7], l22 = el[8];
+      double y0 = u0 - l00 * t0, y1 = u1 - (l10 * t0 + l11 * t1), y2 = u2 - (l20 * t0 + l21 * t1 + l22 * t2);
+      const double *yc = a.vec + 6 * (int64_t)a.S;
+      for (int k = 0; k < a.ncam; ++k) {
+        const double c = yc[k];
+        y0 -= el[16 + 3 * k] * c;
+        y1 -= el[17 + 3 * k] * c;
+        y2 -= el[18 + 3 * k] * c;
+      }
+      double *yo = a.y_pt + 3 * (int64_t)jj;
+      yo[0] = y0; yo[1] = y1; yo[2] = y2;
+      const double *g = a.g_pt + 3 * (int64_t)jj, *dg = a.diag_pt + 3 * (int64_t)jj;
+      const double ir = 1.0 / a.radius;
+      // (the sums carry the sign of the row-wise form sum m (r + m / 2), m = J step: minus the model cost change)
+      acc = 0.5 * ((g[0] * u0 + g[1] * u1 + g[2] * u2) - (dg[0] * ir * y0 * y0 + dg[1] * ir * y1 * y1 + dg[2] * ir * y2 * y2)) -
+            (g[0] * y0 + g[1] * y1 + g[2] * y2);
+    }
+  }
+  const double t = block_sum(acc, lds);
+  if (threadIdx.x == 0) a.partial[blockIdx.x] = t;
+}
+
+// camera-side part of the same sum: out[slot] += (y^T S y - sum d2 y^2) / 2 - g.y  (ytSy may be null: a second
+// call for a second stretch of the vector)
+__global__ void __launch_bounds__(1024)
+k_mcc_reduced(int64_t nr, const double *__restrict__ g, const double *__restrict__ y, const double *__restrict__ d2,
+              const double *__restrict__ ytSy, double *__restrict__ out, int slot) {
+  __shared__ double lds[16];
+  double s = 0.0;
+  for (int64_t k = threadIdx.x; k < nr; k += blockDim.x) s += y[k] * (g[k] + 0.5 * d2[k] * y[k]);
+  const double t = block_sum(s, lds);
+  if (threadIdx.x == 0) out[slot] += (ytSy ? 0.5 * ytSy[0] : 0.0) - t;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1396,6 +1487,12 @@ void launch_point_pass(hipStream_t s, const PointArgs &a, int mode, bool withcam
     if (withcam) hipLaunchKernelGGL(k_backsub_tiles<true>, g, b, 0, s, a);
     else hipLaunchKernelGGL(k_backsub_tiles<false>, g, b, 0, s, a);
   }
+}
+void launch_backsub_y(hipStream_t s, const PointArgs &a) {
+  if (a.P > 0) hipLaunchKernelGGL(k_backsub_y, dim3(nblk(a.P, 256)), dim3(256), 0, s, a);
+}
+void launch_mcc_reduced(hipStream_t s, int64_t nr, const double *g, const double *y, const double *d2, const double *ytSy, double *out, int slot) {
+  hipLaunchKernelGGL(k_mcc_reduced, dim3(1), dim3(1024), 0, s, nr, g, y, d2, ytSy, out, slot);
 }
 void launch_station_pass(hipStream_t s, const StationArgs &a, int smode) {
   if (a.n_chunks <= 0) return;

@@ -495,6 +495,16 @@ k_cg2_update1(BsrCgArgs a, int parity, int nblk_spmv) {
   vec_finish(a, alpha, a.r, blockIdx.x, gridDim.x, v, sh);
 }
 
+// out[0] = p^T S p from the partials a k_bsr_spmv launch has left (the fold of the PCG's second kernel on its own)
+__global__ void __launch_bounds__(256)
+k_quadratic_form(BsrCgArgs a, int nblk_spmv, double *__restrict__ out) {
+  __shared__ Cg2Shared sh;
+  FoldLoads f;
+  fold_issue(a, nblk_spmv, 0, f);
+  (void)cg2_alpha(a, 1.0, nblk_spmv, f, sh);
+  if (threadIdx.x == 0) out[0] = sh.pq;
+}
+
 // beta = r.z(new) / r.z(old); p = z + beta p; stopping test for the next iteration
 __global__ void __launch_bounds__(256)
 k_cg2_update2(BsrCgArgs a, int parity, int nblk) {
@@ -745,6 +755,13 @@ void launch_cg2_spmv_update1(hipStream_t s, const BsrCgArgs &a, int parity) {
 void launch_bsr_spmv(hipStream_t s, const BsrCgArgs &a, int parity) {
   const int nbs = cg2_blocks_spmv(a.S);
   if (nbs > 0) hipLaunchKernelGGL(k_bsr_spmv, dim3(nbs), dim3(64 * SPMV_WAVES), 0, s, a, parity);
+}
+// out[0] = a.p^T S a.p (a.q is overwritten; a.scal must point to zeros: the stopping flag of a finished solve would
+// make the product return at once)
+void launch_quadratic_form(hipStream_t s, const BsrCgArgs &a, double *out) {
+  const int nbs = cg2_blocks_spmv(a.S);
+  if (nbs > 0) hipLaunchKernelGGL(k_bsr_spmv, dim3(nbs), dim3(64 * SPMV_WAVES), 0, s, a, 0);
+  hipLaunchKernelGGL(k_quadratic_form, dim3(1), dim3(256), 0, s, a, nbs, out);
 }
 void launch_cg2_iteration(hipStream_t s, const BsrCgArgs &a, int parity) {
   const int nbs = cg2_blocks_spmv(a.S), nbv = cg2_blocks_vec(a.S);
