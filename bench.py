@@ -235,6 +235,26 @@ def main():
     if steps_done != args.steps:
         sys.exit(f"solver ran {steps_done} iterations instead of {args.steps}: {sm}")
 
+    per_rank = None
+    if world > 1:
+        # Where the time of a rank goes, from one more solve outside the timed region with events around every
+        # reduction over the ranks: host-clock phases of the iteration rows, and the reductions inside them (a
+        # collective also waits for the slowest rank, so load imbalance shows as reduction time).
+        P.set_parameters()
+        P.reduction_stats()
+        P.reduction_timing(True)
+        sm2, rows2 = P.solve_resident(options(args.steps))
+        n_red, red_bytes, red_s = P.reduction_stats()
+        P.reduction_timing(False)
+        mine = {"rank": rank, "observations": int(net.n_obs), "points": int(net.n_pts),
+                "linearise_ms_per_step": 1e3 * sum(r["t_linearize_s"] for r in rows2) / args.steps,
+                "solve_ms_per_step": 1e3 * sum(r["t_solve_s"] for r in rows2) / args.steps,
+                "evaluate_ms_per_step": 1e3 * sum(r["t_eval_s"] for r in rows2) / args.steps,
+                "reductions_per_step": n_red / args.steps, "reduction_MB_per_step": red_bytes / args.steps / 1e6,
+                "reduction_ms_per_step": 1e3 * red_s / args.steps}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+
     if dense:
         # the reduced system is factored on the matrix cores: report that kernel chain against the fp64 MFMA peak
         n_red = 6 * full.n_sta + free_cam
@@ -250,6 +270,8 @@ def main():
                "roofline": {"bound": "mfma", "kernel": "dense Cholesky (k_chol_diag + k_gemm_nt<TRSM> + k_gemm_nt<SYRK>)",
                             "achieved": flops / t_fac / 1e12, "peak": 78.6, "unit": "TFLOP/s", "frac": flops / t_fac / 78.6e12,
                             "traffic": None, "ms": 1e3 * t_fac, "flops": flops}}
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if rank == 0:
             print(json.dumps(out), flush=True)
         P.close()
@@ -313,6 +335,8 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(KERNEL_NAMES[dom], args.config, args.scale, world)},
         "kernels": kernels,
     }
+    if per_rank is not None:
+        out["per_rank"] = per_rank
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         n_cpu, it_s, obs_s, cg = cpu_baseline(args.config, args.cpu_scale * args.scale, args.pcg_rtol)
         out["cpu_baseline"] = {

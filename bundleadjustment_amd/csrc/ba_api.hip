@@ -57,9 +57,11 @@ double now_s() {
 
 int popcount32(unsigned v) { return __builtin_popcount(v); }
 
+// Slots of the scalar block.  What is summed over the ranks in one reduction sits side by side: SC_MCC .. SC_CCOST
+// (the step phase), and for the maximum SC_GMAX_P, SC_NOTPD_P (the linearisation).
 enum Scal {
-  SC_COST = 0, SC_FIXED, SC_GMAX, SC_MCC, SC_STEP2_SC, SC_CNORM2_SC, SC_STEP2_P, SC_CNORM2_P, SC_CCOST, SC_XNORM2_SC,
-  SC_XNORM2_P, SC_GMAX_P, SC_GMAX_SC, SC_LS_DOT_P, SC_LS_DOT_SC, SC_LS_MAX_P, SC_LS_MAX_SC, SC_COUNT = 32
+  SC_COST = 0, SC_FIXED, SC_GMAX, SC_STEP2_SC, SC_CNORM2_SC, SC_MCC, SC_STEP2_P, SC_CNORM2_P, SC_CCOST, SC_XNORM2_SC,
+  SC_XNORM2_P, SC_GMAX_P, SC_NOTPD_P, SC_GMAX_SC, SC_LS_DOT_P, SC_LS_DOT_SC, SC_LS_MAX_P, SC_LS_MAX_SC, SC_COUNT = 32
 };
 
 }  // namespace
@@ -160,6 +162,9 @@ struct ba_problem {
   // multi-GPU
   ba_allreduce_fn ar = nullptr;
   void *ar_user = nullptr;
+  double *d_redsum = nullptr;   // [blocks | camera border | corner sums], see alloc_reduced_sums
+  size_t redsum_blocks = 0, redsum_border = 0;
+  bool general_border = false;  // several cameras: the border comes from the general point and station sweeps
   ncclComm_t comm = nullptr;
 
   template <class T>
@@ -178,9 +183,26 @@ struct ba_problem {
     if (!v.empty()) HIP_OK(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return 0;
   }
+  // reductions over the ranks, counted and (on request, ba_reduction_timing) bracketed by events on the stream
+  bool time_reductions = false;
+  int64_t n_reductions = 0;
+  double reduction_bytes = 0.0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> reduction_events;
   int allreduce(double *buf, int64_t n, int op) {
     if (!ar || n <= 0) return 0;
+    n_reductions++;
+    reduction_bytes += 8.0 * (double)n;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (time_reductions) {
+      HIP_OK(hipEventCreate(&e0));
+      HIP_OK(hipEventCreate(&e1));
+      HIP_OK(hipEventRecord(e0, stream));
+    }
     if (ar(ar_user, buf, n, op, stream) != 0) return fail(BA_ERR_COMM, "allreduce callback failed");
+    if (time_reductions) {
+      HIP_OK(hipEventRecord(e1, stream));
+      reduction_events.emplace_back(e0, e1);
+    }
     return 0;
   }
   int read_scal() {
@@ -231,6 +253,30 @@ struct SetupTrace {
     t = u;
   }
 };
+
+// One allocation for everything of the reduced system that the ranks sum: the off-diagonal blocks, the camera border
+// and the corner sums lie one after another, so that one reduction covers them.  Called again when the block pattern
+// changes (the union over the shards).
+int alloc_reduced_sums(ba_problem *p) {
+  auto pad = [](size_t n) { return (n + 31) / 32 * 32; };
+  const size_t nb = p->explicit_ok ? pad(36 * (size_t)p->n_bsr) : 0, nsc = pad(6 * (size_t)p->S * p->ncam);
+  const size_t ncorner = pad(std::max<size_t>(64, (size_t)p->ncam * p->ncam));
+  if (p->d_redsum) {
+    auto it = std::find(p->allocs.begin(), p->allocs.end(), (void *)p->d_redsum);
+    if (it != p->allocs.end()) p->allocs.erase(it);
+    HIP_OK(hipFree(p->d_redsum));
+    p->d_redsum = nullptr;
+  }
+  BA_TRY(p->dalloc(&p->d_redsum, nb + nsc + ncorner));
+  HIP_OK(hipMemset(p->d_redsum, 0, (nb + nsc + ncorner) * sizeof(double)));
+  p->d_bsr_val = p->explicit_ok ? p->d_redsum : nullptr;
+  p->d_Ssc = p->d_redsum + nb;
+  p->d_corner = p->d_Ssc + nsc;
+  p->d_corner_gen = p->general_border ? p->d_corner : nullptr;
+  p->redsum_blocks = nb;
+  p->redsum_border = nsc + ncorner;
+  return 0;
+}
 
 int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   SetupTrace trace;
@@ -510,10 +556,9 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   BA_TRY(p->dalloc(&p->d_jc2, (size_t)p->ncam));
   BA_TRY(p->dalloc(&p->d_diagfull, (size_t)p->nr));
   p->d_d2_sta = p->d_diagfull;
-  BA_TRY(p->dalloc(&p->d_F, 39 * (size_t)S));
+  BA_TRY(p->dalloc(&p->d_F, 39 * (size_t)S + 3 * (size_t)p->ncam + 8));  // room behind for what is reduced along with it
   BA_TRY(p->dalloc(&p->d_part, (size_t)std::max(std::max(39, border_nacc()), 6 * p->ncam) * p->n_chunks));
   BA_TRY(p->dalloc(&p->d_Sdiag, 36 * (size_t)S));
-  BA_TRY(p->dalloc(&p->d_corner, 64));
   trace.mark("allocations");
   if (p->explicit_ok) {
     BA_TRY(p->upload(&p->d_bsr_rowptr, bsr_rowptr));
@@ -522,7 +567,6 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
     BA_TRY(p->upload(&p->d_ublk_dst, ublk_dst));
     BA_TRY(p->upload(&p->d_pairs, pairs));
     BA_TRY(p->dalloc(&p->d_Y, (size_t)BA_Y_STRIDE * N));
-    BA_TRY(p->dalloc(&p->d_bsr_val, 36 * (size_t)p->n_bsr));
     const size_t npart = (size_t)std::max(std::max(cg2_blocks_spmv(S), cg2_blocks_vec(S)), 1024) + 1;
     BA_TRY(p->dalloc(&p->d_part_pq, npart));
     BA_TRY(p->dalloc(&p->d_part_qc, npart * std::max(p->ncam, 1)));
@@ -542,8 +586,9 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
     BA_TRY(p->upload(&p->d_col_pos, col_pos));
     BA_TRY(p->dalloc(&p->d_Zc, (size_t)P * p->ncam * 3));
     BA_TRY(p->dalloc(&p->d_part_cc, (size_t)p->n_chunks * p->ncmax * p->ncam));
-    BA_TRY(p->dalloc(&p->d_corner_gen, (size_t)p->ncam * p->ncam));
+    p->general_border = true;
   }
+  BA_TRY(alloc_reduced_sums(p));
   if (single_camera_path) {
     // single camera with few free parameters: the linearisation kernel also produces the camera border's inputs
     BA_TRY(p->dalloc(&p->d_Jt, 2 * (size_t)border_ncb() * N));
@@ -564,7 +609,6 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   BA_TRY(p->dalloc(&p->d_q, nr));
   BA_TRY(p->dalloc(&p->d_r2, nr));
   BA_TRY(p->dalloc(&p->d_Minv, 36 * (size_t)S));
-  BA_TRY(p->dalloc(&p->d_Ssc, 6 * (size_t)S * p->ncam));
   BA_TRY(p->dalloc(&p->d_Scc, (size_t)p->ncam * p->ncam));
   BA_TRY(p->dalloc(&p->d_Lcc, (size_t)p->ncam * p->ncam));
   BA_TRY(p->dalloc(&p->d_Sccinv, (size_t)p->ncam * p->ncam));
@@ -636,29 +680,16 @@ PointArgs point_args(ba_problem *p, const double *vec) {
   return a;
 }
 
-// camera rows of J^T v for v = rec[voff]: station sweep with the camera columns, fold per camera
+// camera rows of J^T v for v = rec[voff]: station sweep with the camera columns, fold per camera (this rank's share)
 int camera_rows(ba_problem *p, int voff, double *out_cam) {
   if (p->ncam == 0) return 0;
   StationArgs sa = station_args(p, voff, 6 + BA_NCAMPAR);
   launch_station_pass(p->stream, sa, SMODE_GATHER_CAM);
   launch_camera_fold(p->stream, p->C, p->n_chunks, p->d_chunk_sta, p->d_sta_cam, p->d_cam, p->d_part, 6 + BA_NCAMPAR, 6, out_cam);
-  return p->allreduce(out_cam, p->ncam, 0);
+  return 0;
 }
 
 int build_reduced(ba_problem *p, bool explicit_blocks);
-
-// max over the ranks of a few host values through the device-side reduction callback (the scalar block is free between
-// read_scal and the next phase)
-int host_max_over_ranks(ba_problem *p, std::vector<double> &v) {
-  if (!p->ar || v.empty()) return 0;
-  if (v.size() > 8) return fail(BA_ERR_INVALID, "host_max_over_ranks: vector too long");
-  double *buf = p->d_scal + SC_COUNT - 8;
-  HIP_OK(hipMemcpyAsync(buf, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
-  BA_TRY(p->allreduce(buf, (int64_t)v.size(), 1));
-  HIP_OK(hipMemcpyAsync(v.data(), buf, v.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-  HIP_OK(hipStreamSynchronize(p->stream));
-  return 0;
-}
 
 // Residuals, Jacobians, point elimination, station blocks, gradient, reduced right-hand side.
 // Leaves cost in h_scal[SC_COST] (+ SC_FIXED) and the max-norm of the gradient in h_scal[SC_GMAX].
@@ -692,52 +723,67 @@ int linearize(ba_problem *p, const LmState &st) {
     p->schur_queued = true;
   }
   launch_sum_partials(s, p->d_partial, linearize_blocks(p->P), p->d_scal, SC_COST);
-  BA_TRY(p->allreduce(p->d_scal + SC_COST, 1, 0));
-  launch_camera_prior_cost(s, p->C, p->d_cam, p->d_scal, SC_COST, SC_FIXED, nullptr);
-  // station blocks
+  // this rank's share of the station blocks and of the camera rows of the gradient and the reduced right-hand side
   StationArgs sa = station_args(p, 6, 39);
   launch_station_pass(s, sa, SMODE_SETUP);
   launch_station_fold(s, p->S, p->d_sta_chunk0, p->d_part, 39, 39, p->d_F);
-  BA_TRY(p->allreduce(p->d_F, 39 * (int64_t)p->S, 0));
+  double *g_cam = p->d_g + 6 * (size_t)p->S, *b_cam = p->d_b + 6 * (size_t)p->S;
+  if (p->ncam > 0) {
+    if (p->d_Jt) {
+      launch_camera_rows_fold(s, p->d_campart, obs_rows_blocks(p->N), p->ncam, g_cam, b_cam);
+    } else {
+      BA_TRY(camera_rows(p, 6, g_cam));
+      BA_TRY(camera_rows(p, 7, b_cam));
+    }
+    if (st.need_norms) {
+      StationArgs sn = station_args(p, 6, BA_NCAMPAR);
+      launch_station_pass(s, sn, SMODE_CAMNORM);
+      launch_camera_fold(s, p->C, p->n_chunks, p->d_chunk_sta, p->d_sta_cam, p->d_cam, p->d_part, BA_NCAMPAR, 0, p->d_colnorm_cam_in);
+    }
+  }
+  if (p->ar) {
+    // one sum over the ranks: the small arrays travel behind the station sums
+    PackList pl{};
+    pl.ptr[0] = g_cam; pl.n[0] = p->ncam;
+    pl.ptr[1] = b_cam; pl.n[1] = p->ncam;
+    pl.ptr[2] = p->d_colnorm_cam_in; pl.n[2] = (p->ncam > 0 && st.need_norms) ? p->ncam : 0;
+    pl.ptr[3] = p->d_scal + SC_COST; pl.n[3] = 1;
+    double *tail = p->d_F + 39 * (size_t)p->S;
+    launch_pack_segments(s, pl, tail, 1);
+    BA_TRY(p->allreduce(p->d_F, 39 * (int64_t)p->S + pl.n[0] + pl.n[1] + pl.n[2] + pl.n[3], 0));
+    launch_pack_segments(s, pl, tail, 0);
+  }
+  launch_camera_prior_cost(s, p->C, p->d_cam, p->d_scal, SC_COST, SC_FIXED, nullptr);
   StationFinishArgs fa{};
   fa.S = p->S; fa.reuse_diag = st.reuse_diag; fa.sta_used = p->d_sta_used; fa.F = p->d_F;
   fa.lm_min = st.lm_min; fa.lm_max = st.lm_max; fa.radius = st.radius;
   fa.colnorm_sta = p->d_colnorm_sta; fa.diag_sta = p->d_diag_sta; fa.d2_sta = p->d_d2_sta; fa.g_sta = p->d_g; fa.b_sta = p->d_b;
   fa.Sdiag = p->d_Sdiag;
   launch_station_finish(s, fa);
-  // camera rows of the gradient and of the reduced right-hand side
   if (p->ncam > 0) {
-    if (p->d_Jt) {
-      launch_camera_rows_fold(s, p->d_campart, obs_rows_blocks(p->N), p->ncam, p->d_g + 6 * (size_t)p->S, p->d_b + 6 * (size_t)p->S);
-      BA_TRY(p->allreduce(p->d_g + 6 * (size_t)p->S, p->ncam, 0));
-      BA_TRY(p->allreduce(p->d_b + 6 * (size_t)p->S, p->ncam, 0));
-    } else {
-      BA_TRY(camera_rows(p, 6, p->d_g + 6 * (size_t)p->S));
-      BA_TRY(camera_rows(p, 7, p->d_b + 6 * (size_t)p->S));
-    }
-    if (st.need_norms) {
-      StationArgs sn = station_args(p, 6, BA_NCAMPAR);
-      launch_station_pass(s, sn, SMODE_CAMNORM);
-      launch_camera_fold(s, p->C, p->n_chunks, p->d_chunk_sta, p->d_sta_cam, p->d_cam, p->d_part, BA_NCAMPAR, 0, p->d_colnorm_cam_in);
-      BA_TRY(p->allreduce(p->d_colnorm_cam_in, p->ncam, 0));
-    }
     CamFinishArgs ca{};
     ca.C = p->C; ca.reuse_diag = st.reuse_diag; ca.need_norms = st.need_norms; ca.cam = p->d_cam;
     ca.colnorm_in = st.need_norms ? p->d_colnorm_cam_in : nullptr;
     ca.lm_min = st.lm_min; ca.lm_max = st.lm_max; ca.radius = st.radius;
     ca.jc2 = p->d_jc2; ca.colnorm_cam = p->d_colnorm_cam; ca.diag_cam = p->d_diag_cam; ca.d2_cam = p->d_d2_cam;
-    ca.camdiag = p->d_diagfull + 6 * (size_t)p->S; ca.g_cam = p->d_g + 6 * (size_t)p->S; ca.b_cam = p->d_b + 6 * (size_t)p->S;
+    ca.camdiag = p->d_diagfull + 6 * (size_t)p->S; ca.g_cam = g_cam; ca.b_cam = b_cam;
     launch_camera_finish(s, ca);
   }
-  // gradient max norm: |x - Plus(x, -g_scaled / scale)| over points (local), stations and cameras (replicated)
+  // gradient max norm: |x - Plus(x, -g_scaled / scale)| over points (local), stations and cameras (replicated).  The
+  // flag of a point block that is not positive definite shows on the rank that owns the point only; it travels with
+  // the maximum, so that every rank takes the same branch below (or the others would wait in the next collective
+  // for ever)
   const int bp = cost_blocks(3 * (int64_t)p->P), bs = cost_blocks(6 * (int64_t)p->S);
   launch_absmax_ratio(s, 3 * (int64_t)p->P, p->d_g_pt, p->d_scale_pt, p->d_xyz, p->d_partial, bp);
   launch_max_partials(s, p->d_partial, bp, p->d_scal, SC_GMAX_P);
-  BA_TRY(p->allreduce(p->d_scal + SC_GMAX_P, 1, 1));
+  if (p->ar) {
+    launch_flag_to_scal(s, p->d_flags, p->d_scal, SC_NOTPD_P);
+    BA_TRY(p->allreduce(p->d_scal + SC_GMAX_P, 2, 1));
+  }
   launch_absmax_ratio(s, 6 * (int64_t)p->S, p->d_g, p->d_scale_sta, p->d_eop, p->d_partial + bp, bs);
   launch_max_partials(s, p->d_partial + bp, bs, p->d_scal, SC_GMAX_SC);
   if (p->ncam > 0) {
-    launch_camera_gradient_step(s, p->C, p->d_cam, p->d_g + 6 * (size_t)p->S, p->d_scal, SC_GMAX);
+    launch_camera_gradient_step(s, p->C, p->d_cam, g_cam, p->d_scal, SC_GMAX);
   } else {
     HIP_OK(hipMemsetAsync(p->d_scal + SC_GMAX, 0, sizeof(double), s));
   }
@@ -747,13 +793,7 @@ int linearize(ba_problem *p, const LmState &st) {
   p->h_scal[SC_GMAX] = std::max(p->h_scal[SC_GMAX], std::max(p->h_scal[SC_GMAX_P], p->h_scal[SC_GMAX_SC]));
   unsigned flags[4];
   HIP_OK(hipMemcpy(flags, p->d_flags, sizeof flags, hipMemcpyDeviceToHost));
-  if (p->ar) {
-    // a point block that is not positive definite shows on the rank that owns the point only: every rank must take
-    // the same branch below, or the others wait in the next collective for ever
-    std::vector<double> f(1, (double)flags[0]);
-    BA_TRY(host_max_over_ranks(p, f));
-    if (f[0] != 0.0 && !flags[0]) flags[0] = 1u;
-  }
+  if (p->ar && p->h_scal[SC_NOTPD_P] != 0.0 && !flags[0]) flags[0] = 1u;  // another rank's point block
   if (flags[0]) {
     HIP_OK(hipMemset(p->d_flags, 0, sizeof flags));
     return fail(BA_ERR_NUMERIC, "%s block is not positive definite", (flags[0] & 1) ? "a point" : "a station");
@@ -789,17 +829,12 @@ int probe_column(ba_problem *p, int64_t k, double *out) {
 int build_reduced(ba_problem *p, bool explicit_blocks) {
   hipStream_t s = p->stream;
   const size_t ns = 6 * (size_t)p->S;
-  if (explicit_blocks) {
-    if (p->schur_queued) {
-      HIP_OK(hipStreamWaitEvent(s, p->ev_schur, 0));  // queued by linearize right after the rows were written
-      p->schur_queued = false;
-    } else {
-      // numbers queued for the previous matrix and never waited for (the solve took another route) still read it
-      if (p->amg_numbers_queued) HIP_OK(hipStreamWaitEvent(s, p->ev_amg, 0));
-      HIP_OK(hipMemsetAsync(p->d_bsr_val, 0, 36 * (size_t)p->n_bsr * sizeof(double), s));
-      launch_schur_blocks(s, p->n_ublk, p->d_ublk_cstart, p->d_ublk_dst, p->d_pairs, p->d_Y, p->d_bsr_val);
-    }
-    BA_TRY(p->allreduce(p->d_bsr_val, 36 * (int64_t)p->n_bsr, 0));
+  // Several ranks: the blocks, the camera border and its corner sums lie one after another (alloc_reduced_sums) and are
+  // summed in ONE reduction once the border sweeps are through.  One rank: the blocks are finished first, so that the
+  // numbers of the multilevel preconditioner are refreshed on the second stream beside the border sweeps.
+  const bool merged = p->ar && explicit_blocks && p->ncam > 0 && (p->d_Jt || p->d_Zc);
+  bool blocks_pending = false;  // merged: the wait for the block assembly on the second stream comes right before the sum
+  auto finish_blocks = [&]() -> int {
     launch_bsr_add_diag(s, p->S, p->d_bsr_rowptr, p->d_Sdiag, p->d_bsr_val);
     launch_invert_blocks(s, p->S, p->d_bsr_val, p->d_bsr_rowptr, p->d_sta_used, p->d_Minv, p->d_flags);
     if (p->amg) {
@@ -811,6 +846,32 @@ int build_reduced(ba_problem *p, bool explicit_blocks) {
       HIP_OK(hipEventRecord(p->ev_amg, p->stream2));
       p->amg_numbers_queued = true;
     }
+    return 0;
+  };
+  auto sum_border = [&]() -> int {
+    if (merged) {
+      if (blocks_pending) HIP_OK(hipStreamWaitEvent(s, p->ev_schur, 0));
+      BA_TRY(p->allreduce(p->d_redsum, (int64_t)(p->redsum_blocks + p->redsum_border), 0));
+      return finish_blocks();
+    }
+    return p->allreduce(p->d_Ssc, (int64_t)p->redsum_border, 0);
+  };
+  if (explicit_blocks) {
+    if (p->schur_queued) {
+      // queued by linearize right after the rows were written
+      if (merged) blocks_pending = true;
+      else HIP_OK(hipStreamWaitEvent(s, p->ev_schur, 0));
+      p->schur_queued = false;
+    } else {
+      // numbers queued for the previous matrix and never waited for (the solve took another route) still read it
+      if (p->amg_numbers_queued) HIP_OK(hipStreamWaitEvent(s, p->ev_amg, 0));
+      HIP_OK(hipMemsetAsync(p->d_bsr_val, 0, 36 * (size_t)p->n_bsr * sizeof(double), s));
+      launch_schur_blocks(s, p->n_ublk, p->d_ublk_cstart, p->d_ublk_dst, p->d_pairs, p->d_Y, p->d_bsr_val);
+    }
+    if (!merged) {
+      BA_TRY(p->allreduce(p->d_bsr_val, 36 * (int64_t)p->n_bsr, 0));
+      BA_TRY(finish_blocks());
+    }
   } else {
     launch_invert_blocks(s, p->S, p->d_Sdiag, nullptr, p->d_sta_used, p->d_Minv, p->d_flags);
   }
@@ -821,8 +882,7 @@ int build_reduced(ba_problem *p, bool explicit_blocks) {
     launch_border_station(s, sa, p->d_Jt);
     launch_border_fold(s, p->S, p->ncam, p->n_chunks, p->d_sta_chunk0, p->d_part, border_nacc(), p->d_Ssc);
     launch_camera_corner_fold(s, p->d_campart, obs_rows_blocks(p->N), p->d_corner);  // the sums come out of k_obs_rows
-    BA_TRY(p->allreduce(p->d_Ssc, (int64_t)ns * p->ncam, 0));
-    BA_TRY(p->allreduce(p->d_corner, border_ncb() * (border_ncb() + 1) / 2, 0));
+    BA_TRY(sum_border());
     launch_border_corner(s, p->ncam, p->d_corner, p->d_diagfull + ns, p->d_Scc);
   } else if (p->d_Zc) {
     // several cameras / many free parameters: one point sweep for Z = V^-1 B^T, one station sweep for the sums
@@ -834,8 +894,7 @@ int build_reduced(ba_problem *p, bool explicit_blocks) {
     ga.Vinv = p->d_Vinv; ga.cam = p->d_cam; ga.Zc = p->d_Zc; ga.out_sc = p->d_part; ga.out_cc = p->d_part_cc;
     ga.Ssc = p->d_Ssc; ga.corner = p->d_corner_gen;
     launch_border_general(s, ga);
-    BA_TRY(p->allreduce(p->d_Ssc, (int64_t)ns * p->ncam, 0));
-    BA_TRY(p->allreduce(p->d_corner_gen, (int64_t)p->ncam * p->ncam, 0));
+    BA_TRY(sum_border());
     launch_border_general_corner(s, p->ncam, p->d_corner_gen, p->d_diagfull + ns, p->d_Scc);
   } else {
     // fallback: one pass of the implicit operator per camera column
@@ -869,8 +928,10 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
   if (use_amg) {
     if (!p->amg) {
       p->amg = amg_create();
+      double theta = 0.5;  // strength threshold of the aggregation
+      if (const char *e = std::getenv("BA_AMG_THETA")) theta = std::atof(e);
       if (amg_build(p->amg, s, p->S, p->bsr_rowptr_h, p->bsr_col_h, p->sta_used_h, p->d_bsr_rowptr, p->d_bsr_col, p->d_bsr_val,
-                    p->d_Minv, 0.5) != 0) {
+                    p->d_Minv, theta) != 0) {
         const int rc = fail(BA_ERR_DEVICE, "%s", amg_error(p->amg));
         amg_destroy(p->amg);
         p->amg = nullptr;
@@ -1083,37 +1144,47 @@ int solve_dense(ba_problem *p, bool explicit_blocks) {
   return 0;
 }
 
-int make_candidate(ba_problem *p, double alpha);
+int make_candidate(ba_problem *p, double alpha, bool reduce = true);
+int cost_local(ba_problem *p, const double *eop, const double *xyz, const CamRec *cam, double *sta_buf, int slot, int apply_loss,
+               double *res_out);
 
-// y_p = V^-1 (g_p - W^T y_c); model cost change; candidate = x - y*scale; norms.  Reads d_x.
-int step_and_candidate(ba_problem *p) {
+// y_p = V^-1 (g_p - W^T y_c); model cost change; candidate = x - y*scale; norms; with_cost: the cost at the candidate as
+// well (slot SC_CCOST), so that the phase has ONE sum over the ranks: model cost change, step and candidate norms of the
+// points, candidate cost -- the host decides afterwards whether the step is valid at all.  Reads d_x.
+int step_and_candidate(ba_problem *p, bool with_cost) {
   hipStream_t s = p->stream;
+  const size_t ns = 6 * (size_t)p->S;
+  PointArgs pa = point_args(p, p->d_x);
   if (p->rows_lean) {
-    PointArgs pa = point_args(p, p->d_x);
     pa.Y = p->d_Y; pa.elim = p->d_elim; pa.diag_pt = p->d_diag_pt; pa.radius = p->lin_radius; pa.ncam = p->ncam;
     launch_backsub_y(s, pa);
     launch_sum_partials(s, p->d_partial, linearize_blocks(p->P), p->d_scal, SC_MCC);
-    BA_TRY(p->allreduce(p->d_scal + SC_MCC, 1, 0));
     // y_c^T S y_c with the kernels of the PCG (the system is replicated on every rank)
     BsrCgArgs a{};
     a.S = p->S; a.ncam = p->ncam; a.rowptr = p->d_bsr_rowptr; a.col = p->d_bsr_col; a.val = p->d_bsr_val; a.Ssc = p->d_Ssc;
     a.Scc = p->d_Scc; a.p = p->d_x; a.q = p->d_q; a.scal = p->d_zero; a.part_pq = p->d_part_pq; a.part_qc = p->d_part_qc;
     launch_quadratic_form(s, a, p->d_ytSy);
-    const size_t ns = 6 * (size_t)p->S;
+  } else {
+    launch_point_pass(s, pa, MODE_BACKSUB, p->ncam > 0);
+    launch_sum_partials(s, p->d_partial, linearize_blocks(p->P), p->d_scal, SC_MCC);
+  }
+  BA_TRY(make_candidate(p, 1.0, false));
+  if (with_cost) BA_TRY(cost_local(p, p->d_eop_c, p->d_xyz_c, p->d_cam_c, p->d_sta_c, SC_CCOST, 0, nullptr));
+  static_assert(SC_STEP2_P == SC_MCC + 1 && SC_CNORM2_P == SC_MCC + 2 && SC_CCOST == SC_MCC + 3, "slots summed together");
+  BA_TRY(p->allreduce(p->d_scal + SC_MCC, with_cost ? 4 : 3, 0));
+  // what every rank holds in full comes on top after the sum
+  if (p->rows_lean) {
     launch_mcc_reduced(s, (int64_t)ns, p->d_g, p->d_x, p->d_d2_sta, p->d_ytSy, p->d_scal, SC_MCC);
     if (p->ncam > 0) launch_mcc_reduced(s, p->ncam, p->d_g + ns, p->d_x + ns, p->d_d2_cam, nullptr, p->d_scal, SC_MCC);
-    return make_candidate(p, 1.0);
+  } else {
+    launch_camera_mcc(s, p->C, p->d_cam, p->d_x + ns, p->d_scal, SC_MCC);
   }
-  PointArgs pa = point_args(p, p->d_x);
-  launch_point_pass(s, pa, MODE_BACKSUB, p->ncam > 0);
-  launch_sum_partials(s, p->d_partial, linearize_blocks(p->P), p->d_scal, SC_MCC);
-  BA_TRY(p->allreduce(p->d_scal + SC_MCC, 1, 0));
-  launch_camera_mcc(s, p->C, p->d_cam, p->d_x + 6 * (size_t)p->S, p->d_scal, SC_MCC);
-  return make_candidate(p, 1.0);
+  if (with_cost) launch_camera_prior_cost(s, p->C, p->d_cam_c, p->d_scal, SC_CCOST, -1, nullptr);
+  return p->check_kernels();
 }
 
 // candidate = Plus(x, alpha * delta), its norm and the norm of the step taken
-int make_candidate(ba_problem *p, double alpha) {
+int make_candidate(ba_problem *p, double alpha, bool reduce) {
   hipStream_t s = p->stream;
   CandArgs ca{};
   ca.alpha = alpha;
@@ -1126,12 +1197,13 @@ int make_candidate(ba_problem *p, double alpha) {
   launch_sum_partials(s, p->d_partial + nb, nb, p->d_scal, SC_CNORM2_SC);
   launch_sum_partials(s, p->d_partial + 2 * nb, nb, p->d_scal, SC_STEP2_P);
   launch_sum_partials(s, p->d_partial + 3 * nb, nb, p->d_scal, SC_CNORM2_P);
-  BA_TRY(p->allreduce(p->d_scal + SC_STEP2_P, 2, 0));
+  if (reduce) BA_TRY(p->allreduce(p->d_scal + SC_STEP2_P, 2, 0));
   return p->check_kernels();
 }
 
-int cost_at(ba_problem *p, const double *eop, const double *xyz, const CamRec *cam, double *sta_buf, int slot, int fixed_slot,
-            int apply_loss, double *res_out) {
+// this rank's share of the cost (image rows and point priors of its own points) into d_scal[slot]
+int cost_local(ba_problem *p, const double *eop, const double *xyz, const CamRec *cam, double *sta_buf, int slot, int apply_loss,
+               double *res_out) {
   hipStream_t s = p->stream;
   launch_station_prep(s, p->S, eop, p->d_scale_sta, p->d_sta_cam, sta_buf);
   CostArgs ca{};
@@ -1143,8 +1215,14 @@ int cost_at(ba_problem *p, const double *eop, const double *xyz, const CamRec *c
   launch_cost_prior(s, p->P, xyz, p->d_pt_prior, p->d_pt_isig, p->d_pt_file, res_out ? res_out + 2 * (size_t)p->N : nullptr,
                     p->d_partial + b1, b2);
   launch_sum_partials(s, p->d_partial, b1 + b2, p->d_scal, slot);
+  return 0;
+}
+
+int cost_at(ba_problem *p, const double *eop, const double *xyz, const CamRec *cam, double *sta_buf, int slot, int fixed_slot,
+            int apply_loss, double *res_out) {
+  BA_TRY(cost_local(p, eop, xyz, cam, sta_buf, slot, apply_loss, res_out));
   BA_TRY(p->allreduce(p->d_scal + slot, 1, 0));
-  launch_camera_prior_cost(s, p->C, cam, p->d_scal, slot, fixed_slot,
+  launch_camera_prior_cost(p->stream, p->C, cam, p->d_scal, slot, fixed_slot,
                            res_out ? res_out + 2 * (size_t)p->N + 3 * (size_t)p->P : nullptr);
   return p->check_kernels();
 }
@@ -1267,6 +1345,10 @@ void ba_destroy(ba_problem *p) {
   for (void *q : p->allocs) hipFree(q);
   if (p->h_scal) hipHostFree(p->h_scal);
   if (p->h_cgscal) hipHostFree(p->h_cgscal);
+  for (auto &e : p->reduction_events) {
+    (void)hipEventDestroy(e.first);
+    (void)hipEventDestroy(e.second);
+  }
   if (p->ev_blocks) hipEventDestroy(p->ev_blocks);
   if (p->ev_amg) hipEventDestroy(p->ev_amg);
   if (p->ev_rows) hipEventDestroy(p->ev_rows);
@@ -1544,8 +1626,11 @@ int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary,
     if (lrc != 0 && lrc != BA_ERR_NUMERIC) return lrc;
     bool step_ok = (lrc == 0);
     double mcc = 0.0;
+    // Without a box the candidate is the full step, and its cost is evaluated in the same phase (one sum over the ranks,
+    // one read-back); it is simply not looked at when the step turns out to be invalid.
+    const bool cost_with_step = !constrained;
     if (step_ok) {
-      BA_TRY(step_and_candidate(p));
+      BA_TRY(step_and_candidate(p, cost_with_step));
       BA_TRY(p->read_scal());
       mcc = -p->h_scal[SC_MCC];
       it.step_norm = std::sqrt(p->h_scal[SC_STEP2_SC] + p->h_scal[SC_STEP2_P]);
@@ -1583,8 +1668,10 @@ int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary,
 
     // ---- ComputeCandidatePointAndEvaluateCost ----
     t0 = now_s();
-    BA_TRY(cost_at(p, p->d_eop_c, p->d_xyz_c, p->d_cam_c, p->d_sta_c, SC_CCOST, -1, 0, nullptr));
-    BA_TRY(p->read_scal());
+    if (!cost_with_step) {
+      BA_TRY(cost_at(p, p->d_eop_c, p->d_xyz_c, p->d_cam_c, p->d_sta_c, SC_CCOST, -1, 0, nullptr));
+      BA_TRY(p->read_scal());
+    }
     double cand_cost = p->h_scal[SC_CCOST];
     if (!std::isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
     it.t_eval_s = now_s() - t0;
@@ -2123,7 +2210,7 @@ static int sync_shards(ba_problem *p) {
   BA_TRY(p->upload(&p->d_bsr_rowptr, rowptr));
   BA_TRY(p->upload(&p->d_bsr_col, col));
   BA_TRY(p->upload(&p->d_ublk_dst, dst));
-  BA_TRY(p->dalloc(&p->d_bsr_val, 36 * (size_t)p->n_bsr));
+  BA_TRY(alloc_reduced_sums(p));
   if (p->cg_graph) {
     hipGraphExecDestroy(p->cg_graph);
     if (p->cg_graph_tail) hipGraphExecDestroy(p->cg_graph_tail);
@@ -2134,6 +2221,45 @@ static int sync_shards(ba_problem *p) {
     p->amg = nullptr;
   }
   p->have_G = false;
+  return 0;
+}
+
+int ba_reduction_timing(ba_problem *p, int32_t on) {
+  if (!p) return fail(BA_ERR_INVALID, "ba_reduction_timing: null problem");
+  p->time_reductions = on != 0;
+  return 0;
+}
+
+int ba_reduction_stats(ba_problem *p, int64_t *count, double *bytes, double *seconds) {
+  if (!p) return fail(BA_ERR_INVALID, "ba_reduction_stats: null problem");
+  HIP_OK(hipStreamSynchronize(p->stream));
+  double t = 0.0;
+  for (auto &e : p->reduction_events) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) t += 1e-3 * ms;
+    (void)hipEventDestroy(e.first);
+    (void)hipEventDestroy(e.second);
+  }
+  p->reduction_events.clear();
+  if (count) *count = p->n_reductions;
+  if (bytes) *bytes = p->reduction_bytes;
+  if (seconds) *seconds = t;
+  p->n_reductions = 0;
+  p->reduction_bytes = 0.0;
+  return 0;
+}
+
+int ba_device_count(int32_t *count) {
+  if (!count) return fail(BA_ERR_INVALID, "ba_device_count: null argument");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+  *count = n;
+  return 0;
+}
+
+int ba_set_device(int32_t device) {
+  const hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(BA_ERR_DEVICE, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
   return 0;
 }
 

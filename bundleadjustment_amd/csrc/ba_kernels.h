@@ -127,6 +127,14 @@ int cost_blocks(int64_t n);
 void launch_cost_obs(hipStream_t s, const CostArgs &a, int blocks);
 void launch_cost_prior(hipStream_t s, int P, const double *xyz, const double *prior, const double *isig, const int *pt_file,
                        double *res_out, double *partial, int blocks);
+#define BA_PACK_MAX 4
+struct PackList {
+  double *ptr[BA_PACK_MAX];
+  int n[BA_PACK_MAX];
+};
+// gather 1: the segments, one after another, into packed; 0: back from packed into the segments
+void launch_pack_segments(hipStream_t s, const PackList &l, double *packed, int gather);
+void launch_flag_to_scal(hipStream_t s, const unsigned *flags, double *out, int slot);
 void launch_sum_partials(hipStream_t s, const double *partial, int n, double *out, int slot);
 void launch_max_partials(hipStream_t s, const double *partial, int n, double *out, int slot);
 void launch_absmax_ratio(hipStream_t s, int64_t n, const double *g, const double *scale, const double *x, double *partial, int blocks);

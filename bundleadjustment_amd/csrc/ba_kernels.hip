@@ -1536,6 +1536,32 @@ void launch_cost_prior(hipStream_t s, int P, const double *xyz, const double *pr
                        double *res_out, double *partial, int blocks) {
   hipLaunchKernelGGL(k_cost_prior, dim3(blocks), dim3(256), 0, s, P, xyz, prior, isig, pt_file, res_out, partial);
 }
+// Small arrays gathered behind one large one (or scattered back), so that one reduction over the ranks covers them all
+__global__ void k_pack_segments(PackList l, double *__restrict__ packed, int gather) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int off = 0;
+#pragma unroll
+  for (int k = 0; k < BA_PACK_MAX; ++k) {
+    const int n = l.n[k];
+    if (t >= off && t < off + n) {
+      if (gather) packed[t] = l.ptr[k][t - off];
+      else l.ptr[k][t - off] = packed[t];
+    }
+    off += n;
+  }
+}
+void launch_pack_segments(hipStream_t s, const PackList &l, double *packed, int gather) {
+  int total = 0;
+  for (int k = 0; k < BA_PACK_MAX; ++k) total += l.n[k];
+  if (total > 0) hipLaunchKernelGGL(k_pack_segments, dim3(nblk(total, 256)), dim3(256), 0, s, l, packed, gather);
+}
+// out[slot] = flags[0] as a number (the flag travels with the maximum over the ranks)
+__global__ void k_flag_to_scal(const unsigned *__restrict__ flags, double *__restrict__ out, int slot) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[slot] = (double)flags[0];
+}
+void launch_flag_to_scal(hipStream_t s, const unsigned *flags, double *out, int slot) {
+  hipLaunchKernelGGL(k_flag_to_scal, dim3(1), dim3(64), 0, s, flags, out, slot);
+}
 void launch_sum_partials(hipStream_t s, const double *partial, int n, double *out, int slot) {
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, partial, n, out, slot);
 }

@@ -97,6 +97,9 @@ def lib():
         L.ba_net_dims.argtypes = [C.c_void_p, C.POINTER(BaDims)]
         L.ba_net_inputs.argtypes = [C.c_void_p, C.POINTER(BaInputs)]
         L.ba_net_set_free.argtypes = [C.c_void_p, C.c_uint16, C.c_uint8]
+        L.ba_net_point_ranges.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
+        L.ba_net_shard.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int64)]
         L.ba_net_write_inputs.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         L.ba_net_write_results.argtypes = [C.c_void_p, C.c_char_p, c_double_p]
         L.ba_net_set_variances.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]
@@ -188,6 +191,19 @@ class HostNetwork:
         d = self.dims
         n = {0: d.n_obs, 1: d.n_obs, 2: d.n_sta, 3: d.n_sta, 4: d.n_pts, 5: d.n_cam}[names[which]]
         return _arr(lib().ba_net_ids(self._h, names[which]), n, np.int32)
+
+    def point_ranges(self, world):
+        """[world+1] point boundaries of the ranks (ba_net_point_ranges)."""
+        b = (C.c_int64 * (world + 1))()
+        _check(lib().ba_net_point_ranges(self._h, world, b))
+        return np.array(b[:], dtype=np.int64)
+
+    def shard(self, rank, world):
+        """(HostNetwork of `rank`, slice of the point arrays it owns) -- ba_net_shard."""
+        h = C.c_void_p()
+        lo, hi = C.c_int64(), C.c_int64()
+        _check(lib().ba_net_shard(self._h, rank, world, C.byref(h), C.byref(lo), C.byref(hi)))
+        return HostNetwork(h.value), slice(lo.value, hi.value)
 
     def set_free(self, ap_free_mask, iop_free_mask=7):
         _check(lib().ba_net_set_free(self._h, ap_free_mask, iop_free_mask))

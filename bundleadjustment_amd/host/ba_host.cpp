@@ -540,6 +540,69 @@ const double *ba_net_truth_xyz(const ba_network *n) { return n->tXYZ.empty() ? n
 const double *ba_net_truth_iop(const ba_network *n) { return n->tIOP.empty() ? nullptr : n->tIOP.data(); }
 const double *ba_net_truth_ap(const ba_network *n) { return n->tAP.empty() ? nullptr : n->tAP.data(); }
 
+// Point boundaries of the ranks: contiguous ranges with about the same sum of (observations + 1) per rank.  The "+ 1"
+// stands for a point's own prior row and keeps ranges of unobserved points from collapsing.
+int ba_net_point_ranges(const ba_network *n, int32_t world, int64_t *bounds) {
+  if (!n || !bounds || world < 1) return fail(BA_ERR_INVALID, "ba_net_point_ranges: bad argument");
+  const int64_t P = static_cast<int64_t>(n->xyzTarget.size());
+  std::vector<int64_t> w(static_cast<size_t>(P), 1);
+  for (int32_t p : n->indexPoint) w[p]++;
+  for (int64_t p = 1; p < P; ++p) w[p] += w[p - 1];
+  const double total = P ? static_cast<double>(w[P - 1]) : 0.0;
+  bounds[0] = 0;
+  for (int32_t r = 1; r < world; ++r) {
+    const double target = total * r / world;
+    const int64_t b = std::lower_bound(w.begin(), w.end(), target,
+                                       [](int64_t a, double t) { return static_cast<double>(a) < t; }) - w.begin();
+    bounds[r] = std::max(b, bounds[r - 1]);
+  }
+  bounds[world] = P;
+  return 0;
+}
+
+// The sub-network of one rank: its point range with every observation of those points (file order kept), all stations
+// and cameras.  The station and camera unknowns are replicated; only the reduced camera system is summed over ranks.
+int ba_net_shard(const ba_network *n, int32_t rank, int32_t world, ba_network **out, int64_t *pt_lo, int64_t *pt_hi) {
+  if (!n || !out || world < 1 || rank < 0 || rank >= world) return fail(BA_ERR_INVALID, "ba_net_shard: bad argument");
+  std::vector<int64_t> b(static_cast<size_t>(world) + 1);
+  if (int rc = ba_net_point_ranges(n, world, b.data())) return rc;
+  const int64_t lo = b[rank], hi = b[rank + 1];
+  ba_network *s = new ba_network();
+  s->model = n->model;
+  s->eopStation = n->eopStation; s->eopCamera = n->eopCamera; s->EOP = n->EOP;
+  s->iopCamera = n->iopCamera; s->iopAxis = n->iopAxis;
+  s->iopXMin = n->iopXMin; s->iopYMin = n->iopYMin; s->iopXMax = n->iopXMax; s->iopYMax = n->iopYMax;
+  s->IOP = n->IOP; s->AP = n->AP;
+  s->staSensor = n->staSensor; s->iopPrior = n->iopPrior; s->iopStdDev = n->iopStdDev;
+  s->apFree = n->apFree; s->iopFree = n->iopFree;
+  s->tEOP = n->tEOP; s->tIOP = n->tIOP; s->tAP = n->tAP;
+  s->vEOP = n->vEOP; s->vIOP = n->vIOP; s->vAP = n->vAP;
+  auto cut = [&](const std::vector<double> &v, std::vector<double> &o, int per) {
+    if (!v.empty()) o.assign(v.begin() + per * lo, v.begin() + per * hi);
+  };
+  s->xyzTarget.assign(n->xyzTarget.begin() + lo, n->xyzTarget.begin() + hi);
+  cut(n->XYZ, s->XYZ, 3); cut(n->xyzPrior, s->xyzPrior, 3); cut(n->xyzStdDev, s->xyzStdDev, 3);
+  cut(n->tXYZ, s->tXYZ, 3); cut(n->vXYZ, s->vXYZ, 3);
+  const size_t N = n->indexPoint.size();
+  size_t cnt = 0;
+  for (size_t i = 0; i < N; ++i) cnt += (n->indexPoint[i] >= lo && n->indexPoint[i] < hi);
+  for (auto *v : {&s->imageTarget, &s->imageStation, &s->indexPoint, &s->indexPose}) v->reserve(cnt);
+  for (auto *v : {&s->imageX, &s->imageY, &s->imageXStdDev, &s->imageYStdDev, &s->imageXCorr, &s->imageYCorr}) v->reserve(cnt);
+  for (size_t i = 0; i < N; ++i) {
+    const int64_t p = n->indexPoint[i];
+    if (p < lo || p >= hi) continue;
+    s->imageTarget.push_back(n->imageTarget[i]); s->imageStation.push_back(n->imageStation[i]);
+    s->indexPoint.push_back(static_cast<int32_t>(p - lo)); s->indexPose.push_back(n->indexPose[i]);
+    s->imageX.push_back(n->imageX[i]); s->imageY.push_back(n->imageY[i]);
+    s->imageXStdDev.push_back(n->imageXStdDev[i]); s->imageYStdDev.push_back(n->imageYStdDev[i]);
+    s->imageXCorr.push_back(n->imageXCorr[i]); s->imageYCorr.push_back(n->imageYCorr[i]);
+  }
+  if (pt_lo) *pt_lo = lo;
+  if (pt_hi) *pt_hi = hi;
+  *out = s;
+  return 0;
+}
+
 const int32_t *ba_net_ids(const ba_network *n, int which) {
   switch (which) {
     case 0: return n->imageTarget.data();

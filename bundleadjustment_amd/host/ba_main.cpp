@@ -5,12 +5,82 @@
 // 4487-4504); here they are arguments.
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
 
+#include <atomic>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include "ba_gpu.h"
 #include "ba_host.h"
+
+// Reduction over the ranks through a file that all of them map (--comm shm): for machines with fewer GPUs than ranks
+// (RCCL wants one GPU per rank) and for tests.  Every rank copies its chunk into its own slot, waits for the others, and
+// adds the slots up in rank order -- the same sum in the same order everywhere, so the ranks stay bit-identical.
+struct ShmComm {
+  static constexpr int64_t kChunk = 1 << 16;
+  struct Header {
+    std::atomic<int> arrived;
+    std::atomic<int> generation;
+  };
+  Header *h = nullptr;
+  double *slots = nullptr;
+  int ranks = 1, rank = 0;
+  std::vector<double> host;
+
+  static size_t bytes(int ranks) { return 4096 + sizeof(double) * (size_t)kChunk * ranks; }
+  bool open(const std::string &path, int ranks_, int rank_) {
+    ranks = ranks_; rank = rank_;
+    int fd = -1;
+    if (rank == 0) {
+      const std::string tmp = path + ".tmp";
+      fd = ::open(tmp.c_str(), O_CREAT | O_TRUNC | O_RDWR, 0600);
+      if (fd < 0 || ftruncate(fd, (off_t)bytes(ranks)) != 0 || rename(tmp.c_str(), path.c_str()) != 0) return false;
+    } else {
+      for (int tries = 0; tries < 1200 && (fd = ::open(path.c_str(), O_RDWR)) < 0; ++tries) usleep(100000);
+      if (fd < 0) return false;
+    }
+    void *m = mmap(nullptr, bytes(ranks), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return false;
+    h = static_cast<Header *>(m);  // a new file is all zero: nobody has arrived, generation 0
+    slots = reinterpret_cast<double *>(static_cast<char *>(m) + 4096);
+    host.resize(kChunk);
+    return true;
+  }
+  void barrier() {
+    const int gen = h->generation.load();
+    if (h->arrived.fetch_add(1) + 1 == ranks) {
+      h->arrived.store(0);
+      h->generation.fetch_add(1);
+    } else {
+      while (h->generation.load() == gen) usleep(50);
+    }
+  }
+  static int reduce(void *user, double *dev, int64_t count, int32_t op, void *stream) {
+    ShmComm *c = static_cast<ShmComm *>(user);
+    for (int64_t o = 0; o < count; o += kChunk) {
+      const int64_t n = std::min<int64_t>(kChunk, count - o);
+      if (ba_copy_to_host(c->slots + (size_t)c->rank * kChunk, dev + o, n, stream)) return -1;
+      c->barrier();
+      for (int64_t k = 0; k < n; ++k) {
+        double v = c->slots[k];
+        for (int r = 1; r < c->ranks; ++r) {
+          const double w = c->slots[(size_t)r * kChunk + k];
+          v = op == 1 ? std::max(v, w) : v + w;
+        }
+        c->host[k] = v;
+      }
+      c->barrier();  // every rank has read the slots before any of them writes the next chunk
+      if (ba_copy_to_device(dev + o, c->host.data(), n, stream)) return -1;
+    }
+    return 0;
+  }
+};
 
 static void usage() {
   fprintf(stderr,
@@ -18,6 +88,8 @@ static void usage() {
           "               [--solver auto|dense|pcg|implicit] [--pcg-rtol X] [--max-iter N] [--covariance] [--model M]\n"
           "               [--bins B] [--truth file.xyz] [--iop-bounds]\n"
           "       ba_main --synth C S P RAYS [same options]\n"
+          "       ba_main ... --ranks N --rank R --id-file PATH [--comm rccl|shm]\n"
+          "                                          one process per GPU: start N of these, R = 0..N-1\n"
           "  MASK: bit k of --free-ap frees AP[k] (a1 a2 k1 k2 k3 p1 p2 ep1..ep9); default 0x4 = k1 only,\n"
           "        the reference's choice (src/main.cpp:4487-4504).  --free-iop: bits xp yp c, default 7.\n"
           "  --model: projection functor, 0 collinearity (default), 1 collinearity stereographic, 2 fisheye equidistant,\n"
@@ -28,6 +100,11 @@ static void usage() {
           "        of rows \"id X Y Z sX sY sZ\" (src/main.cpp:7242-7346).\n"
           "  --iop-bounds: the box on xp, yp, c from the sensor format columns of the .iop file, as the reference's\n"
           "        stereographic and fisheye branches set it (src/main.cpp:4252-4256); its collinearity branches set none.\n"
+          "  --ranks/--rank: rank R takes its share of the points (contiguous ranges balanced by observation count, all\n"
+          "        observations of those points; stations and cameras on every rank), uses GPU R modulo the GPUs that are\n"
+          "        visible, and the ranks sum the reduced camera system over RCCL.  Rank 0 writes the communicator's id to\n"
+          "        PATH, the others wait for it.  Every rank writes the results of its own points to DIR/rank<R>.\n"
+          "        --comm shm sums through a memory-mapped file at PATH instead (ranks on one machine that share GPUs).\n"
           "  --covariance: standard deviations of all parameters in the result files (the reference's COMPUTECX\n"
           "        branch, src/main.cpp:5261); small networks only.\n");
 }
@@ -38,7 +115,9 @@ int main(int argc, char **argv) {
   unsigned ap_mask = 0x4, iop_mask = 7;
   bool synth = false, covariance = false, iop_bounds = false;
   int model = 0, bins = 30;
-  std::string truth;
+  std::string truth, id_file, comm = "rccl";
+  ShmComm shm;
+  int ranks = 1, rank = 0;
   ba_options opt;
   ba_default_options(&opt);
   for (int i = 1; i < argc; ++i) {
@@ -59,6 +138,10 @@ int main(int argc, char **argv) {
     else if (a == "--model") model = atoi(next());
     else if (a == "--bins") bins = atoi(next());
     else if (a == "--truth") truth = next();
+    else if (a == "--ranks") ranks = atoi(next());
+    else if (a == "--rank") rank = atoi(next());
+    else if (a == "--id-file") id_file = next();
+    else if (a == "--comm") comm = next();
     else pos.push_back(a);
   }
   ba_network *net = nullptr;
@@ -80,6 +163,22 @@ int main(int argc, char **argv) {
     ba_net_set_free(net, (uint16_t)ap_mask, (uint8_t)iop_mask);
   }
   if (ba_net_set_model(net, model)) { fprintf(stderr, "error: %s\n", ba_host_last_error()); return 1; }
+  if (ranks < 1 || rank < 0 || rank >= ranks || (ranks > 1 && id_file.empty())) { usage(); return 2; }
+  if (ranks > 1) {
+    if (covariance) { fprintf(stderr, "error: --covariance is for one rank\n"); return 2; }
+    // this rank's points, all of their observations; the whole network is let go
+    ba_network *shard = nullptr;
+    int64_t lo = 0, hi = 0;
+    if (ba_net_shard(net, rank, ranks, &shard, &lo, &hi)) { fprintf(stderr, "error: %s\n", ba_host_last_error()); return 1; }
+    ba_net_free(net);
+    net = shard;
+    printf("    Rank %d of %d: points [%lld, %lld)\n", rank, ranks, (long long)lo, (long long)hi);
+    int32_t n_dev = 0;
+    ba_device_count(&n_dev);
+    if (n_dev < 1 || ba_set_device(rank % n_dev)) { fprintf(stderr, "error: no GPU for rank %d: %s\n", rank, ba_last_error()); return 1; }
+    out += "/rank" + std::to_string(rank);
+    if (system(("mkdir -p '" + out + "'").c_str()) != 0) { fprintf(stderr, "error: cannot create %s\n", out.c_str()); return 1; }
+  }
   ba_dims d;
   ba_inputs in;
   ba_net_dims(net, &d);
@@ -88,6 +187,29 @@ int main(int argc, char **argv) {
          d.n_obs, d.n_sta, d.n_cam, d.n_pts);
   ba_problem *p = nullptr;
   if (ba_create(&d, &in, &p)) { fprintf(stderr, "error: %s\n", ba_last_error()); return 1; }
+  if (ranks > 1 && comm == "shm") {
+    if (!shm.open(id_file, ranks, rank)) { fprintf(stderr, "error: cannot map %s\n", id_file.c_str()); return 1; }
+    if (ba_set_allreduce(p, ShmComm::reduce, &shm)) { fprintf(stderr, "error: %s\n", ba_last_error()); return 1; }
+  } else if (ranks > 1) {
+    // the id of the communicator travels through a file: written under another name and renamed, so that a reader
+    // never sees half of it
+    unsigned char id[128];
+    if (rank == 0) {
+      if (ba_rccl_unique_id(id)) { fprintf(stderr, "error: %s\n", ba_last_error()); return 1; }
+      const std::string tmp = id_file + ".tmp";
+      FILE *f = fopen(tmp.c_str(), "wb");
+      if (!f || fwrite(id, 1, sizeof id, f) != sizeof id || fclose(f) != 0 || rename(tmp.c_str(), id_file.c_str()) != 0) {
+        fprintf(stderr, "error: cannot write %s\n", id_file.c_str());
+        return 1;
+      }
+    } else {
+      FILE *f = nullptr;
+      for (int tries = 0; tries < 1200 && !(f = fopen(id_file.c_str(), "rb")); ++tries) usleep(100000);
+      if (!f || fread(id, 1, sizeof id, f) != sizeof id) { fprintf(stderr, "error: no communicator id in %s\n", id_file.c_str()); return 1; }
+      fclose(f);
+    }
+    if (ba_use_rccl(p, ranks, rank, id)) { fprintf(stderr, "error: %s\n", ba_last_error()); return 1; }
+  }
   if (iop_bounds) {
     std::vector<double> lo(3 * (size_t)d.n_cam), hi(3 * (size_t)d.n_cam);
     ba_net_iop_bounds(net, lo.data(), hi.data());
@@ -100,12 +222,12 @@ int main(int argc, char **argv) {
     return 1;
   }
   // the table ceres prints with minimizer_progress_to_stdout (src/main.cpp:4711)
-  printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius  ls_iter\n");
-  for (int i = 0; i < sm.num_iterations && i < (int)rows.size(); ++i)
+  if (rank == 0) printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius  ls_iter\n");
+  for (int i = 0; rank == 0 && i < sm.num_iterations && i < (int)rows.size(); ++i)
     printf("%4d  %.6e  %9.2e  %9.2e  %9.2e  %9.2e  %9.2e  %6d\n", rows[i].iteration, rows[i].cost, rows[i].cost_change,
            rows[i].gradient_max_norm, rows[i].step_norm, rows[i].relative_decrease, rows[i].trust_region_radius,
            rows[i].linear_iterations);
-  printf("Initial cost %.6e  Final cost %.6e  Termination %s\n", sm.initial_cost, sm.final_cost,
+  if (rank == 0) printf("Initial cost %.6e  Final cost %.6e  Termination %s\n", sm.initial_cost, sm.final_cost,
          sm.termination == BA_CONVERGENCE ? "CONVERGENCE" : sm.termination == BA_NO_CONVERGENCE ? "NO_CONVERGENCE" : "FAILURE");
   if (covariance) {
     std::vector<double> ve(6 * (size_t)d.n_sta + 1), vx(3 * (size_t)d.n_pts + 1), vi(3 * (size_t)d.n_cam + 1), va(16 * (size_t)d.n_cam + 1);
@@ -132,9 +254,11 @@ int main(int argc, char **argv) {
   // quantile lines (:4905-5137), the reprojection errors (:6982-6984), the result files, the QC against truth (:7242)
   ba_report rep;
   std::vector<ba_bin_stats> bin_stats(bins > 0 ? bins : 1);
+  // (several ranks: the statistics mix counts of the whole network with those of the shard, so they are left out)
   if (ba_net_write_angles(net, out.c_str()) ||
-      ba_net_report(net, &sm, res.data(), (int64_t)res.size(), bins > 0 ? bins : 0, &rep, bin_stats.data()) ||
-      ba_net_print_report(net, &rep, bin_stats.data(), nullptr) || ba_net_write_results(net, out.c_str(), res.data())) {
+      (ranks == 1 && (ba_net_report(net, &sm, res.data(), (int64_t)res.size(), bins > 0 ? bins : 0, &rep, bin_stats.data()) ||
+                      ba_net_print_report(net, &rep, bin_stats.data(), nullptr))) ||
+      ba_net_write_results(net, out.c_str(), res.data())) {
     fprintf(stderr, "error: %s\n", ba_host_last_error());
     return 1;
   }

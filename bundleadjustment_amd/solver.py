@@ -22,6 +22,7 @@ EXPORTS = ("ba_default_options", "ba_create", "ba_destroy", "ba_set_parameters",
            "ba_set_iop_bounds", "ba_line_search_contract",
            "ba_solve_resident", "ba_solve", "ba_evaluate", "ba_covariance", "ba_sparsity", "ba_residual_jacobian", "ba_time_kernel",
            "ba_set_allreduce", "ba_copy_to_host", "ba_copy_to_device", "ba_rccl_unique_id", "ba_use_rccl", "ba_evaluate_noalloc",
+           "ba_device_count", "ba_set_device", "ba_reduction_timing", "ba_reduction_stats",
            "ba_last_error")
 
 
@@ -67,6 +68,10 @@ def lib():
         L.ba_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.ba_copy_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.ba_rccl_unique_id.argtypes = [C.c_void_p]
+        L.ba_device_count.argtypes = [C.POINTER(C.c_int32)]
+        L.ba_reduction_timing.argtypes = [C.c_void_p, C.c_int32]
+        L.ba_reduction_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.ba_set_device.argtypes = [C.c_int32]
         L.ba_use_rccl.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.ba_evaluate_noalloc.argtypes = [C.POINTER(BaDims), C.POINTER(BaInputs)] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 3
         _lib = L
@@ -232,6 +237,15 @@ class Problem:
             return 0
         self.set_allreduce(cb)
 
+    def reduction_timing(self, on=True):
+        _check(lib().ba_reduction_timing(self._h, int(bool(on))))
+
+    def reduction_stats(self):
+        """(calls, bytes, seconds on the stream) of the reductions over the ranks since the last call; resets them."""
+        n, b, t = C.c_int64(), C.c_double(), C.c_double()
+        _check(lib().ba_reduction_stats(self._h, C.byref(n), C.byref(b), C.byref(t)))
+        return n.value, b.value, t.value
+
     def use_rccl(self, n_ranks, rank, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, 128)
         _check(lib().ba_use_rccl(self._h, n_ranks, rank, buf))
@@ -241,6 +255,17 @@ def evaluate_noalloc(dims, inputs, eop, xyz, iop, ap, apply_loss, cost, residual
     """ba_evaluate_noalloc: every pointer (those inside `inputs` too) is a device address, given as an int; cost [2] and
     residuals are device outputs.  Queues kernels on `stream` (a hipStream_t as int, None = default) and returns."""
     _check(lib().ba_evaluate_noalloc(C.byref(dims), C.byref(inputs), eop, xyz, iop, ap, int(bool(apply_loss)), cost, residuals, stream))
+
+
+def device_count() -> int:
+    n = C.c_int32()
+    _check(lib().ba_device_count(C.byref(n)))
+    return n.value
+
+
+def set_device(device: int):
+    """The GPU of the calling thread: before the first Problem of a process that owns one GPU of several."""
+    _check(lib().ba_set_device(int(device)))
 
 
 def rccl_unique_id() -> bytes:

@@ -310,6 +310,11 @@ int ba_residual_jacobian(ba_problem *p, double *r, double *J);
  */
 int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *seconds_per_launch);
 
+/* The GPU of the calling thread (one process per GPU picks its own before ba_create), for hosts that do not link the HIP
+ * runtime themselves.  No counterpart in the reference. */
+int ba_device_count(int32_t *count);
+int ba_set_device(int32_t device);
+
 /*
  * Multi-GPU: a problem built from one shard of the points (and all observations of those
  * points) takes part in a sum over ranks of the reduced camera system.  Stations and
@@ -325,6 +330,16 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
 typedef int (*ba_allreduce_fn)(void *user, double *device_buf, int64_t count, int32_t op,
                                void *hip_stream);
 int ba_set_allreduce(ba_problem *p, ba_allreduce_fn fn, void *user);
+
+/* What the reductions cost this rank.  ba_reduction_stats returns, for the calls of the callback since the last
+ * ba_reduction_stats: their number, the bytes they carried and -- while ba_reduction_timing is on -- the time they took
+ * on the solver's stream between events recorded before and after each (a collective also waits for the slowest rank,
+ * so load imbalance shows here); it waits for the stream and resets the three.  A solve makes four calls per LM
+ * iteration with the dense and the block-sparse PCG solvers: station sums + camera rows + cost, gradient maximum +
+ * not-positive-definite flag, reduced matrix + camera border, step sums + candidate cost.  The matrix-free PCG adds one
+ * per inner iteration, a bounded solve those of its line search. */
+int ba_reduction_timing(ba_problem *p, int32_t on);
+int ba_reduction_stats(ba_problem *p, int64_t *count, double *bytes, double *seconds);
 
 /* Helpers for callbacks that stage through host memory (e.g. a gloo or MPI reduction in tests):
  * synchronous copies ordered after the work already queued on hip_stream. */

@@ -57,6 +57,14 @@ void ba_net_free(ba_network *net);
 int ba_net_dims(const ba_network *net, ba_dims *dims);
 /* Fills *in with pointers into the network's own storage (valid until ba_net_free). */
 int ba_net_inputs(ba_network *net, ba_inputs *in);
+/* Partition of a network over the ranks of a multi-GPU solve (one process per GPU).  Points are independent given the
+ * station and camera unknowns, so rank r gets the contiguous point range [bounds[r], bounds[r+1]) -- balanced by
+ * observations + 1 per point -- with every observation of those points; stations and cameras are replicated and the
+ * ranks only sum the reduced camera system (ba_set_allreduce / ba_use_rccl in ba_gpu.h).  No counterpart in the
+ * reference, which runs ceres::Solve (src/main.cpp:4721) in one process.  bounds has world + 1 entries. */
+int ba_net_point_ranges(const ba_network *net, int32_t world, int64_t *bounds);
+/* New network (ba_net_free it) holding rank's points and observations; pt_lo/pt_hi (optional) = its range in `net`. */
+int ba_net_shard(const ba_network *net, int32_t rank, int32_t world, ba_network **out, int64_t *pt_lo, int64_t *pt_hi);
 /* Parameter arrays, updated in place by the caller after a solve: [6S], [3P], [3C], [16C]. */
 double *ba_net_eop(ba_network *net);
 double *ba_net_xyz(ba_network *net);

@@ -74,3 +74,37 @@ def test_point_ranges_balance_and_cover(world):
     assert max(counts) - min(counts) <= 2 * 4 + 2  # within a couple of points of each other
     total_pts = sum(sharding.shard_network(net, r, world)[0].n_pts for r in range(world))
     assert total_pts == net.n_pts
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_host_library_shards_like_the_python_partition(world):
+    """ba_net_point_ranges / ba_net_shard (the C++ host's own path) against sharding.shard_network."""
+    hn = host.synth(n_cam=2, n_sta=20, n_pts=501, rays_per_point=4, seed=2)
+    net = hn.net
+    assert np.array_equal(hn.point_ranges(world), sharding.point_ranges(net.obs_pt, net.n_pts, world))
+    for rank in range(world):
+        sh, sl = hn.shard(rank, world)
+        ref, rsl = sharding.shard_network(net, rank, world)
+        assert (sl.start, sl.stop) == (rsl.start, rsl.stop)
+        for f in ("obs_pt", "obs_sta", "sta_cam", "obs_x", "obs_y", "obs_sx", "obs_sy", "obs_cx", "obs_cy", "pt_prior", "pt_sigma",
+                  "iop_prior", "iop_sigma", "ap_free_mask", "iop_free_mask", "eop", "xyz", "iop", "ap"):
+            a, b = getattr(sh.net, f), getattr(ref, f)
+            assert np.array_equal(np.asarray(a).reshape(-1), np.asarray(b).reshape(-1)), f
+        assert sh.net.model == ref.model and sh.net.huber_a == ref.huber_a
+        # the ids of the shard's records are those of the records it took
+        sel = (net.obs_pt >= sl.start) & (net.obs_pt < sl.stop)
+        assert np.array_equal(sh.ids("pho_target"), hn.ids("pho_target")[sel])
+        assert np.array_equal(sh.ids("xyz_target"), hn.ids("xyz_target")[sl])
+        assert np.array_equal(sh.net.truth["xyz"], net.truth["xyz"][sl])
+        sh.close()
+
+
+def test_shard_of_points_without_observations():
+    """Unobserved points weigh one unit each, so ranges stay non-degenerate; bad arguments are refused."""
+    hn = host.synth(n_cam=1, n_sta=6, n_pts=40, rays_per_point=3, seed=5)
+    b = hn.point_ranges(4)
+    assert b[0] == 0 and b[-1] == 40 and np.all(np.diff(b) > 0)
+    with pytest.raises(RuntimeError):
+        hn.shard(4, 4)
+    with pytest.raises(RuntimeError):
+        hn.point_ranges(0)

@@ -51,7 +51,10 @@ def _worker(rank, world, port, ls, n_cam, out, bounded=False):
     net = _make_net(n_cam)
     shard, sl = sharding.shard_network(net, rank, world)
 
+    calls = []
+
     def reduce_fn(buf, op):
+        calls.append(buf.size)
         t = torch.from_numpy(buf)
         dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
 
@@ -60,7 +63,9 @@ def _worker(rank, world, port, ls, n_cam, out, bounded=False):
         if bounded:
             P.set_iop_bounds(*_box(net))
         opt = _options(ls, bounded)
+        n_setup = len(calls)
         eop, xyz, iop, ap, sm, rows = P.solve(opt)
+        sm["reductions_in_solve"] = len(calls) - n_setup
     gathered = [None] * world
     dist.all_gather_object(gathered, (sl.start, sl.stop, xyz))
     if rank == 0:
@@ -96,6 +101,47 @@ def test_two_ranks_match_oracle(ls, n_cam, bounded):
               "num_residuals"):
         g[4][k] = o[4][k]
     assert_solve_parity(tuple(g), o)
+    if ls != 2 and not bounded:
+        # dense and block-sparse PCG: two reductions in the linearisation (sums, maxima), one for the reduced system,
+        # one for the step phase -- four per LM iteration; the Jacobi scaling pass and the parameter norm of iteration zero add four to the solve.  (The matrix-free PCG sums once per inner iteration; a bounded solve adds its
+        # line search.)
+        assert res[4]["reductions_in_solve"] <= 4 * len(res[5]) + 4, (res[4]["reductions_in_solve"], len(res[5]))
+
+
+def test_two_ranks_of_the_command_line_program(tmp_path):
+    """ba_main --ranks 2: two processes on the one GPU, summing through a mapped file (RCCL wants a GPU per rank), against
+    the one-rank run of the same files."""
+    import subprocess
+    from bundleadjustment_amd import build, host
+    hn = host.synth(n_cam=1, n_sta=40, n_pts=300, rays_per_point=5, seed=9, ap_free_mask=host.AP_K1K2P1P2)
+    hn.write_inputs(str(tmp_path), "net")
+    paths = [str(tmp_path / ("net." + e)) for e in ("pho", "eop", "iop", "xyz")]
+    common = paths + ["--free-ap", hex(host.AP_K1K2P1P2), "--solver", "pcg", "--bins", "0"]
+    one = tmp_path / "one"
+    one.mkdir()
+    r1 = subprocess.run([build.MAIN_BIN] + common + ["--out", str(one)], capture_output=True, text=True, timeout=240)
+    assert r1.returncode == 0, r1.stderr
+    two = tmp_path / "two"
+    two.mkdir()
+    idf = str(tmp_path / "rccl.id")
+    procs = [subprocess.Popen([build.MAIN_BIN] + common + ["--out", str(two), "--ranks", "2", "--rank", str(r), "--id-file", idf, "--comm", "shm"],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se
+    assert "Termination CONVERGENCE" in outs[0][0]
+    # stations and cameras are replicated: every rank writes the same station file, equal to the one-rank run's to the
+    # accuracy of a sum taken in another order
+    e1 = np.loadtxt(one / "EOP.jck", ndmin=2)
+    for r in range(2):
+        e2 = np.loadtxt(two / ("rank%d" % r) / "EOP.jck", ndmin=2)
+        assert e2.shape == e1.shape
+        assert np.allclose(e2, e1, rtol=1e-9, atol=1e-9)
+    # the points: the two shards together are the one-rank file
+    x1 = np.loadtxt(one / "XYZ.jck", ndmin=2)
+    x2 = np.vstack([np.loadtxt(two / ("rank%d" % r) / "XYZ.jck", ndmin=2) for r in range(2)])
+    assert x2.shape == x1.shape and np.array_equal(x2[:, 0], x1[:, 0])
+    assert np.allclose(x2[:, 1:4], x1[:, 1:4], rtol=1e-9, atol=1e-9)
 
 
 def test_rccl_single_rank():
