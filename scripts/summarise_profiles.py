@@ -1,5 +1,5 @@
 """Turns the rocprofv3 output of one round (kernel statistics of `bench.py`, and the FETCH_SIZE and WRITE_SIZE passes of
-`scripts/dev_bench.py cfg4 1.0 2`) into the files kept under profiles/: the kernel-statistics table, the per-kernel
+`scripts/pmc_workload.py cfg4 1.0 2`) into the files kept under profiles/: the kernel-statistics table, the per-kernel
 traffic table, and pmc_traffic.json, which bench.py reads for roofline.traffic.
 
     python scripts/summarise_profiles.py r01e gpurun_out/prof_r01e gpurun_out/pmc_fetch gpurun_out/pmc_write
@@ -59,7 +59,7 @@ kernels["linearisation (k_point_elim + k_obs_rows)"] = {
     "bytes_per_launch": kernels["k_point_elim"]["bytes_per_launch"] + kernels["k_obs_rows"]["bytes_per_launch"],
     "note": "k_point_elim + k_obs_rows"}
 out = {"config": "cfg4",
-       "source": f"profiles/{tag}_pmc_fetch_write_cfg4.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, scripts/dev_bench.py cfg4 1.0 2)",
+       "source": f"profiles/{tag}_pmc_fetch_write_cfg4.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, scripts/pmc_workload.py cfg4 1.0 2)",
        "correction": "FETCH_SIZE doubled for kernels whose dominant reads are 16 B per lane (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE as reported; KB = 1024 B; Infinity-Cache hits are included in FETCH_SIZE",
        "kernels": kernels}
 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
