@@ -6,8 +6,8 @@
 // a-posteriori covariance (src/main.cpp:5261-5279) needs the inverse of the same matrix.
 //
 // Right-looking, panel width CB = 128, three launches per panel:
-//   1. k_chol_diag : the 128 x 128 diagonal block in LDS (one workgroup): left-looking Cholesky, then its inverse W
-//                    in place (kept: the triangular solves use it too);
+//   1. k_chol_diag : the 128 x 128 diagonal block in LDS (one workgroup): Cholesky over block columns of 16 with the
+//                    sums on the matrix cores, then its inverse W in place (kept: the triangular solves use it too);
 //   2. k_gemm_nt<TRSM> : rows below the block, X = A_panel W^T -- the triangular solve as a product;
 //   3. k_gemm_nt<SYRK> : trailing update C -= X X^T over the 128 x 128 tiles of the lower triangle.
 // One product kernel serves all of it: a 256-thread workgroup per 128 x 128 tile of C = beta C + alpha A B^T (both
@@ -169,83 +169,121 @@ k_gemm_nt(GemmArgs g) {
     gemm_tile_nt(g.U, ld, r0, n, g.U, ld, c0, n, CB * ti, n, sA, sB, acc);
     C = g.A;
   }
-  // C layout of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4 * reg
+  // C layout of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4 * reg.
+  // Sixteen entries at a time: their old values are all requested before the first is needed (one wait per sixteen
+  // instead of one per entry -- a tile of the trailing update sits on the critical path of the next panel).  Addresses
+  // are clamped into the matrix so that the loads need no branch; the stores are predicated.
+  constexpr bool accumulate = MODE == GEMM_SYRK;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < 4; ++a) {
+    double *dst[4][4];
+    double old[4][4];
+    bool ok[4][4];
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int r = r0 + 64 * wr + 16 * a + lk + 4 * reg;
-      if (r >= rmax) continue;
+    for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const int cc = c0 + 64 * wc + 16 * c + lr;
-        if (cc >= cmax || (lower_only && cc > r)) continue;
-        double *dst = C + (int64_t)r * ldc + cc;
-        const double v = alpha * acc[a][c][reg];
-        *dst = (beta != 0.0) ? beta * *dst + v : v;
-        if (MODE == GEMM_INV_S && cc != r) C[(int64_t)cc * ldc + r] = v;  // the inverse is returned as a full symmetric matrix
+        const int r = r0 + 64 * wr + 16 * a + lk + 4 * reg, cc = c0 + 64 * wc + 16 * c + lr;
+        ok[reg][c] = r < rmax && cc < cmax && !(lower_only && cc > r);
+        dst[reg][c] = C + (int64_t)min(r, rmax - 1) * ldc + min(cc, cmax - 1);
+        old[reg][c] = accumulate ? *dst[reg][c] : 0.0;
       }
-    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (!ok[reg][c]) continue;
+        const double v = alpha * acc[a][c][reg];
+        *dst[reg][c] = accumulate ? beta * old[reg][c] + v : v;
+        if (MODE == GEMM_INV_S) {  // the inverse is returned as a full symmetric matrix
+          const int r = r0 + 64 * wr + 16 * a + lk + 4 * reg, cc = c0 + 64 * wc + 16 * c + lr;
+          if (cc != r) C[(int64_t)cc * ldc + r] = v;
+        }
+      }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // diagonal block: Cholesky and inverse in LDS
 // ------------------------------------------------------------------------------------------------------------------
-// One workgroup, the 128 x 128 block in LDS (rows beyond the matrix are identity rows).  Both sweeps advance EIGHT
-// columns at a time.  Four threads own a PAIR of rows and a quarter of the summation range each: a thread sums a
-// 2 x 8 tile of dot products against the finished part (16-byte LDS reads: 10 reads per 32 multiply-adds), the quarters
-// are folded by lane swaps, and the 8 x 8 diagonal piece is factored / inverted redundantly in the registers of every
-// thread.  Two barriers per eight columns instead of two per column.
-#define TS (CB + 2)  // even: every row starts on a 16-byte boundary
-#define SB 8         // columns per step
+// One workgroup of four waves, the 128 x 128 block row-major in LDS (rows beyond the matrix are identity rows).
+//   Factorisation, left-looking over block columns of 16: the tiles of a block column take the sum over the finished
+//   columns on the matrix cores (operands straight from the row-major block: with a row stride of 130 doubles the 32
+//   lanes of a half wave hit 32 different banks); its 16 x 16 diagonal tile is factored by one wave, a lane per row,
+//   pivots and column entries handed round by DPP row broadcasts (no LDS round trip inside the chain of 16 pivots), and
+//   inverted in the same instruction stream (the inverse's steps fill the waits of the pivot chain), while the other
+//   three waves already sum for the next block column; the tiles below become X = P W^T, again on the matrix cores.
+//   Inverse: the 16 x 16 inverses are merged pairwise, 16 -> 32 -> 64 -> 128,
+//   [L11 0; L21 L22]^-1 = [W11 0; -W22 (L21 W11), W22], two products per level over 16 x 16 tiles, in place.
+#define TS (CB + 2)  // even (16-byte aligned rows) and = 2 mod 32 (conflict-free operand reads)
+#define WS 18        // row stride of the saved 16 x 16 inverses
 
-// Cholesky of the 8 x 8 lower triangle D (row-major) in registers; il = reciprocals of the diagonal of the factor;
-// bad = index of the first pivot that is not positive
-__device__ __forceinline__ void chol8(const double *D, double (&L)[SB][SB], double (&il)[SB], int &bad) {
-  bad = -1;
+// lane J of every row of 16 lanes, in all lanes of that row (DPP row_newbcast: one VALU move per 32 bits, the result
+// stays in vector registers)
+template <int J>
+__device__ __forceinline__ double bcast16(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + J, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + J, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bcast16(double v, int j) {  // j is a constant after unrolling: the switch folds away
+  switch (j) {
+    case 0: return bcast16<0>(v);
+    case 1: return bcast16<1>(v);
+    case 2: return bcast16<2>(v);
+    case 3: return bcast16<3>(v);
+    case 4: return bcast16<4>(v);
+    case 5: return bcast16<5>(v);
+    case 6: return bcast16<6>(v);
+    case 7: return bcast16<7>(v);
+    case 8: return bcast16<8>(v);
+    case 9: return bcast16<9>(v);
+    case 10: return bcast16<10>(v);
+    case 11: return bcast16<11>(v);
+    case 12: return bcast16<12>(v);
+    case 13: return bcast16<13>(v);
+    case 14: return bcast16<14>(v);
+    default: return bcast16<15>(v);
+  }
+}
+
+// acc += X[rows of xa][k] Y[rows of xb][k] over k in [kb, ke), both operands row-major in LDS (pointers at row lr, column
+// lk); ke - kb is a multiple of 16: the twelve operand reads of sixteen columns are issued before their products
+__device__ __forceinline__ void mfma_nt16(const double *xa, const double *xb, int kb, int ke, d4 &acc) {
+  for (int k = kb; k < ke; k += 16) {
+    double a[4], b[4];
 #pragma unroll
-  for (int j = 0; j < SB; ++j) {
-    double d = D[j * SB + j];
-#pragma unroll
-    for (int k = 0; k < SB; ++k)
-      if (k < j) d -= L[j][k] * L[j][k];
-    if (!(d > 0.0) && bad < 0) bad = j;
-    // 1 / sqrt(d) from the hardware estimate and two Newton steps (nine dependent operations; the IEEE square root
-    // and division of the compiler are five times as long, and this chain of 128 pivots is the kernel's critical path)
-    double y = __builtin_amdgcn_rsq(d);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const double e = fma(-(d * y), y, 1.0);
-      y = fma(0.5 * y, e, y);
+    for (int u = 0; u < 4; ++u) {
+      a[u] = xa[k + 4 * u];
+      b[u] = xb[k + 4 * u];
     }
-    il[j] = y;
-    L[j][j] = d * y;
 #pragma unroll
-    for (int i = 0; i < SB; ++i)
-      if (i > j) {
-        double v = D[i * SB + j];
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+  }
+}
+// the same for X[rows][k] B[k][columns]: pb at row lk, column lr of B
+__device__ __forceinline__ void mfma_nn16(const double *xa, const double *pb, int kb, int ke, d4 &acc) {
+  for (int k = kb; k < ke; k += 16) {
+    double a[4], b[4];
 #pragma unroll
-        for (int k = 0; k < SB; ++k)
-          if (k < j) v -= L[i][k] * L[j][k];
-        L[i][j] = v * il[j];
-      }
+    for (int u = 0; u < 4; ++u) {
+      a[u] = xa[k + 4 * u];
+      b[u] = pb[(k + 4 * u) * TS];
+    }
 #pragma unroll
-    for (int i = 0; i < SB; ++i)
-      if (i < j) L[i][j] = 0.0;
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
   }
 }
 
 __global__ void __launch_bounds__(256)
 k_chol_diag(double *__restrict__ A, int n, int ld, int k0, double *__restrict__ Wk, int *__restrict__ info) {
-  extern __shared__ double Tm[];   // CB x TS
-  double *Db = Tm + CB * TS;       // SB x SB: the diagonal piece of a step
-  double *Cb = Db + SB * SB;       // (CB - SB) x SB: the old column block of the inversion sweep
-  double *invd = Cb + (CB - SB) * SB;  // CB: reciprocals of the diagonal of the factor
+  extern __shared__ double Tm[];  // CB x TS
+  double *Wd = Tm + CB * TS;      // 8 x (16 x WS): inverses of the diagonal 16 x 16 tiles
   const int kw = min(CB, n - k0);
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, lr = lane & 15, lk = lane >> 4;
+  const int NT = CB / 16;
   {
-    // half a row per thread, eight 16-byte loads in flight at a time (a loop of single guarded loads would wait for
-    // every one of them in turn)
+    // half a row per thread, eight 16-byte loads in flight at a time
     const int r = t >> 1, cb = 64 * (t & 1);
     const double *src = A + (int64_t)(k0 + r) * ld + k0 + cb;
 #pragma unroll
@@ -265,165 +303,165 @@ k_chol_diag(double *__restrict__ A, int n, int ld, int k0, double *__restrict__ 
     }
   }
   __syncthreads();
-  const int rp = t >> 2, q = t & 3;   // four threads per pair of rows
-  const int ra = 2 * rp, rb = ra + 1;
-  // ---- factorisation, left-looking, SB columns per step
-  for (int j0 = 0; j0 < CB; j0 += SB) {
-    double acc[2][SB];
+  // Sums of the NEXT block column over all finished columns but the last sixteen, held by waves 1..3 (tile m of the
+  // block column in wave 1 + m % 3, slot m / 3): they are formed while wave 0 factors the current diagonal tile.
+  d4 ahead[3];
 #pragma unroll
-    for (int c = 0; c < SB; ++c) acc[0][c] = acc[1][c] = 0.0;
-    if (ra >= j0) {
-      const int kq = j0 / 4, kb = q * kq, ke = kb + kq;  // j0 is a multiple of 8: even quarters
-      const double *pa = Tm + ra * TS, *pb = Tm + rb * TS, *pj = Tm + j0 * TS;
-      for (int k = kb; k < ke; k += 2) {
-        const double2 a0 = *reinterpret_cast<const double2 *>(pa + k), a1 = *reinterpret_cast<const double2 *>(pb + k);
+  for (int sl = 0; sl < 3; ++sl) ahead[sl] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int J = 0; J < NT; ++J) {
+    const int c0 = 16 * J;
+    // ---- 1. tiles (I, J), I >= J: minus the sum over the finished columns
+    if (J > 0) {
+      if (w > 0) {
 #pragma unroll
-        for (int c = 0; c < SB; ++c) {
-          const double2 b = *reinterpret_cast<const double2 *>(pj + c * TS + k);
-          acc[0][c] += a0.x * b.x + a0.y * b.y;
-          acc[1][c] += a1.x * b.x + a1.y * b.y;
-        }
-      }
-    }
+        for (int sl = 0; sl < 3; ++sl) {
+          const int I = J + (w - 1) + 3 * sl;
+          if (I < NT) {
+            d4 acc = ahead[sl];
+            mfma_nt16(Tm + (16 * I + lr) * TS + lk, Tm + (c0 + lr) * TS + lk, c0 - 16, c0, acc);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int c = 0; c < SB; ++c) {
-        acc[i][c] += __shfl_xor(acc[i][c], 1, 64);
-        acc[i][c] += __shfl_xor(acc[i][c], 2, 64);
-      }
-    double v[2][SB];
-    if (q == 0 && ra >= j0) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int c = 0; c < SB; ++c) v[i][c] = Tm[(ra + i) * TS + j0 + c] - acc[i][c];
-      if (ra < j0 + SB)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int c = 0; c < SB; ++c) Db[(ra + i - j0) * SB + c] = v[i][c];
-    }
-    __syncthreads();
-    double Lb[SB][SB], il[SB];
-    int bad;
-    chol8(Db, Lb, il, bad);
-    if (t == 0) {
-      if (bad >= 0 && j0 + bad < kw) atomicMax(info, k0 + j0 + bad + 1);
-#pragma unroll
-      for (int c = 0; c < SB; ++c) invd[j0 + c] = il[c];
-    }
-    if (q == 0 && ra >= j0) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = ra + i;
-        double x[SB];
-        if (row < j0 + SB) {
-#pragma unroll
-          for (int c = 0; c < SB; ++c) {
-            x[c] = 0.0;
-#pragma unroll
-            for (int m = 0; m < SB; ++m)
-              if (m == row - j0) x[c] = Lb[m][c];
-          }
-        } else {
-          // x Lb^T = v
-#pragma unroll
-          for (int c = 0; c < SB; ++c) {
-            double sdot = v[i][c];
-#pragma unroll
-            for (int k = 0; k < SB; ++k)
-              if (k < c) sdot -= x[k] * Lb[c][k];
-            x[c] = sdot * il[c];
+            for (int reg = 0; reg < 4; ++reg) Tm[(16 * I + lk + 4 * reg) * TS + c0 + lr] -= acc[reg];
           }
         }
+      }
+      __syncthreads();
+    }
+    // ---- 2. the diagonal tile: factor and invert, wave 0, lane lr = row lr (the four rows of 16 lanes do the same);
+    //         the others sum ahead for block column J + 1
+    if (w == 0) {
+      double r[16];
+      {
+        const double2 *row = reinterpret_cast<const double2 *>(Tm + (c0 + lr) * TS + c0);
 #pragma unroll
-        for (int c = 0; c < SB; ++c) Tm[row * TS + j0 + c] = x[c];
+        for (int c = 0; c < 8; ++c) {
+          const double2 v = row[c];
+          r[2 * c] = v.x;
+          r[2 * c + 1] = v.y;
+        }
+      }
+      int bad = -1;
+      double ili = 1.0;  // 1 / L[lr][lr]
+      double sacc[16];   // inverse, row lr in this lane: W[i][c] = (delta_ic - sum_{k = c}^{i-1} L[i][k] W[k][c]) / L[i][i]
+#pragma unroll
+      for (int c = 0; c < 16; ++c) sacc[c] = 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const double d = bcast16(r[j], j);
+        if (!(d > 0.0) && bad < 0) bad = j;
+        // 1 / sqrt(d): hardware estimate and two Newton steps (the IEEE square root and division are five times as
+        // long, and the chain of pivots is the critical path of the whole factorisation)
+        double y = __builtin_amdgcn_rsq(d);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const double e = fma(-(d * y), y, 1.0);
+          y = fma(0.5 * y, e, y);
+        }
+        if (lr == j) ili = y;
+        const double lij = (lr > j) ? r[j] * y : (lr == j ? d * y : 0.0);
+        r[j] = lij;
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) r[c] = fma(-lij, bcast16(lij, c), r[c]);
+        // step j of the inverse (column j of L is final): it fills the waits of the next pivot's chain
+        if (j < 15) {
+          const double lik = (lr > j) ? lij : 0.0;
+#pragma unroll
+          for (int c = 0; c <= j; ++c) {
+            const double mine = ili * ((lr == c ? 1.0 : 0.0) - sacc[c]);  // final in lane j: all its terms are in
+            sacc[c] = fma(lik, bcast16(mine, j), sacc[c]);
+          }
+        }
+      }
+      if (lane == 0 && bad >= 0 && c0 + bad < kw) atomicMax(info, k0 + c0 + bad + 1);
+      if (lk == 0) {
+        double2 *lrow = reinterpret_cast<double2 *>(Tm + (c0 + lr) * TS + c0), *wrow = reinterpret_cast<double2 *>(Wd + (16 * J + lr) * WS);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int ca = 2 * c, cb = 2 * c + 1;
+          lrow[c] = make_double2(ca <= lr ? r[ca] : 0.0, cb <= lr ? r[cb] : 0.0);
+          wrow[c] = make_double2(ca <= lr ? ili * ((lr == ca ? 1.0 : 0.0) - sacc[ca]) : 0.0,
+                                 cb <= lr ? ili * ((lr == cb ? 1.0 : 0.0) - sacc[cb]) : 0.0);
+        }
+      }
+    } else if (J + 1 < NT) {
+#pragma unroll
+      for (int sl = 0; sl < 3; ++sl) {
+        const int I = J + 1 + (w - 1) + 3 * sl;
+        ahead[sl] = (d4){0.0, 0.0, 0.0, 0.0};
+        if (I < NT) mfma_nt16(Tm + (16 * I + lr) * TS + lk, Tm + (c0 + 16 + lr) * TS + lk, 0, c0, ahead[sl]);
       }
     }
     __syncthreads();
+    // ---- 3. the tiles below: X = P W^T
+    if (J + 1 < NT) {
+      const int I0 = J + 1 + w, I1 = J + 5 + w;
+      if (I0 < NT) {
+        const bool two = I1 < NT;
+        d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
+        const double *wj = Wd + (16 * J + lr) * WS + lk;
+        mfma_nt16(Tm + (16 * I0 + lr) * TS + c0 + lk, wj, 0, 16, a0);
+        if (two) mfma_nt16(Tm + (16 * I1 + lr) * TS + c0 + lk, wj, 0, 16, a1);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          Tm[(16 * I0 + lk + 4 * reg) * TS + c0 + lr] = a0[reg];
+          if (two) Tm[(16 * I1 + lk + 4 * reg) * TS + c0 + lr] = a1[reg];
+        }
+      }
+      __syncthreads();
+    }
   }
   for (int e = t; e < CB * CB; e += 256) {
     const int rr = e / CB, c = e - rr * CB;
     if (rr < kw && c <= rr) A[(int64_t)(k0 + rr) * ld + k0 + c] = Tm[rr * TS + c];
   }
-  // ---- inverse of the lower triangle in place, column blocks from the right:
-  //      [L11 0; L21 L22]^-1 = [W11 0; -W22 L21 W11, W22],  W22 already in place
-  for (int j0 = CB - SB; j0 >= 0; j0 -= SB) {
-    // W11 = L11^-1 in registers (every thread), the old L21 to Cb
-    double W11[SB][SB];
-    {
-      double L11[SB][SB], id[SB];
+  __syncthreads();
+  // ---- inverse in place: the diagonal tiles first, then the pairwise merges
+  for (int e = t; e < NT * 256; e += 256) {
+    const int J = e >> 8, rr = (e >> 4) & 15, c = e & 15;
+    Tm[(16 * J + rr) * TS + 16 * J + c] = Wd[(16 * J + rr) * WS + c];
+  }
+  __syncthreads();
+  for (int s = 16; s < CB; s *= 2) {
+    const int ts = s / 16, per = ts * ts, ntile = (CB / (2 * s)) * per;
+    d4 acc[4];
+    // M = L21 W11 (W11 lower triangular: k from the first row of the tile column on)
 #pragma unroll
-      for (int i = 0; i < SB; ++i) {
-        id[i] = invd[j0 + i];
-#pragma unroll
-        for (int c = 0; c < SB; ++c) L11[i][c] = (c < i) ? Tm[(j0 + i) * TS + j0 + c] : 0.0;
+    for (int m = 0; m < 4; ++m) {
+      acc[m] = (d4){0.0, 0.0, 0.0, 0.0};
+      const int q = w + 4 * m;
+      if (q < ntile) {
+        const int o = 2 * s * (q / per), ti = (q % per) / ts, tj = q % ts;
+        mfma_nn16(Tm + (o + s + 16 * ti + lr) * TS + o + lk, Tm + (o + lk) * TS + o + 16 * tj + lr, 16 * tj, s, acc[m]);
       }
-#pragma unroll
-      for (int c = 0; c < SB; ++c)
-#pragma unroll
-        for (int i = 0; i < SB; ++i) {
-          if (i < c) {
-            W11[i][c] = 0.0;
-          } else {
-            double sdot = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-            for (int k = 0; k < SB; ++k)
-              if (k >= c && k < i) sdot -= L11[i][k] * W11[k][c];
-            W11[i][c] = sdot * id[i];
-          }
-        }
     }
-    const int m0 = j0 + SB;  // first row of the 22 part
-    for (int e = t; e < (CB - m0) * SB; e += 256) Cb[e] = Tm[(m0 + e / SB) * TS + j0 + (e % SB)];
     __syncthreads();
-    double acc[2][SB];
 #pragma unroll
-    for (int c = 0; c < SB; ++c) acc[0][c] = acc[1][c] = 0.0;
-    if (ra >= m0) {
-      // k = m0 .. rb for both rows of the pair (the entry beyond the diagonal of the upper row is a stored zero)
-      const int len = rb - m0 + 1, per = ((len / 2 + 3) / 4) * 2;
-      const int kb = m0 + q * per, ke = min(kb + per, rb + 1);
-      const double *pa = Tm + ra * TS, *pb = Tm + rb * TS;
-      for (int k = kb; k < ke; k += 2) {
-        const double2 a0 = *reinterpret_cast<const double2 *>(pa + k), a1 = *reinterpret_cast<const double2 *>(pb + k);
-        const double2 *c0 = reinterpret_cast<const double2 *>(Cb + (k - m0) * SB), *c1 = c0 + SB / 2;
+    for (int m = 0; m < 4; ++m) {
+      const int q = w + 4 * m;
+      if (q < ntile) {
+        const int o = 2 * s * (q / per), ti = (q % per) / ts, tj = q % ts;
 #pragma unroll
-        for (int c = 0; c < SB / 2; ++c) {
-          const double2 x0 = c0[c], x1 = c1[c];
-          acc[0][2 * c] += a0.x * x0.x + a0.y * x1.x;
-          acc[0][2 * c + 1] += a0.x * x0.y + a0.y * x1.y;
-          acc[1][2 * c] += a1.x * x0.x + a1.y * x1.x;
-          acc[1][2 * c + 1] += a1.x * x0.y + a1.y * x1.y;
-        }
+        for (int reg = 0; reg < 4; ++reg) Tm[(o + s + 16 * ti + lk + 4 * reg) * TS + o + 16 * tj + lr] = acc[m][reg];
       }
     }
+    __syncthreads();
+    // W21 = -W22 M (W22 lower triangular: k up to the last row of the tile row)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int c = 0; c < SB; ++c) {
-        acc[i][c] += __shfl_xor(acc[i][c], 1, 64);
-        acc[i][c] += __shfl_xor(acc[i][c], 2, 64);
+    for (int m = 0; m < 4; ++m) {
+      acc[m] = (d4){0.0, 0.0, 0.0, 0.0};
+      const int q = w + 4 * m;
+      if (q < ntile) {
+        const int o = 2 * s * (q / per), ti = (q % per) / ts, tj = q % ts;
+        mfma_nn16(Tm + (o + s + 16 * ti + lr) * TS + o + s + lk, Tm + (o + s + lk) * TS + o + 16 * tj + lr, 0, 16 * (ti + 1), acc[m]);
       }
-    if (q == 0 && ra >= j0) {
+    }
+    __syncthreads();
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = ra + i;
+    for (int m = 0; m < 4; ++m) {
+      const int q = w + 4 * m;
+      if (q < ntile) {
+        const int o = 2 * s * (q / per), ti = (q % per) / ts, tj = q % ts;
 #pragma unroll
-        for (int c = 0; c < SB; ++c) {
-          double x = 0.0;
-          if (row >= m0) {
-#pragma unroll
-            for (int m = 0; m < SB; ++m)
-              if (m >= c) x -= acc[i][m] * W11[m][c];
-          } else {
-#pragma unroll
-            for (int m = 0; m < SB; ++m)
-              if (m == row - j0) x = W11[m][c];
-          }
-          Tm[row * TS + j0 + c] = x;
-        }
+        for (int reg = 0; reg < 4; ++reg) Tm[(o + s + 16 * ti + lk + 4 * reg) * TS + o + 16 * tj + lr] = -acc[m][reg];
       }
     }
     __syncthreads();
@@ -523,7 +561,7 @@ size_t chol_blocked_workspace(int n) { return (size_t)((n + CB - 1) / CB) * CB *
 
 void launch_cholesky_blocked(hipStream_t s, double *A, int n, int ld, double *W, int *info) {
   (void)hipMemsetAsync(info, 0, sizeof(int), s);
-  const size_t lds = (size_t)(CB * TS + SB * SB + (CB - SB) * SB + CB) * sizeof(double);
+  const size_t lds = (size_t)(CB * TS + (CB / 16) * 16 * WS) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
