@@ -39,12 +39,13 @@ __device__ __forceinline__ void gemm_tile_nt(const double *__restrict__ A, int l
   const int wr = w >> 1, wc = w & 1, lr = lane & 15, lk = lane >> 4;
   const int row = t >> 1, h = t & 1;
   const bool aon = ar0 + row < am, bon = br0 + row < bm;
-  const double *ap = A + (int64_t)(ar0 + row) * lda + 8 * h, *bp = B + (int64_t)(br0 + row) * ldb + 8 * h;
-  double2 ra[4], rb[4];
+  constexpr int HK = KC / 2, NJ = KC / 4;  // a thread stages half a chunk row: HK columns as NJ 16-byte pieces
+  const double *ap = A + (int64_t)(ar0 + row) * lda + HK * h, *bp = B + (int64_t)(br0 + row) * ldb + HK * h;
+  double2 ra[NJ], rb[NJ];
   auto fetch = [&](int k0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = k0 + 8 * h + 2 * j;
+    for (int j = 0; j < NJ; ++j) {
+      const int k = k0 + HK * h + 2 * j;
       ra[j] = (aon && k < ke) ? *reinterpret_cast<const double2 *>(ap + k0 + 2 * j) : make_double2(0.0, 0.0);
       rb[j] = (bon && k < ke) ? *reinterpret_cast<const double2 *>(bp + k0 + 2 * j) : make_double2(0.0, 0.0);
     }
@@ -53,11 +54,11 @@ __device__ __forceinline__ void gemm_tile_nt(const double *__restrict__ A, int l
   for (int k0 = kb; k0 < ke; k0 += KC) {
     __syncthreads();  // the previous chunk has been read
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      sA[(8 * h + 2 * j) * LDT + row] = ra[j].x;
-      sA[(8 * h + 2 * j + 1) * LDT + row] = ra[j].y;
-      sB[(8 * h + 2 * j) * LDT + row] = rb[j].x;
-      sB[(8 * h + 2 * j + 1) * LDT + row] = rb[j].y;
+    for (int j = 0; j < NJ; ++j) {
+      sA[(HK * h + 2 * j) * LDT + row] = ra[j].x;
+      sA[(HK * h + 2 * j + 1) * LDT + row] = ra[j].y;
+      sB[(HK * h + 2 * j) * LDT + row] = rb[j].x;
+      sB[(HK * h + 2 * j + 1) * LDT + row] = rb[j].y;
     }
     __syncthreads();
     if (k0 + KC < ke) fetch(k0 + KC);  // in flight during the products below
@@ -210,13 +211,12 @@ k_gemm_nt(GemmArgs g) {
 //   Factorisation, left-looking over block columns of 16: the tiles of a block column take the sum over the finished
 //   columns on the matrix cores (operands straight from the row-major block: with a row stride of 130 doubles the 32
 //   lanes of a half wave hit 32 different banks); its 16 x 16 diagonal tile is factored by one wave, a lane per row,
-//   pivots and column entries handed round by DPP row broadcasts (no LDS round trip inside the chain of 16 pivots), and
-//   inverted in the same instruction stream (the inverse's steps fill the waits of the pivot chain), while the other
-//   three waves already sum for the next block column; the tiles below become X = P W^T, again on the matrix cores.
-//   Inverse: the 16 x 16 inverses are merged pairwise, 16 -> 32 -> 64 -> 128,
+//   pivots and column entries handed round by DPP row broadcasts (no LDS round trip inside the chain of 16 pivots),
+//   while the other three waves already sum for the next block column; the rows below are solved against the tile by
+//   substitution, a lane per row.
+//   Inverse: the eight tiles are inverted side by side (a row of 16 lanes each), then merged pairwise, 16 -> 32 -> 64 -> 128,
 //   [L11 0; L21 L22]^-1 = [W11 0; -W22 (L21 W11), W22], two products per level over 16 x 16 tiles, in place.
 #define TS (CB + 2)  // even (16-byte aligned rows) and = 2 mod 32 (conflict-free operand reads)
-#define WS 18        // row stride of the saved 16 x 16 inverses
 
 // lane J of every row of 16 lanes, in all lanes of that row (DPP row_newbcast: one VALU move per 32 bits, the result
 // stays in vector registers)
@@ -278,7 +278,7 @@ __device__ __forceinline__ void mfma_nn16(const double *xa, const double *pb, in
 __global__ void __launch_bounds__(256)
 k_chol_diag(double *__restrict__ A, int n, int ld, int k0, double *__restrict__ Wk, int *__restrict__ info) {
   extern __shared__ double Tm[];  // CB x TS
-  double *Wd = Tm + CB * TS;      // 8 x (16 x WS): inverses of the diagonal 16 x 16 tiles
+  double *Il = Tm + CB * TS;      // CB: reciprocals of the diagonal of the factor
   const int kw = min(CB, n - k0);
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, lr = lane & 15, lk = lane >> 4;
   const int NT = CB / 16;
@@ -326,8 +326,8 @@ k_chol_diag(double *__restrict__ A, int n, int ld, int k0, double *__restrict__ 
       }
       __syncthreads();
     }
-    // ---- 2. the diagonal tile: factor and invert, wave 0, lane lr = row lr (the four rows of 16 lanes do the same);
-    //         the others sum ahead for block column J + 1
+    // ---- 2. the diagonal tile: factored by wave 0, lane lr = row lr (the four rows of 16 lanes do the same); the others
+    //         sum ahead for block column J + 1
     if (w == 0) {
       double r[16];
       {
@@ -341,9 +341,6 @@ k_chol_diag(double *__restrict__ A, int n, int ld, int k0, double *__restrict__ 
       }
       int bad = -1;
       double ili = 1.0;  // 1 / L[lr][lr]
-      double sacc[16];   // inverse, row lr in this lane: W[i][c] = (delta_ic - sum_{k = c}^{i-1} L[i][k] W[k][c]) / L[i][i]
-#pragma unroll
-      for (int c = 0; c < 16; ++c) sacc[c] = 0.0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const double d = bcast16(r[j], j);
@@ -361,26 +358,16 @@ k_chol_diag(double *__restrict__ A, int n, int ld, int k0, double *__restrict__ 
         r[j] = lij;
 #pragma unroll
         for (int c = j + 1; c < 16; ++c) r[c] = fma(-lij, bcast16(lij, c), r[c]);
-        // step j of the inverse (column j of L is final): it fills the waits of the next pivot's chain
-        if (j < 15) {
-          const double lik = (lr > j) ? lij : 0.0;
-#pragma unroll
-          for (int c = 0; c <= j; ++c) {
-            const double mine = ili * ((lr == c ? 1.0 : 0.0) - sacc[c]);  // final in lane j: all its terms are in
-            sacc[c] = fma(lik, bcast16(mine, j), sacc[c]);
-          }
-        }
       }
       if (lane == 0 && bad >= 0 && c0 + bad < kw) atomicMax(info, k0 + c0 + bad + 1);
       if (lk == 0) {
-        double2 *lrow = reinterpret_cast<double2 *>(Tm + (c0 + lr) * TS + c0), *wrow = reinterpret_cast<double2 *>(Wd + (16 * J + lr) * WS);
+        double2 *lrow = reinterpret_cast<double2 *>(Tm + (c0 + lr) * TS + c0);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           const int ca = 2 * c, cb = 2 * c + 1;
           lrow[c] = make_double2(ca <= lr ? r[ca] : 0.0, cb <= lr ? r[cb] : 0.0);
-          wrow[c] = make_double2(ca <= lr ? ili * ((lr == ca ? 1.0 : 0.0) - sacc[ca]) : 0.0,
-                                 cb <= lr ? ili * ((lr == cb ? 1.0 : 0.0) - sacc[cb]) : 0.0);
         }
+        Il[c0 + lr] = ili;
       }
     } else if (J + 1 < NT) {
 #pragma unroll
@@ -391,33 +378,73 @@ k_chol_diag(double *__restrict__ A, int n, int ld, int k0, double *__restrict__ 
       }
     }
     __syncthreads();
-    // ---- 3. the tiles below: X = P W^T
+    // ---- 3. the rows below: x L^T = p by substitution, a lane per row (the tile of L comes as broadcast reads)
     if (J + 1 < NT) {
-      const int I0 = J + 1 + w, I1 = J + 5 + w;
-      if (I0 < NT) {
-        const bool two = I1 < NT;
-        d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
-        const double *wj = Wd + (16 * J + lr) * WS + lk;
-        mfma_nt16(Tm + (16 * I0 + lr) * TS + c0 + lk, wj, 0, 16, a0);
-        if (two) mfma_nt16(Tm + (16 * I1 + lr) * TS + c0 + lk, wj, 0, 16, a1);
+      const int row = c0 + 16 + t;
+      if (row < CB) {
+        double x[16];
+        double2 *prow = reinterpret_cast<double2 *>(Tm + row * TS + c0);
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          Tm[(16 * I0 + lk + 4 * reg) * TS + c0 + lr] = a0[reg];
-          if (two) Tm[(16 * I1 + lk + 4 * reg) * TS + c0 + lr] = a1[reg];
+        for (int c = 0; c < 8; ++c) {
+          const double2 v = prow[c];
+          x[2 * c] = v.x;
+          x[2 * c + 1] = v.y;
         }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const double *lrow = Tm + (c0 + c) * TS + c0;
+          double sdot = x[c];
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            if (k < c) sdot = fma(-x[k], lrow[k], sdot);
+          x[c] = sdot * Il[c0 + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) prow[c] = make_double2(x[2 * c], x[2 * c + 1]);
       }
       __syncthreads();
     }
   }
-  for (int e = t; e < CB * CB; e += 256) {
-    const int rr = e / CB, c = e - rr * CB;
-    if (rr < kw && c <= rr) A[(int64_t)(k0 + rr) * ld + k0 + c] = Tm[rr * TS + c];
+#pragma unroll 8
+  for (int e = t; e < CB * CB / 2; e += 256) {
+    const int rr = e / (CB / 2), c = 2 * (e - rr * (CB / 2));
+    if (rr < kw && c <= rr) {
+      const double2 v = *reinterpret_cast<const double2 *>(Tm + rr * TS + c);
+      double *dst = A + (int64_t)(k0 + rr) * ld + k0 + c;
+      if (c + 1 <= rr) *reinterpret_cast<double2 *>(dst) = v;
+      else *dst = v.x;
+    }
   }
   __syncthreads();
-  // ---- inverse in place: the diagonal tiles first, then the pairwise merges
-  for (int e = t; e < NT * 256; e += 256) {
-    const int J = e >> 8, rr = (e >> 4) & 15, c = e & 15;
-    Tm[(16 * J + rr) * TS + 16 * J + c] = Wd[(16 * J + rr) * WS + c];
+  // ---- inverse in place: the eight diagonal tiles first, one per row of 16 lanes of waves 0 and 1 (lane lr = row lr:
+  //      W[i][c] = (delta_ic - sum_{k = c}^{i-1} L[i][k] W[k][c]) / L[i][i], the finished rows handed down by row broadcasts)
+  if (w < 2) {
+    const int J = 4 * w + lk;
+    double2 *row = reinterpret_cast<double2 *>(Tm + (16 * J + lr) * TS + 16 * J);
+    double r[16], sacc[16];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const double2 v = row[c];
+      r[2 * c] = v.x;
+      r[2 * c + 1] = v.y;
+      sacc[2 * c] = sacc[2 * c + 1] = 0.0;
+    }
+    const double ili = Il[16 * J + lr];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+      const double lik = (lr > k) ? r[k] : 0.0;
+#pragma unroll
+      for (int c = 0; c <= k; ++c) {
+        const double mine = ili * ((lr == c ? 1.0 : 0.0) - sacc[c]);  // final in lane k: all its terms are in
+        sacc[c] = fma(lik, bcast16(mine, k), sacc[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int ca = 2 * c, cb = 2 * c + 1;
+      row[c] = make_double2(ca <= lr ? ili * ((lr == ca ? 1.0 : 0.0) - sacc[ca]) : 0.0,
+                            cb <= lr ? ili * ((lr == cb ? 1.0 : 0.0) - sacc[cb]) : 0.0);
+    }
   }
   __syncthreads();
   for (int s = 16; s < CB; s *= 2) {
@@ -466,9 +493,11 @@ k_chol_diag(double *__restrict__ A, int n, int ld, int k0, double *__restrict__ 
     }
     __syncthreads();
   }
-  for (int e = t; e < CB * CB; e += 256) {
-    const int rr = e / CB, c = e - rr * CB;
-    Wk[e] = (rr < kw && c <= rr) ? Tm[rr * TS + c] : 0.0;
+#pragma unroll 8
+  for (int e = t; e < CB * CB / 2; e += 256) {
+    const int rr = e / (CB / 2), c = 2 * (e - rr * (CB / 2));
+    const double2 v = *reinterpret_cast<const double2 *>(Tm + rr * TS + c);
+    reinterpret_cast<double2 *>(Wk)[e] = make_double2((rr < kw && c <= rr) ? v.x : 0.0, (rr < kw && c + 1 <= rr) ? v.y : 0.0);
   }
 }
 
@@ -526,8 +555,16 @@ k_chol_backward(const double *__restrict__ L, int n, int ld, const double *__res
     const int i0 = CB * i, iw = min(CB, n - i0);
     xs[t] = t < iw ? b[i0 + t] : 0.0;
     __syncthreads();
+    // consecutive threads, consecutive columns; eight rows requested at a time (rows beyond the block: a valid row, times 0)
     double s = 0.0;
-    for (int r = 0; r < iw; ++r) s += L[(int64_t)(i0 + r) * ld + col] * xs[r];  // consecutive threads, consecutive columns
+    const double *lc = L + (int64_t)i0 * ld + col;
+    for (int r0 = 0; r0 < iw; r0 += 8) {
+      double l[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) l[u] = lc[(int64_t)min(r0 + u, iw - 1) * ld];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += l[u] * xs[r0 + u];
+    }
     v -= s;
     if (kb != i - 1) {
       b[col] = v;
@@ -561,7 +598,7 @@ size_t chol_blocked_workspace(int n) { return (size_t)((n + CB - 1) / CB) * CB *
 
 void launch_cholesky_blocked(hipStream_t s, double *A, int n, int ld, double *W, int *info) {
   (void)hipMemsetAsync(info, 0, sizeof(int), s);
-  const size_t lds = (size_t)(CB * TS + (CB / 16) * 16 * WS) * sizeof(double);
+  const size_t lds = (size_t)(CB * TS + CB) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
