@@ -347,19 +347,44 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   p->nr = 6 * S + p->ncam;
 
   trace.mark("degrees, cameras");
+  // The index structures: on the device for networks of some size (ba_setup.hip), by the host loops below otherwise.
+  // Both give the same arrays.
+  const bool on_device = setup_on_device(N);
+  HIP_OK(hipStreamCreate(&p->stream));
+  HIP_OK(hipStreamCreate(&p->stream2));
   // internal point order: by number of observations (descending, stable) so that the lanes of
   // a wave walk segments of similar length
   p->pt_file.resize(P);
+  std::vector<int> pt_start, obs_pt, e_sta;
+  std::vector<double> obs;
+  if (on_device) {
+    SetupArrays sa{};
+    BA_TRY(p->dalloc(&p->d_pt_file, (size_t)P));
+    BA_TRY(p->dalloc(&p->d_pt_start, (size_t)P + 1));
+    BA_TRY(p->dalloc(&p->d_obs_pt, (size_t)N));
+    BA_TRY(p->dalloc(&p->d_obs_sta, (size_t)N));
+    BA_TRY(p->dalloc(&p->d_sta_list, (size_t)N));
+    BA_TRY(p->dalloc(&p->d_obs, (size_t)N * BA_OBS_STRIDE));
+    BA_TRY(p->dalloc(&p->d_pt_prior, 3 * (size_t)P));
+    BA_TRY(p->dalloc(&p->d_pt_isig, 3 * (size_t)P));
+    sa.pt_file = p->d_pt_file; sa.pt_start = p->d_pt_start; sa.obs_pt = p->d_obs_pt; sa.obs_sta = p->d_obs_sta; sa.sta_list = p->d_sta_list;
+    sa.obs = p->d_obs; sa.pt_prior = p->d_pt_prior; sa.pt_isig = p->d_pt_isig;
+    const double *cols[6] = {in->obs_x, in->obs_y, in->obs_sx, in->obs_sy, in->obs_cx, in->obs_cy};
+    std::string err;
+    if (setup_sort_observations(p->stream, N, S, P, in->obs_pt, in->obs_sta, cols, in->pt_prior, in->pt_sigma, deg.data(), sa, p->pt_file.data(), err))
+      return fail(BA_ERR_DEVICE, "set-up on the device: %s", err.c_str());
+  } else {
   std::iota(p->pt_file.begin(), p->pt_file.end(), 0);
   std::stable_sort(p->pt_file.begin(), p->pt_file.end(), [&](int a, int b) { return deg[a] > deg[b]; });
   std::vector<int> pt_int(P);
   for (int jj = 0; jj < P; ++jj) pt_int[p->pt_file[jj]] = jj;
-  std::vector<int> pt_start(P + 1, 0);
+  pt_start.assign(P + 1, 0);
   for (int jj = 0; jj < P; ++jj) pt_start[jj + 1] = pt_start[jj] + deg[p->pt_file[jj]];
   // observations sorted by internal point, file order inside a point
   std::vector<int> fill(pt_start.begin(), pt_start.end() - 1);
-  std::vector<double> obs((size_t)N * BA_OBS_STRIDE, 0.0);
-  std::vector<int> obs_pt(N), e_sta(N), slot(N);
+  obs.assign((size_t)N * BA_OBS_STRIDE, 0.0);
+  obs_pt.resize(N); e_sta.resize(N);
+  std::vector<int> slot(N);
   for (int n = 0; n < N; ++n) slot[n] = fill[pt_int[in->obs_pt[n]]]++;  // the only order-dependent part
   parallel_ranges(N, [&](int64_t n0, int64_t n1) {
     for (int64_t n = n0; n < n1; ++n) {
@@ -373,12 +398,17 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
       e_sta[e] = in->obs_sta[n];
     }
   });
+  }
   trace.mark("observations by point");
   // station-sorted index list and its chunks
   std::vector<int> sta_start(S + 1, 0);
   for (int i = 0; i < S; ++i) sta_start[i + 1] = sta_start[i] + sdeg[i];
-  std::vector<int> sfill(sta_start.begin(), sta_start.end() - 1), sta_list(N);
-  for (int e = 0; e < N; ++e) sta_list[sfill[e_sta[e]]++] = e;
+  std::vector<int> sta_list;
+  if (!on_device) {
+    std::vector<int> sfill(sta_start.begin(), sta_start.end() - 1);
+    sta_list.resize(N);
+    for (int e = 0; e < N; ++e) sta_list[sfill[e_sta[e]]++] = e;
+  }
   std::vector<int> chunk_sta, chunk_begin, sta_chunk0(S + 1, 0);
   for (int i = 0; i < S; ++i) {
     sta_chunk0[i] = (int)chunk_sta.size();
@@ -408,7 +438,17 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
     for (int j = 0; j < P; ++j) npairs += (int64_t)deg[j] * (deg[j] - 1) / 2;
     // pairs of one point that share a station are listed in both orders (diagonal block)
     const int64_t pair_cap = 600000000LL;
-    if (npairs <= pair_cap && S > 0) {
+    std::vector<int> ub_lo, ub_hi;
+    int64_t tot = 0;
+    bool have_blocks = false;
+    if (npairs <= pair_cap && S > 0 && on_device) {
+      std::string err;
+      const int rc = setup_pairs(p->stream, S, P, p->d_pt_start, p->d_obs_sta, pair_cap, &p->d_pairs, &tot, ub_lo, ub_hi, ublk_cstart, err);
+      if (rc < 0) return fail(BA_ERR_DEVICE, "set-up on the device: %s", err.c_str());
+      if (p->d_pairs) p->allocs.push_back(p->d_pairs);
+      have_blocks = rc == 0;
+      trace.mark("pairs on the device");
+    } else if (npairs <= pair_cap && S > 0) {
       std::vector<int64_t> rowcnt(S + 1, 0);
       auto for_pairs = [&](auto &&fn) {
         for (int jj = 0; jj < P; ++jj)
@@ -422,7 +462,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
       };
       for_pairs([&](int lo, int, int, int) { rowcnt[lo + 1]++; });
       for (int i = 0; i < S; ++i) rowcnt[i + 1] += rowcnt[i];
-      const int64_t tot = rowcnt[S];
+      tot = rowcnt[S];
       std::vector<int> hi_of(tot), ea_of(tot), eb_of(tot);
       {
         std::vector<int64_t> pos(rowcnt.begin(), rowcnt.end() - 1);
@@ -435,7 +475,6 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
       // inside a row: stable counting sort by hi (keeps point order inside a block)
       pairs.resize(tot);
       std::vector<int> cnt(S + 1), nb_lo(S, 0), nb_hi(S, 0);
-      std::vector<int> ub_lo, ub_hi;
       ublk_cstart.push_back(0);
       std::vector<int> touched;
       for (int lo = 0; lo < S; ++lo) {
@@ -461,6 +500,9 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
         for (int h : touched) cnt[h] = 0;
       }
       trace.mark("pairs by block");
+      have_blocks = true;
+    }
+    if (have_blocks) {
       const int nu = (int)ub_lo.size();
       // full BSR pattern: diagonal first, then neighbours in ascending column order
       std::vector<int> nnb(S, 1);
@@ -495,34 +537,37 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   }
 
   trace.mark("block-sparse pattern");
-  std::vector<double> prior(3 * (size_t)P), isig(3 * (size_t)P);
-  for (int jj = 0; jj < P; ++jj)
-    for (int k = 0; k < 3; ++k) {
-      prior[3 * (size_t)jj + k] = in->pt_prior[3 * (size_t)p->pt_file[jj] + k];
-      isig[3 * (size_t)jj + k] = 1.0 / in->pt_sigma[3 * (size_t)p->pt_file[jj] + k];
-    }
+  std::vector<double> prior, isig;
+  if (!on_device) {
+    prior.resize(3 * (size_t)P); isig.resize(3 * (size_t)P);
+    for (int jj = 0; jj < P; ++jj)
+      for (int k = 0; k < 3; ++k) {
+        prior[3 * (size_t)jj + k] = in->pt_prior[3 * (size_t)p->pt_file[jj] + k];
+        isig[3 * (size_t)jj + k] = 1.0 / in->pt_sigma[3 * (size_t)p->pt_file[jj] + k];
+      }
+  }
 
   trace.mark("point priors");
-  HIP_OK(hipStreamCreate(&p->stream));
-  HIP_OK(hipStreamCreate(&p->stream2));
   HIP_OK(hipEventCreateWithFlags(&p->ev_blocks, hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&p->ev_amg, hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&p->ev_rows, hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&p->ev_schur, hipEventDisableTiming));
   trace.mark("stream");
-  BA_TRY(p->upload(&p->d_pt_start, pt_start));
-  BA_TRY(p->upload(&p->d_obs_pt, obs_pt));
-  BA_TRY(p->upload(&p->d_obs_sta, e_sta));
-  BA_TRY(p->upload(&p->d_sta_list, sta_list));
+  if (!on_device) {
+    BA_TRY(p->upload(&p->d_pt_start, pt_start));
+    BA_TRY(p->upload(&p->d_obs_pt, obs_pt));
+    BA_TRY(p->upload(&p->d_obs_sta, e_sta));
+    BA_TRY(p->upload(&p->d_sta_list, sta_list));
+    BA_TRY(p->upload(&p->d_pt_file, p->pt_file));
+    BA_TRY(p->upload(&p->d_obs, obs));
+    BA_TRY(p->upload(&p->d_pt_prior, prior));
+    BA_TRY(p->upload(&p->d_pt_isig, isig));
+  }
   BA_TRY(p->upload(&p->d_chunk_sta, chunk_sta));
   BA_TRY(p->upload(&p->d_chunk_begin, chunk_range));
   BA_TRY(p->upload(&p->d_sta_chunk0, sta_chunk0));
   BA_TRY(p->upload(&p->d_sta_cam, p->sta_cam_h));
-  BA_TRY(p->upload(&p->d_pt_file, p->pt_file));
   BA_TRY(p->upload(&p->d_sta_used, p->sta_used_h));
-  BA_TRY(p->upload(&p->d_obs, obs));
-  BA_TRY(p->upload(&p->d_pt_prior, prior));
-  BA_TRY(p->upload(&p->d_pt_isig, isig));
   BA_TRY(p->upload(&p->d_cam, p->cam_h));
   trace.mark("uploads");
   BA_TRY(p->dalloc(&p->d_cam_c, (size_t)C));
@@ -565,7 +610,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
     BA_TRY(p->upload(&p->d_bsr_col, bsr_col));
     BA_TRY(p->upload(&p->d_ublk_cstart, ublk_cstart));
     BA_TRY(p->upload(&p->d_ublk_dst, ublk_dst));
-    BA_TRY(p->upload(&p->d_pairs, pairs));
+    if (!on_device) BA_TRY(p->upload(&p->d_pairs, pairs));
     BA_TRY(p->dalloc(&p->d_Y, (size_t)BA_Y_STRIDE * N));
     const size_t npart = (size_t)std::max(std::max(cg2_blocks_spmv(S), cg2_blocks_vec(S)), 1024) + 1;
     BA_TRY(p->dalloc(&p->d_part_pq, npart));

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
 #include <vector>
 
 struct CamRec;
@@ -127,6 +128,18 @@ int cost_blocks(int64_t n);
 void launch_cost_obs(hipStream_t s, const CostArgs &a, int blocks);
 void launch_cost_prior(hipStream_t s, int P, const double *xyz, const double *prior, const double *isig, const int *pt_file,
                        double *res_out, double *partial, int blocks);
+// ---- index structures of a problem built on the device (ba_setup.hip)
+struct SetupArrays {  // device arrays, allocated by the caller
+  int *pt_file, *pt_start /* P + 1 */, *obs_pt, *obs_sta, *sta_list;
+  double *obs, *pt_prior, *pt_isig;
+};
+bool setup_on_device(int64_t n_obs);  // BA_SETUP=host|gpu in the environment overrides the size rule
+int setup_sort_observations(hipStream_t s, int N, int S, int P, const int *obs_pt, const int *obs_sta, const double *const obs_cols[6],
+                            const double *pt_prior, const double *pt_sigma, const int *deg, const SetupArrays &out, int *pt_file_host,
+                            std::string &err);
+int setup_pairs(hipStream_t s, int S, int P, const int *d_pt_start, const int *d_obs_sta, int64_t pair_cap, int2 **d_pairs, int64_t *n_pairs,
+                std::vector<int> &ub_lo, std::vector<int> &ub_hi, std::vector<int> &cstart, std::string &err);
+
 #define BA_PACK_MAX 4
 struct PackList {
   double *ptr[BA_PACK_MAX];

@@ -438,3 +438,39 @@ def test_many_camera_columns_through_the_pcg_solvers():
     assert_solve_parity(g, o, par_rtol=1e-8)
     d = gpu_solve(net, options(capi.SOLVER_DENSE_SCHUR))
     assert_solve_parity(d, o, par_rtol=1e-8)
+
+
+def test_index_structures_built_on_the_device_match_the_host_construction(monkeypatch):
+    # The same network set up twice: by the host loops (the rule for small networks) and by the sorts and scans on the
+    # device (the rule from 65 536 observations on).  Both must give the same arrays, so everything downstream --
+    # evaluation, sparsity pattern, every iteration of the solve -- is the same bits.  Three cameras and few rays per
+    # point make station pairs of several sizes; points without observations and a station that two observations of one
+    # point share exercise the corners.
+    hn = host.synth(n_cam=3, n_sta=90, n_pts=3000, rays_per_point=5, seed=11, ap_free_mask=host.AP_K1K2P1P2, control_every=9)
+    net = hn.net
+    keep = np.ones(net.n_obs, dtype=bool)
+    keep[net.obs_pt == 17] = False                      # a point without observations
+    keep[(net.obs_pt % 50 == 3) & (np.arange(net.n_obs) % 2 == 0)] = False   # points with fewer rays than the others
+    net = capi.Network(**{**{f: getattr(net, f) for f in ("sta_cam", "pt_prior", "pt_sigma", "iop_prior", "iop_sigma", "ap_free_mask",
+                                                             "iop_free_mask", "eop", "xyz", "iop", "ap", "huber_a", "model")},
+                          **{f: getattr(net, f)[keep] for f in ("obs_pt", "obs_sta", "obs_x", "obs_y", "obs_sx", "obs_sy", "obs_cx", "obs_cy")}})
+    dup = np.nonzero(net.obs_pt == 40)[0]
+    net.obs_sta[dup[1]] = net.obs_sta[dup[0]]           # two observations of one point from the same station
+    out = {}
+    for mode in ("host", "gpu"):
+        monkeypatch.setenv("BA_SETUP", mode)
+        opt = solver.default_options()
+        opt.linear_solver = capi.SOLVER_PCG_SCHUR
+        opt.max_num_iterations = 6
+        with solver.Problem(net) as P:
+            c, res = P.evaluate()
+            sp = P.sparsity()
+            sol = P.solve(opt)
+        out[mode] = (c, res, sp, sol)
+    a, b = out["host"], out["gpu"]
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    assert a[2][0] == b[2][0] and a[2][1] == b[2][1] and np.array_equal(a[2][2], b[2][2]) and np.array_equal(a[2][3], b[2][3])
+    for x, y in zip(a[3][:4], b[3][:4]):
+        assert np.array_equal(x, y)
+    assert [r["cost"] for r in a[3][5]] == [r["cost"] for r in b[3][5]]
+    assert [r["linear_iterations"] for r in a[3][5]] == [r["linear_iterations"] for r in b[3][5]]
