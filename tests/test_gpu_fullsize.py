@@ -112,3 +112,33 @@ def test_full_size_properties(name):
             nr, nc, rws, cols = P.sparsity()
             assert nr == 2 * N + 3 * Pn + 3 and nc == 6 * S + 3 * Pn + 3 + 16
             assert rws[-1] == 2 * N * (6 + 3) + 9 * Pn
+
+
+@pytest.mark.timeout(600)
+def test_cfg3_full_size_variances():
+    # 1800 stations (reduced system of order 10 800, inverted densely on the matrix cores), one million points: the
+    # oracle's full inverse is out of reach, so properties.  Every variance is positive; an observation can only add
+    # information, so no point ends up less certain than its prior; the control points (the tight priors) end up better
+    # known on average than the tie points; the constant camera has no variance.
+    hn = host.synth_config("cfg3", outlier_fraction=0.0)
+    net = hn.net
+    with solver.Problem(net) as P:
+        opt = solver.default_options()
+        opt.max_num_iterations = 3
+        P.set_parameters()
+        P.solve_resident(opt)
+        ve, vx, vi, va = P.covariance()
+    assert ve.shape == (net.n_sta, 6) and vx.shape == (net.n_pts, 3)
+    assert np.all(np.isfinite(ve)) and np.all(ve > 0.0)
+    assert np.all(np.isfinite(vx)) and np.all(vx > 0.0)
+    assert np.all(vx <= net.pt_sigma ** 2 * (1.0 + 1e-9))
+    assert np.all(vi == 0.0) and np.all(va == 0.0)
+    tight = net.pt_sigma[:, 0] < np.median(net.pt_sigma[:, 0])
+    if tight.any() and (~tight).any():
+        assert np.mean(vx[tight]) < np.mean(vx[~tight])
+    # the same call again gives the same bits
+    with solver.Problem(net) as P:
+        P.set_parameters()
+        P.solve_resident(opt)
+        ve2, vx2, _, _ = P.covariance()
+    assert np.array_equal(ve, ve2) and np.array_equal(vx, vx2)

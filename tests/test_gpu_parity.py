@@ -180,8 +180,10 @@ def test_multilevel_preconditioner_several_cameras():
 @pytest.mark.parametrize("which", ["cfg1", "three_cameras", "fixed_camera"])
 def test_covariance_after_the_solve(which):
     # a-posteriori variances (src/main.cpp:5261-5279, 5443-5565) at the adjusted parameters: the GPU's
-    # Schur-complement route against the oracle's inverse of the full normal matrix.  1e-7: the inverse
-    # amplifies rounding by the condition number of the network.
+    # Schur-complement route against the oracle's inverse of the full normal matrix.  1e-8: the inverse
+    # amplifies rounding by the condition number of the network -- the oracle and an independent numpy inverse of
+    # the same matrix differ by up to 1.5e-10 on these networks (tests/test_oracle_covariance.py), the GPU and the
+    # oracle by up to 4e-10 (scripts/cov_gap.py).
     if which == "cfg1":
         net = host.synth_config("cfg1").net
     elif which == "three_cameras":
@@ -201,7 +203,7 @@ def test_covariance_after_the_solve(which):
         assert g.shape == w.shape
         assert np.array_equal(g == 0.0, w == 0.0), name
         nz = w != 0.0
-        assert np.all(np.abs(g[nz] - w[nz]) <= 1e-7 * w[nz]), (name, np.max(np.abs(g[nz] - w[nz]) / w[nz]))
+        assert np.all(np.abs(g[nz] - w[nz]) <= 1e-8 * w[nz]), (name, np.max(np.abs(g[nz] - w[nz]) / w[nz]))
 
 
 @pytest.mark.parametrize("which", ["cfg1", "three_cameras"])
@@ -264,7 +266,7 @@ def test_blocked_cholesky_solve_and_covariance_against_the_oracle(n_sta):
     for a, w, name in zip(got, want, ("eop", "xyz", "iop", "ap")):
         assert np.array_equal(a == 0.0, w == 0.0), name
         nz = w != 0.0
-        assert np.all(np.abs(a[nz] - w[nz]) <= 1e-7 * w[nz]), (name, np.max(np.abs(a[nz] - w[nz]) / w[nz]))
+        assert np.all(np.abs(a[nz] - w[nz]) <= 1e-8 * w[nz]), (name, np.max(np.abs(a[nz] - w[nz]) / w[nz]))
 
 
 def test_covariance_too_large_is_refused():
