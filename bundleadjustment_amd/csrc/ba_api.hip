@@ -313,12 +313,13 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   p->sta_used_h.assign(S, 0);
   std::vector<int> &cam_used = p->cam_used_h;
   cam_used.assign(C, 0);
-  std::vector<int> deg(P, 0), sdeg(S, 0);
+  std::vector<int> deg(P, 0), sdeg(S, 0), min_sta(P, std::max(S - 1, 0));
   for (int n = 0; n < N; ++n) {
     p->sta_used_h[in->obs_sta[n]] = 1;
     cam_used[in->sta_cam[in->obs_sta[n]]] = 1;
     deg[in->obs_pt[n]]++;
     sdeg[in->obs_sta[n]]++;
+    min_sta[in->obs_pt[n]] = std::min(min_sta[in->obs_pt[n]], in->obs_sta[n]);
   }
   // cameras: free-parameter lists (src/main.cpp:4479-4511 for the AP; an AP block that no
   // observation references is not part of the reduced program)
@@ -371,11 +372,21 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
     sa.obs = p->d_obs; sa.pt_prior = p->d_pt_prior; sa.pt_isig = p->d_pt_isig;
     const double *cols[6] = {in->obs_x, in->obs_y, in->obs_sx, in->obs_sy, in->obs_cx, in->obs_cy};
     std::string err;
-    if (setup_sort_observations(p->stream, N, S, P, in->obs_pt, in->obs_sta, cols, in->pt_prior, in->pt_sigma, deg.data(), sa, p->pt_file.data(), err))
+    if (setup_sort_observations(p->stream, N, S, P, in->obs_pt, in->obs_sta, cols, in->pt_prior, in->pt_sigma, deg.data(), min_sta.data(), sa, p->pt_file.data(), err))
       return fail(BA_ERR_DEVICE, "set-up on the device: %s", err.c_str());
   } else {
   std::iota(p->pt_file.begin(), p->pt_file.end(), 0);
-  std::stable_sort(p->pt_file.begin(), p->pt_file.end(), [&](int a, int b) { return deg[a] > deg[b]; });
+  {
+    // more observations first, then by the lowest station that sees the point (points of one neighbourhood end up side
+    // by side, so the records a station sweep gathers cluster); the device path sorts by the same key
+    int dmax = 0;
+    for (int j = 0; j < P; ++j) dmax = std::max(dmax, deg[j]);
+    const bool by_station = point_order_station_bits(S, dmax) > 0;
+    std::stable_sort(p->pt_file.begin(), p->pt_file.end(), [&](int a, int b) {
+      if (deg[a] != deg[b]) return deg[a] > deg[b];
+      return by_station && min_sta[a] < min_sta[b];
+    });
+  }
   std::vector<int> pt_int(P);
   for (int jj = 0; jj < P; ++jj) pt_int[p->pt_file[jj]] = jj;
   pt_start.assign(P + 1, 0);

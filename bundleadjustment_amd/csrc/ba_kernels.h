@@ -135,8 +135,9 @@ struct SetupArrays {  // device arrays, allocated by the caller
 };
 bool setup_on_device(int64_t n_obs);  // BA_SETUP=host|gpu in the environment overrides the size rule
 int setup_sort_observations(hipStream_t s, int N, int S, int P, const int *obs_pt, const int *obs_sta, const double *const obs_cols[6],
-                            const double *pt_prior, const double *pt_sigma, const int *deg, const SetupArrays &out, int *pt_file_host,
-                            std::string &err);
+                            const double *pt_prior, const double *pt_sigma, const int *deg, const int *min_sta, const SetupArrays &out,
+                            int *pt_file_host, std::string &err);
+int point_order_station_bits(int S, int dmax);
 int setup_pairs(hipStream_t s, int S, int P, const int *d_pt_start, const int *d_obs_sta, int64_t pair_cap, int2 **d_pairs, int64_t *n_pairs,
                 std::vector<int> &ub_lo, std::vector<int> &ub_hi, std::vector<int> &cstart, std::string &err);
 

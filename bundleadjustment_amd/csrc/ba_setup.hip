@@ -58,10 +58,12 @@ __global__ void k_iota(int n, int *v) {
   if (t < n) v[t] = t;
 }
 
-// key of a point for the internal order: more observations first
-__global__ void k_degree_key(int P, const int *__restrict__ deg, int dmax, unsigned *__restrict__ key) {
+// key of a point for the internal order: more observations first, then by the lowest station that sees the point
+// (points of one neighbourhood end up side by side, so the records a station sweep gathers cluster)
+__global__ void k_degree_key(int P, const int *__restrict__ deg, const int *__restrict__ min_sta, int dmax, int sbits,
+                             unsigned *__restrict__ key) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < P) key[j] = (unsigned)(dmax - deg[j]);
+  if (j < P) key[j] = ((unsigned)(dmax - deg[j]) << sbits) | (sbits ? (unsigned)min_sta[j] : 0u);
 }
 
 // pt_int = inverse of pt_file; degrees in internal order (entry P = 0 closes the scan)
@@ -145,6 +147,12 @@ __global__ void k_pair_emit(int P, int S, const int *__restrict__ pt_start, cons
 
 }  // namespace
 
+// bits of the station index in the sort key of the point order (0: the key would not fit 32 bits, order by count only)
+int point_order_station_bits(int S, int dmax) {
+  const int sbits = bits_for((uint64_t)std::max(S, 1));
+  return bits_for((uint64_t)dmax) + sbits <= 32 ? sbits : 0;
+}
+
 bool setup_on_device(int64_t n_obs) {
   if (const char *e = std::getenv("BA_SETUP")) {
     if (std::string(e) == "host") return false;
@@ -156,15 +164,16 @@ bool setup_on_device(int64_t n_obs) {
 // Observations by point and by station, point records.  deg [P]: observations per point (host).  The arrays of `out`
 // are allocated by the caller; pt_file_host [P] receives the internal point order.
 int setup_sort_observations(hipStream_t s, int N, int S, int P, const int *obs_pt, const int *obs_sta, const double *const obs_cols[6],
-                            const double *pt_prior, const double *pt_sigma, const int *deg, const SetupArrays &out, int *pt_file_host,
-                            std::string &err) {
+                            const double *pt_prior, const double *pt_sigma, const int *deg, const int *min_sta, const SetupArrays &out,
+                            int *pt_file_host, std::string &err) {
   Scratch sc;
-  int *d_deg = nullptr, *d_iota = nullptr, *d_pt_int = nullptr, *d_deg_sorted = nullptr, *d_obs_pt_file = nullptr, *d_obs_sta_file = nullptr,
+  int *d_deg = nullptr, *d_min_sta = nullptr, *d_iota = nullptr, *d_pt_int = nullptr, *d_deg_sorted = nullptr, *d_obs_pt_file = nullptr, *d_obs_sta_file = nullptr,
       *d_perm = nullptr;
   unsigned *d_key = nullptr, *d_key2 = nullptr;
   double *d_col[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, *d_prior_file = nullptr, *d_sigma_file = nullptr;
   const int M = std::max(N, P) + 1;
   SETUP_HIP(sc.get(&d_deg, (size_t)P));
+  SETUP_HIP(sc.get(&d_min_sta, (size_t)P));
   SETUP_HIP(sc.get(&d_iota, (size_t)M));
   SETUP_HIP(sc.get(&d_pt_int, (size_t)P));
   SETUP_HIP(sc.get(&d_deg_sorted, (size_t)P + 1));
@@ -177,6 +186,7 @@ int setup_sort_observations(hipStream_t s, int N, int S, int P, const int *obs_p
   SETUP_HIP(sc.get(&d_prior_file, 3 * (size_t)P));
   SETUP_HIP(sc.get(&d_sigma_file, 3 * (size_t)P));
   SETUP_HIP(hipMemcpyAsync(d_deg, deg, (size_t)P * sizeof(int), hipMemcpyHostToDevice, s));
+  SETUP_HIP(hipMemcpyAsync(d_min_sta, min_sta, (size_t)P * sizeof(int), hipMemcpyHostToDevice, s));
   SETUP_HIP(hipMemcpyAsync(d_obs_pt_file, obs_pt, (size_t)N * sizeof(int), hipMemcpyHostToDevice, s));
   SETUP_HIP(hipMemcpyAsync(d_obs_sta_file, obs_sta, (size_t)N * sizeof(int), hipMemcpyHostToDevice, s));
   for (int k = 0; k < 6; ++k) SETUP_HIP(hipMemcpyAsync(d_col[k], obs_cols[k], (size_t)N * sizeof(double), hipMemcpyHostToDevice, s));
@@ -188,7 +198,8 @@ int setup_sort_observations(hipStream_t s, int N, int S, int P, const int *obs_p
   // one temporary buffer for all sorts and scans of this function
   size_t tmp_bytes = 0, need = 0;
   const int pbits = bits_for((uint64_t)std::max(P, 1)), sbits = bits_for((uint64_t)std::max(S, 1)), dbits = bits_for((uint64_t)dmax);
-  SETUP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, d_key, d_key2, d_iota, d_perm, P, 0, dbits, s));
+  const int obits = point_order_station_bits(S, dmax);  // station bits inside the key of the point order
+  SETUP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, d_key, d_key2, d_iota, d_perm, P, 0, dbits + obits, s));
   tmp_bytes = std::max(tmp_bytes, need);
   SETUP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, d_key, d_key2, d_iota, d_perm, N, 0, std::max(pbits, sbits), s));
   tmp_bytes = std::max(tmp_bytes, need);
@@ -200,8 +211,8 @@ int setup_sort_observations(hipStream_t s, int N, int S, int P, const int *obs_p
   // ---- internal point order: by number of observations, descending, stable
   hipLaunchKernelGGL(k_iota, dim3(nblocks(M, 256)), dim3(256), 0, s, M, d_iota);
   if (P > 0) {
-    hipLaunchKernelGGL(k_degree_key, dim3(nblocks(P, 256)), dim3(256), 0, s, P, d_deg, dmax, d_key);
-    SETUP_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_key, d_key2, d_iota, out.pt_file, P, 0, dbits, s));
+    hipLaunchKernelGGL(k_degree_key, dim3(nblocks(P, 256)), dim3(256), 0, s, P, d_deg, d_min_sta, dmax, obits, d_key);
+    SETUP_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_key, d_key2, d_iota, out.pt_file, P, 0, dbits + obits, s));
   }
   hipLaunchKernelGGL(k_point_order, dim3(nblocks(P + 1, 256)), dim3(256), 0, s, P, out.pt_file, d_deg, d_pt_int, d_deg_sorted);
   SETUP_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_deg_sorted, out.pt_start, P + 1, s));
