@@ -181,18 +181,31 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the solver has no CPU path")
+    # BA_BENCH_COMM=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (RCCL wants a GPU per rank):
+    # the ranks share the GPUs, torch.distributed runs over gloo and the solver's reductions are staged through the host.
+    rehearsal = world > 1 and os.environ.get("BA_BENCH_COMM") == "gloo"
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     from bundleadjustment_amd import capi, host, sharding, solver
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    red_dev = "cpu" if rehearsal else "cuda"  # where the few scalars that the ranks compare live
 
     hn = host.synth_config(args.config, scale=args.scale)
     full = hn.net
     net, _ = sharding.shard_network(full, rank, world)
     P = solver.Problem(net)
-    if world > 1:
+    if world > 1 and rehearsal:
+        def reduce_fn(buf, op):
+            dist.all_reduce(torch.from_numpy(buf), op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+        P.set_allreduce_host_staged(reduce_fn)
+    elif world > 1:
         ids = [solver.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         P.use_rccl(world, rank, ids[0])
@@ -228,7 +241,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     steps_done = sm["num_iterations"] - 1
@@ -283,7 +296,7 @@ def main():
     which_all = (0, 7, 8, 4, 6, 5, 3)
     ktime = {w: P.time_kernel(w, 10) for w in which_all}
     if world > 1:
-        t = torch.tensor([ktime[w] for w in which_all], dtype=torch.float64, device="cuda")
+        t = torch.tensor([ktime[w] for w in which_all], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ktime = {w: float(t[i].item()) for i, w in enumerate(which_all)}
     lin_iters = sm["total_linear_iterations"]
