@@ -1087,6 +1087,30 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
   int it = 0;
   double done = 0.0;
   const int expect = p->last_pcg_iters;
+  auto launch_batch = [&](int at, int n) -> int {
+    if (p->cg_graph && n == batch && (at & 1) == 0) {
+      HIP_OK(hipGraphLaunch(p->cg_graph, s));
+    } else if (p->cg_graph_tail && n == tail && (at & 1) == 0) {
+      HIP_OK(hipGraphLaunch(p->cg_graph_tail, s));
+    } else {
+      for (int k = 0; k < n; ++k) iteration((at + k) & 1);
+    }
+    return 0;
+  };
+  // What the previous solve says will be needed is queued without a look at the flag in between (the device is never
+  // left waiting for the host's answer and the next launch); only the last few iterations go one short batch at a time.
+  int queued = 0;
+  if (expect > 0 && p->cg_graph && p->cg_graph_tail) {
+    const int sure = std::min(expect - tail / 2, opt->pcg_max_iters);
+    while (queued + batch <= sure) {
+      BA_TRY(launch_batch(queued, batch));
+      queued += batch;
+    }
+    while (queued + tail <= sure) {
+      BA_TRY(launch_batch(queued, tail));
+      queued += tail;
+    }
+  }
   for (;;) {
     HIP_OK(hipMemcpyAsync(p->h_cgscal, p->d_cg2scal, 10 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
@@ -1095,13 +1119,7 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
     if (done != 0.0 || it >= opt->pcg_max_iters) break;
     const bool long_batch = expect <= 0 || it + batch <= expect - tail / 2;
     const int n = std::min(long_batch ? batch : tail, opt->pcg_max_iters - it);
-    if (p->cg_graph && n == batch && (it & 1) == 0) {
-      HIP_OK(hipGraphLaunch(p->cg_graph, s));
-    } else if (p->cg_graph_tail && n == tail && (it & 1) == 0) {
-      HIP_OK(hipGraphLaunch(p->cg_graph_tail, s));
-    } else {
-      for (int k = 0; k < n; ++k) iteration((it + k) & 1);
-    }
+    BA_TRY(launch_batch(it, n));
   }
   p->last_pcg_iters = it;
   *iters = it;
