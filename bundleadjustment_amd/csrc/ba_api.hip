@@ -61,7 +61,7 @@ int popcount32(unsigned v) { return __builtin_popcount(v); }
 // (the step phase), and for the maximum SC_GMAX_P, SC_NOTPD_P (the linearisation).
 enum Scal {
   SC_COST = 0, SC_FIXED, SC_GMAX, SC_STEP2_SC, SC_CNORM2_SC, SC_MCC, SC_STEP2_P, SC_CNORM2_P, SC_CCOST, SC_XNORM2_SC,
-  SC_XNORM2_P, SC_GMAX_P, SC_NOTPD_P, SC_GMAX_SC, SC_LS_DOT_P, SC_LS_DOT_SC, SC_LS_MAX_P, SC_LS_MAX_SC, SC_COUNT = 32
+  SC_XNORM2_P, SC_GMAX_P, SC_NOTPD_P, SC_GMAX_SC, SC_LS_DOT_P, SC_LS_DOT_SC, SC_LS_MAX_P, SC_LS_MAX_SC, SC_FLAGS, SC_COUNT = 32
 };
 
 }  // namespace
@@ -844,15 +844,15 @@ int linearize(ba_problem *p, const LmState &st) {
     HIP_OK(hipMemsetAsync(p->d_scal + SC_GMAX, 0, sizeof(double), s));
   }
   if (st.reduced) BA_TRY(build_reduced(p, st.reduced == 2));
+  launch_flag_to_scal(s, p->d_flags, p->d_scal, SC_FLAGS);  // the flag word comes back with the scalars: one read-back
   BA_TRY(p->check_kernels());
   BA_TRY(p->read_scal());
   p->h_scal[SC_GMAX] = std::max(p->h_scal[SC_GMAX], std::max(p->h_scal[SC_GMAX_P], p->h_scal[SC_GMAX_SC]));
-  unsigned flags[4];
-  HIP_OK(hipMemcpy(flags, p->d_flags, sizeof flags, hipMemcpyDeviceToHost));
-  if (p->ar && p->h_scal[SC_NOTPD_P] != 0.0 && !flags[0]) flags[0] = 1u;  // another rank's point block
-  if (flags[0]) {
-    HIP_OK(hipMemset(p->d_flags, 0, sizeof flags));
-    return fail(BA_ERR_NUMERIC, "%s block is not positive definite", (flags[0] & 1) ? "a point" : "a station");
+  unsigned flag = (unsigned)p->h_scal[SC_FLAGS];
+  if (p->ar && p->h_scal[SC_NOTPD_P] != 0.0 && !flag) flag = 1u;  // another rank's point block
+  if (flag) {
+    HIP_OK(hipMemset(p->d_flags, 0, 4 * sizeof(unsigned)));
+    return fail(BA_ERR_NUMERIC, "%s block is not positive definite", (flag & 1) ? "a point" : "a station");
   }
   return 0;
 }

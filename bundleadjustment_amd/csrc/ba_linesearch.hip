@@ -117,6 +117,8 @@ extern "C" double ba_line_search_contract(const ba_ls_sample *start, const ba_ls
   };
   offer(min_step);
   offer(max_step);
+  // (Ceres also offers the real parts of complex root pairs of the derivative; such a point is not stationary, so its value
+  //  cannot lie below the smallest of the ends and the real stationary points inside -- offering it changes nothing)
   if (p.size() > 2)
     for (double r : roots_within(derivative(p), min_step, max_step)) offer(r);
   // [MinimizeInterpolatingPolynomial] and the samples that lie inside

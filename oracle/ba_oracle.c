@@ -1426,6 +1426,8 @@ double bao_interpolating_step(const double *lower, const double *previous, const
   const double v_min = poly_eval(coef, n, x_min), v_max = poly_eval(coef, n, x_max);
   if (v_min < best) { best = v_min; best_x = x_min; }
   if (v_max < best) { best = v_max; best_x = x_max; }
+  /* ([CERES] also offers the real parts of complex root pairs of the derivative; such a point is not stationary, so its
+   *  value cannot lie below the smallest of the ends and the real stationary points inside: it changes nothing) */
   if (n > 2) {
     for (int i = 0; i < n - 1; ++i) der[i] = (n - 1 - i) * coef[i];
     const int nroots = poly_real_roots(der, n - 1, x_min, x_max, roots);

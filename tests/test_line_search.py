@@ -21,7 +21,10 @@ def numpy_contract(samples, lo, hi):
         A.append([(deg - j) * x ** (deg - j - 1) if j < deg else 0.0 for j in range(deg + 1)])
         rhs.append(g)
     c = np.linalg.solve(np.array(A), np.array(rhs))
-    cands = [(lo + hi) / 2, lo, hi] + [z.real for z in np.roots(np.polyder(c)) if abs(z.imag) < 1e-12 and lo <= z.real <= hi]
+    # as Ceres' MinimizePolynomial: the real parts of ALL roots of the derivative, complex pairs included.  The real
+    # part of a complex pair is no stationary point, so it can never beat the interval's ends and the real stationary
+    # points inside, which the oracle and the product offer: same minimum, asserted below for both.
+    cands = [(lo + hi) / 2, lo, hi] + [z.real for z in np.roots(np.polyder(c)) if lo <= z.real <= hi]
     vals = [np.polyval(c, x) for x in cands]
     return c, min(vals)
 
