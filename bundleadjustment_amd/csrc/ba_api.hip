@@ -736,15 +736,6 @@ PointArgs point_args(ba_problem *p, const double *vec) {
   return a;
 }
 
-// camera rows of J^T v for v = rec[voff]: station sweep with the camera columns, fold per camera (this rank's share)
-int camera_rows(ba_problem *p, int voff, double *out_cam) {
-  if (p->ncam == 0) return 0;
-  StationArgs sa = station_args(p, voff, 6 + BA_NCAMPAR);
-  launch_station_pass(p->stream, sa, SMODE_GATHER_CAM);
-  launch_camera_fold(p->stream, p->C, p->n_chunks, p->d_chunk_sta, p->d_sta_cam, p->d_cam, p->d_part, 6 + BA_NCAMPAR, 6, out_cam);
-  return 0;
-}
-
 int build_reduced(ba_problem *p, bool explicit_blocks);
 
 // Residuals, Jacobians, point elimination, station blocks, gradient, reduced right-hand side.
@@ -788,8 +779,11 @@ int linearize(ba_problem *p, const LmState &st) {
     if (p->d_Jt) {
       launch_camera_rows_fold(s, p->d_campart, obs_rows_blocks(p->N), p->ncam, g_cam, b_cam);
     } else {
-      BA_TRY(camera_rows(p, 6, g_cam));
-      BA_TRY(camera_rows(p, 7, b_cam));
+      // camera rows of the gradient and of the reduced right-hand side: one station sweep over the camera columns for both
+      StationArgs sc2 = station_args(p, 6, 2 * BA_NCAMPAR);
+      launch_station_pass(s, sc2, SMODE_CAM2);
+      launch_camera_fold(s, p->C, p->n_chunks, p->d_chunk_sta, p->d_sta_cam, p->d_cam, p->d_part, 2 * BA_NCAMPAR, 0, g_cam);
+      launch_camera_fold(s, p->C, p->n_chunks, p->d_chunk_sta, p->d_sta_cam, p->d_cam, p->d_part, 2 * BA_NCAMPAR, BA_NCAMPAR, b_cam);
     }
     if (st.need_norms) {
       StationArgs sn = station_args(p, 6, BA_NCAMPAR);
@@ -889,6 +883,9 @@ int build_reduced(ba_problem *p, bool explicit_blocks) {
   // summed in ONE reduction once the border sweeps are through.  One rank: the blocks are finished first, so that the
   // numbers of the multilevel preconditioner are refreshed on the second stream beside the border sweeps.
   const bool merged = p->ar && explicit_blocks && p->ncam > 0 && (p->d_Jt || p->d_Zc);
+  // No hierarchy to refresh (dense solver, or the first solves of a PCG run): the border sweeps go first as well, so
+  // that they run beside the block assembly instead of after it.
+  const bool border_first = merged || (explicit_blocks && !p->amg && p->ncam > 0 && (p->d_Jt || p->d_Zc));
   bool blocks_pending = false;  // merged: the wait for the block assembly on the second stream comes right before the sum
   auto finish_blocks = [&]() -> int {
     launch_bsr_add_diag(s, p->S, p->d_bsr_rowptr, p->d_Sdiag, p->d_bsr_val);
@@ -910,12 +907,18 @@ int build_reduced(ba_problem *p, bool explicit_blocks) {
       BA_TRY(p->allreduce(p->d_redsum, (int64_t)(p->redsum_blocks + p->redsum_border), 0));
       return finish_blocks();
     }
-    return p->allreduce(p->d_Ssc, (int64_t)p->redsum_border, 0);
+    BA_TRY(p->allreduce(p->d_Ssc, (int64_t)p->redsum_border, 0));
+    if (border_first) {
+      if (blocks_pending) HIP_OK(hipStreamWaitEvent(s, p->ev_schur, 0));
+      BA_TRY(p->allreduce(p->d_bsr_val, 36 * (int64_t)p->n_bsr, 0));
+      return finish_blocks();
+    }
+    return 0;
   };
   if (explicit_blocks) {
     if (p->schur_queued) {
       // queued by linearize right after the rows were written
-      if (merged) blocks_pending = true;
+      if (border_first) blocks_pending = true;
       else HIP_OK(hipStreamWaitEvent(s, p->ev_schur, 0));
       p->schur_queued = false;
     } else {
@@ -924,7 +927,7 @@ int build_reduced(ba_problem *p, bool explicit_blocks) {
       HIP_OK(hipMemsetAsync(p->d_bsr_val, 0, 36 * (size_t)p->n_bsr * sizeof(double), s));
       launch_schur_blocks(s, p->n_ublk, p->d_ublk_cstart, p->d_ublk_dst, p->d_pairs, p->d_Y, p->d_bsr_val);
     }
-    if (!merged) {
+    if (!border_first) {
       BA_TRY(p->allreduce(p->d_bsr_val, 36 * (int64_t)p->n_bsr, 0));
       BA_TRY(finish_blocks());
     }

@@ -13,7 +13,7 @@ struct CamRec;
 namespace ba {
 
 enum { MODE_APPLY = 0, MODE_BACKSUB = 1 };
-enum { SMODE_GATHER = 0, SMODE_GATHER_CAM = 1, SMODE_SETUP = 2, SMODE_CAMNORM = 3 };
+enum { SMODE_GATHER = 0, SMODE_GATHER_CAM = 1, SMODE_SETUP = 2, SMODE_CAMNORM = 3, SMODE_CAM2 = 4 };
 enum { BA_CHUNK = 1024 };  // observations of one station handled by one workgroup
 
 struct LinArgs {

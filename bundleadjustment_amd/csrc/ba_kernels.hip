@@ -647,11 +647,12 @@ k_mcc_reduced(int64_t nr, const double *__restrict__ g, const double *__restrict
 //                    out[chunk][27..32] = sum Js^T r      (gradient)
 //                    out[chunk][33..38] = sum Js^T rhat   (reduced right-hand side)
 //   SMODE_CAMNORM    out[chunk][0..nc)  = sum of squares of the Jc columns
+//   SMODE_CAM2       out[chunk][0..nc), [19..19+nc) = sum Jc^T r, sum Jc^T rhat (camera rows of gradient and reduced rhs in one sweep)
 template <int SMODE>
 __global__ void __launch_bounds__(256)
 k_station_pass(StationArgs a) {
   constexpr int NACC = SMODE == SMODE_GATHER ? 6 : SMODE == SMODE_GATHER_CAM ? 6 + BA_NCAMPAR
-                       : SMODE == SMODE_SETUP ? 39 : BA_NCAMPAR;
+                       : SMODE == SMODE_SETUP ? 39 : SMODE == SMODE_CAM2 ? 2 * BA_NCAMPAR : BA_NCAMPAR;
   __shared__ double lds[4 * NACC];
   const int ch = blockIdx.x;
   const int sta = a.chunk_sta[ch];
@@ -660,7 +661,7 @@ k_station_pass(StationArgs a) {
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
   int nc = 0;
-  if (SMODE == SMODE_GATHER_CAM || SMODE == SMODE_CAMNORM) nc = a.cam[a.sta_cam[sta]].nc;
+  if (SMODE == SMODE_GATHER_CAM || SMODE == SMODE_CAMNORM || SMODE == SMODE_CAM2) nc = a.cam[a.sta_cam[sta]].nc;
   for (int q = b0 + threadIdx.x; q < b1; q += blockDim.x) {
     const int e = a.sta_list[q];
     const double2 *rec = reinterpret_cast<const double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
@@ -679,6 +680,16 @@ k_station_pass(StationArgs a) {
         for (int k = 0; k < BA_NCAMPAR; ++k)
           if (k < nc) acc[6 + k] += jc[k] * v.x + jc[a.ncmax + k] * v.y;
       }
+    } else if (SMODE == SMODE_CAM2) {
+      const double2 rr = rec[6], rh = rec[7];
+      const double *jc = a.Jc + 2 * (int64_t)a.ncmax * e;
+#pragma unroll
+      for (int k = 0; k < BA_NCAMPAR; ++k)
+        if (k < nc) {
+          const double j0 = jc[k], j1 = jc[a.ncmax + k];
+          acc[k] += j0 * rr.x + j1 * rr.y;
+          acc[BA_NCAMPAR + k] += j0 * rh.x + j1 * rh.y;
+        }
     } else if (SMODE == SMODE_SETUP) {
       double r0[6], r1[6];
       {
@@ -1501,6 +1512,7 @@ void launch_station_pass(hipStream_t s, const StationArgs &a, int smode) {
     case SMODE_GATHER: hipLaunchKernelGGL((k_station_pass<SMODE_GATHER>), g, b, 0, s, a); break;
     case SMODE_GATHER_CAM: hipLaunchKernelGGL((k_station_pass<SMODE_GATHER_CAM>), g, b, 0, s, a); break;
     case SMODE_SETUP: hipLaunchKernelGGL((k_station_pass<SMODE_SETUP>), g, b, 0, s, a); break;
+    case SMODE_CAM2: hipLaunchKernelGGL((k_station_pass<SMODE_CAM2>), g, b, 0, s, a); break;
     default: hipLaunchKernelGGL((k_station_pass<SMODE_CAMNORM>), g, b, 0, s, a); break;
   }
 }
