@@ -325,7 +325,7 @@ def main():
                         "share_of_kernel_time": ktime[w] * calls[w] / max(sum(share.values()), 1e-30)})
 
     out = {
-        "metric": "LM iter/s (10M-obs synthetic network)",
+        "metric": "LM iter/s (10M-obs synthetic network)" if args.config == "cfg4" and args.scale == 1.0 else f"LM iter/s ({args.config}, scale {args.scale})",
         "value": args.steps / elapsed,
         "unit": "iter/s",
         "n_gpus": world,
