@@ -185,15 +185,16 @@ __device__ __forceinline__ void tile_store(double *buf, const double (&v)[R], do
     for (int i = 0; i < R / 2; ++i) {
       const int q = 2 * (i * 64 + lane);
       const double *src = buf + (q / R) * (R + 1) + q % R;
-      const double2 x = make_double2(src[0], src[1]);
-      if (q < nvalid * R) *reinterpret_cast<double2 *>(g + q) = x;
+      typedef double nt2 __attribute__((ext_vector_type(2)));
+      const nt2 x = {src[0], src[1]};
+      if (q < nvalid * R) __builtin_nontemporal_store(x, reinterpret_cast<nt2 *>(g + q));
     }
   } else {
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       const int q = i * 64 + lane;
       const double x = buf[(q / R) * (R + 1) + q % R];
-      if (q < nvalid * R) g[q] = x;
+      if (q < nvalid * R) __builtin_nontemporal_store(x, g + q);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
