@@ -61,33 +61,79 @@ k_amg_build_P(int nP, const int *__restrict__ P_row, const int *__restrict__ P_o
   if (lane < 36) P_val[36 * (int64_t)t + lane] = own - omega * acc;
 }
 
-// out[o] = sum_k op(X[la[k]]) Y[lb[k]], k in [ptr[o], ptr[o+1]) ; op = transpose when TRANS ; one wave per block
+// out[o] = sum_k op(X[la[k]]) Y[lb[k]], k in [ptr[o], ptr[o+1]) ; op = transpose when TRANS.
+// One wave per PAIR of output blocks, on the matrix cores: the two 6x6 products of a step sit on the diagonal of one
+// 16x16 tile of v_mfma_f64_16x16x4_f64 (rows/columns 0-5 and 6-11; the summation index 6 takes two instructions), so a
+// lane fetches single matrix entries straight from memory -- no shuffles -- and four steps' entries are in flight at
+// once, with the indices of the next four already requested.  The lists are short (a dozen to a hundred products) and
+// every product is two dependent loads (index, block): the kernel is bounded by how many of them overlap.
+typedef double amg_d4 __attribute__((ext_vector_type(4)));
 template <int TRANS>
 __global__ void __launch_bounds__(256)
 k_amg_products(int n_out, const int *__restrict__ ptr, const int *__restrict__ la, const int *__restrict__ lb,
                const double *__restrict__ X, const double *__restrict__ Y, double *__restrict__ out) {
-  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (o >= n_out) return;
-  const int e = lane < 36 ? lane : 0, r = e / 6, c = e % 6;
-  double acc = 0.0;
-  const int beg = ptr[o], end = ptr[o + 1];
-  double xv = 0.0, yv = 0.0;
-  if (beg < end) {
-    xv = X[36 * (int64_t)la[beg] + e];
-    yv = Y[36 * (int64_t)lb[beg] + e];
-  }
-  for (int k = beg; k < end; ++k) {
-    double xn = 0.0, yn = 0.0;
-    if (k + 1 < end) {  // next pair in flight while this one is multiplied
-      xn = X[36 * (int64_t)la[k + 1] + e];
-      yn = Y[36 * (int64_t)lb[k + 1] + e];
-    }
+  constexpr int U = 4;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (2 * w >= n_out) return;
+  const int c16 = lane & 15, kq = lane >> 4, g = c16 / 6, e = c16 % 6;
+  const int o = 2 * w + g;
+  const bool active = g < 2 && o < n_out;
+  const int p0 = ptr[2 * w], p1 = ptr[2 * w + 1], p2 = (2 * w + 1 < n_out) ? ptr[2 * w + 2] : p1;
+  const int beg = g == 0 ? p0 : p1, len = active ? (g == 0 ? p1 - p0 : p2 - p1) : 0;
+  const int nsteps = max(p1 - p0, p2 - p1);
+  // entry offsets inside a block: operand A = op(X)[e][kk], operand B = Y[kk][e], kk = kq + 4 c
+  int offa[2], offb[2];
+  bool okk[2];
 #pragma unroll
-    for (int m = 0; m < 6; ++m) acc += __shfl(xv, TRANS ? (6 * m + r) : (6 * r + m), 64) * __shfl(yv, 6 * m + c, 64);
-    xv = xn;
-    yv = yn;
+  for (int c = 0; c < 2; ++c) {
+    const int kk = kq + 4 * c;
+    okk[c] = kk < 6;
+    offa[c] = okk[c] ? (TRANS ? 6 * kk + e : 6 * e + kk) : 0;
+    offb[c] = okk[c] ? 6 * kk + e : 0;
   }
-  if (lane < 36) out[36 * (int64_t)o + lane] = acc;
+  amg_d4 acc = {0.0, 0.0, 0.0, 0.0};
+  int ia[U], ib[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const bool on = u < len;
+    ia[u] = on ? la[beg + u] : -1;
+    ib[u] = on ? lb[beg + u] : -1;
+  }
+  for (int s = 0; s < nsteps; s += U) {
+    int na[U], nb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool on = s + U + u < len;
+      na[u] = on ? la[beg + s + U + u] : -1;
+      nb[u] = on ? lb[beg + s + U + u] : -1;
+    }
+    double xa[U][2], yb[U][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const bool on = ia[u] >= 0 && okk[c];
+        xa[u][c] = on ? X[36 * (int64_t)ia[u] + offa[c]] : 0.0;
+        yb[u][c] = on ? Y[36 * (int64_t)ib[u] + offb[c]] : 0.0;
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u][c], yb[u][c], acc, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ia[u] = na[u];
+      ib[u] = nb[u];
+    }
+  }
+  // D layout: column = lane & 15, row = (lane >> 4) + 4 reg ; the block of this lane's column group is rows 6g .. 6g+5
+  if (active) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = kq + 4 * reg - 6 * g;
+      if (row >= 0 && row < 6) out[36 * (int64_t)o + 6 * row + e] = acc[reg];
+    }
+  }
 }
 
 // x_out = Dinv A x_in ; one wave per block row (power iteration for the damping factor)
@@ -732,9 +778,9 @@ void symbolic(const Pattern &A, const std::vector<int> &agg, int nc, const std::
 void numeric_level(hipStream_t s, const Level &L, unsigned *flags) {
   hipLaunchKernelGGL(k_amg_build_P, dim3(nblk(L.nP, 4)), dim3(256), 0, s, L.nP, L.P_row, L.P_own, L.Pa_ptr, L.Pa_idx, L.A_val,
                      L.Dinv, L.omega, L.P_val);
-  hipLaunchKernelGGL(k_amg_products<0>, dim3(nblk(L.nAP, 4)), dim3(256), 0, s, L.nAP, L.AP_ptr, L.AP_la, L.AP_lb, L.A_val,
+  hipLaunchKernelGGL(k_amg_products<0>, dim3(nblk(L.nAP, 8)), dim3(256), 0, s, L.nAP, L.AP_ptr, L.AP_la, L.AP_lb, L.A_val,
                      L.P_val, L.AP_val);
-  hipLaunchKernelGGL(k_amg_products<1>, dim3(nblk(L.nAc, 4)), dim3(256), 0, s, L.nAc, L.Ac_ptr, L.Ac_la, L.Ac_lb, L.P_val,
+  hipLaunchKernelGGL(k_amg_products<1>, dim3(nblk(L.nAc, 8)), dim3(256), 0, s, L.nAc, L.Ac_ptr, L.Ac_la, L.Ac_lb, L.P_val,
                      L.AP_val, L.Ac_val);
   launch_invert_blocks(s, L.nc, L.Ac_val, L.Ac_diag, L.used_c, L.Dinv_c, flags);
 }
