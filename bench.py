@@ -209,6 +209,10 @@ def main():
         ids = [solver.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         P.use_rccl(world, rank, ids[0])
+    if world > 1:
+        # rows of the PCG's product split over the ranks when the library's model says it pays (it does not at 10 000
+        # stations); BA_BENCH_PCG_ROWS=always|never overrides
+        P.shard_reduced_solve(rank, world, {"always": 1, "never": -1}.get(os.environ.get("BA_BENCH_PCG_ROWS", ""), 0))
     P.set_parameters()
 
     free_cam = int(sum(bin(int(a)).count("1") + bin(int(b) & 7).count("1") for a, b in zip(full.ap_free_mask, full.iop_free_mask)))
@@ -264,7 +268,8 @@ def main():
                 "solve_ms_per_step": 1e3 * sum(r["t_solve_s"] for r in rows2) / args.steps,
                 "evaluate_ms_per_step": 1e3 * sum(r["t_eval_s"] for r in rows2) / args.steps,
                 "reductions_per_step": n_red / args.steps, "reduction_MB_per_step": red_bytes / args.steps / 1e6,
-                "reduction_ms_per_step": 1e3 * red_s / args.steps}
+                "reduction_ms_per_step": 1e3 * red_s / args.steps,
+                "pcg_product_rows": list(P.reduced_solve_rows())}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
 

@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "ba_cg_device.h"
@@ -819,7 +820,9 @@ int amg_build(Amg *a, hipStream_t s, int nb0, const std::vector<int> &rowptr, co
   if (!a->dalloc(&a->d_tmp, tmp_cap) || !a->dalloc(&a->d_tmp2, n0) || !a->dalloc(&a->d_norm, 2) || !a->dalloc(&a->d_flags, 1))
     return -1;
   (void)hipMemsetAsync(a->d_flags, 0, sizeof(unsigned), s);
-  for (int l = 0; l < AMG_MAX_LEVELS - 1 && A.nb >= 2 * AMG_MIN_BLOCKS; ++l) {
+  int max_levels = AMG_MAX_LEVELS;
+  if (const char *e = std::getenv("BA_AMG_LEVELS")) max_levels = std::min(std::max(std::atoi(e), 1), (int)AMG_MAX_LEVELS);
+  for (int l = 0; l < max_levels - 1 && A.nb >= 2 * AMG_MIN_BLOCKS; ++l) {
     const int nA = (int)A.col.size();
     std::vector<double> fro(nA);
     if ((size_t)nA > tmp_cap) {
@@ -948,6 +951,13 @@ void launch_amg_cg_iteration(hipStream_t s, const BsrCgArgs &cg, const Amg *a, i
     return;
   }
   launch_bsr_spmv(s, cg, parity);
+  launch_amg_cg_iteration_after_product(s, cg, a, parity);
+}
+
+bool amg_cg_iteration_splits(const BsrCgArgs &cg, const Amg *a) { return apply_args(a).n_transfers > 0 && cg.r2 != nullptr; }
+
+void launch_amg_cg_iteration_after_product(hipStream_t s, const BsrCgArgs &cg, const Amg *a, int parity) {
+  const AmgApplyArgs aa = apply_args(a);
   const int nbv = cg2_blocks_vec(cg.S), nbr = nblk(aa.t[0].nc, 4);
   hipLaunchKernelGGL(k_amg_update1_restrict, dim3(nbv + nbr), dim3(256), 0, s, cg, aa.t[0], parity, cg2_blocks_spmv(cg.S), nbv, aa.part);
   amg_finish_iteration(s, cg, a, parity, 1, 0.0, 1);

@@ -136,6 +136,12 @@ struct ba_problem {
   hipGraphExec_t cg_graph = nullptr;  // one batch of PCG iterations, captured once
   hipGraphExec_t cg_graph_tail = nullptr;  // a short batch for the end of a solve
   int last_pcg_iters = 0;                  // iterations the previous solve of this problem took (0: none yet)
+  // several ranks: which of how many this problem is (ba_shard_reduced_solve / ba_use_rccl), whether the product of the
+  // block-sparse PCG is formed by rows (-1 never, 0 when the model below says it pays, 1 always), its buffer
+  // [q | partials], and the rows the last solve gave this rank (both 0: every rank formed the whole product)
+  int shard_rank = 0, shard_world = 1, shard_mode = 0;
+  double *d_qshard = nullptr;
+  int last_row0 = 0, last_row_end = 0;
   bool cg_graph_failed = false;
   int cg_graph_precond = -1;          // preconditioner the captured batch was recorded with
   ba::Amg *amg = nullptr;             // multilevel preconditioner (built at the first PCG solve)
@@ -972,6 +978,20 @@ int build_reduced(ba_problem *p, bool explicit_blocks) {
   return 0;
 }
 
+// Whether forming q = S p by rows pays on `world` ranks: the time of the product that the other ranks take over against
+// the time of the sum that completes q.  The product streams 292 B per block and 96 B per station at the 3.5 TB/s the
+// kernel reaches; the sum is a ring all-reduce over xGMI links of about 150 GB/s (2 (W-1)/W of the buffer crosses each
+// link) plus 30 us for a small collective and for queueing the iteration launch by launch instead of as a graph.
+// 10 000 stations / 220 000 blocks on 8 ranks: 16 us saved, 36 us spent -- every rank keeps the whole product;
+// 50 000 stations / 1.1 M blocks: 79 us saved, 58 us spent -- by rows.
+bool row_sharding_pays(const ba_problem *p, int nbs) {
+  const double W = p->shard_world;
+  const double t_product = (292.0 * (double)p->n_bsr + 96.0 * (double)p->S) / 3.5e12;
+  const double bytes = 8.0 * (6.0 * (double)p->S + (double)nbs * (1 + p->ncam));
+  const double t_sum = 30e-6 + 2.0 * (W - 1.0) / W * bytes / 150e9;
+  return t_product * (1.0 - 1.0 / W) > t_sum;
+}
+
 // PCG on the explicit block-sparse system: the whole iteration stays on the device, the host
 // only looks at the stopping flag once per batch.
 int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
@@ -1048,9 +1068,44 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
     }
   }
   const int precond = use_amg ? (use_defl ? 2 : 0) : 1;
-  auto iteration = [&](int parity) {
-    if (use_amg) launch_amg_cg_iteration(s, a, p->amg, parity);
-    else launch_cg2_iteration(s, a, parity);
+  // Several ranks: every rank runs the whole iteration on the summed system (all scalars and vectors are bitwise equal
+  // on all of them, so no rank needs anything from another), unless the product q = S p is large enough to be worth
+  // forming by rows: each rank then takes a slice of the station rows with an equal share of the blocks, leaves zeros
+  // in the rest of q, and one sum over the ranks of [q | partial sums] completes it -- adding zeros is exact, so the
+  // vectors stay equal on all ranks.  Such an iteration holds a collective and is queued launch by launch, not as a graph.
+  const int nbs = cg2_blocks_spmv(p->S);
+  const bool shard_rows = p->ar && p->shard_world > 1 && p->shard_mode >= 0 && use_amg && amg_cg_iteration_splits(a, p->amg) &&
+                          (p->shard_mode > 0 || row_sharding_pays(p, nbs));
+  const int64_t n_shard_buf = 6 * (int64_t)p->S + (int64_t)nbs * (1 + p->ncam);
+  p->last_row0 = p->last_row_end = 0;
+  if (shard_rows) {
+    if (!p->d_qshard) BA_TRY(p->dalloc(&p->d_qshard, (size_t)n_shard_buf));
+    a.q = p->d_qshard;
+    a.part_pq = a.q + 6 * (size_t)p->S;
+    a.part_qc = a.part_pq + nbs;
+    const std::vector<int> &rp = p->bsr_rowptr_h;
+    auto cut = [&](int r) {  // first row of rank r: the blocks before it are r / world of all
+      if (r <= 0) return 0;
+      if (r >= p->shard_world) return p->S;
+      const int64_t target = (int64_t)rp[p->S] * r / p->shard_world;
+      return (int)(std::lower_bound(rp.begin(), rp.begin() + p->S, (int)target) - rp.begin());
+    };
+    a.rows_sharded = 1;
+    a.row0 = p->last_row0 = cut(p->shard_rank);
+    a.row_end = p->last_row_end = cut(p->shard_rank + 1);
+  }
+  auto iteration = [&](int parity) -> int {
+    if (shard_rows) {
+      HIP_OK(hipMemsetAsync(a.q, 0, 6 * (size_t)p->S * sizeof(double), s));
+      launch_bsr_spmv(s, a, parity);
+      BA_TRY(p->allreduce(a.q, n_shard_buf, 0));
+      launch_amg_cg_iteration_after_product(s, a, p->amg, parity);
+    } else if (use_amg) {
+      launch_amg_cg_iteration(s, a, p->amg, parity);
+    } else {
+      launch_cg2_iteration(s, a, parity);
+    }
+    return 0;
   };
   if (use_amg) launch_amg_cg_init(s, a, p->amg, opt->pcg_rtol);
   else launch_cg2_init(s, a, opt->pcg_rtol);
@@ -1064,14 +1119,14 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
     if (p->cg_graph_tail) hipGraphExecDestroy(p->cg_graph_tail);
     p->cg_graph = p->cg_graph_tail = nullptr;
   }
-  if (!p->cg_graph && !p->cg_graph_failed) {
+  if (!p->cg_graph && !p->cg_graph_failed && !shard_rows) {
     p->cg_graph_precond = precond;
     // the launch sequence of a batch never changes for this problem: capture it into a graph once
     auto capture = [&](int n, hipGraphExec_t *exec) {
       hipGraph_t graph = nullptr;
       bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
       if (ok) {
-        for (int k = 0; k < n; ++k) iteration(k & 1);
+        for (int k = 0; k < n; ++k) (void)iteration(k & 1);
         ok = hipStreamEndCapture(s, &graph) == hipSuccess && graph != nullptr;
       }
       if (ok) ok = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0) == hipSuccess;
@@ -1091,19 +1146,19 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
   double done = 0.0;
   const int expect = p->last_pcg_iters;
   auto launch_batch = [&](int at, int n) -> int {
-    if (p->cg_graph && n == batch && (at & 1) == 0) {
+    if (!shard_rows && p->cg_graph && n == batch && (at & 1) == 0) {
       HIP_OK(hipGraphLaunch(p->cg_graph, s));
-    } else if (p->cg_graph_tail && n == tail && (at & 1) == 0) {
+    } else if (!shard_rows && p->cg_graph_tail && n == tail && (at & 1) == 0) {
       HIP_OK(hipGraphLaunch(p->cg_graph_tail, s));
     } else {
-      for (int k = 0; k < n; ++k) iteration((at + k) & 1);
+      for (int k = 0; k < n; ++k) BA_TRY(iteration((at + k) & 1));
     }
     return 0;
   };
   // What the previous solve says will be needed is queued without a look at the flag in between (the device is never
   // left waiting for the host's answer and the next launch); only the last few iterations go one short batch at a time.
   int queued = 0;
-  if (expect > 0 && p->cg_graph && p->cg_graph_tail) {
+  if (expect > 0 && ((p->cg_graph && p->cg_graph_tail) || shard_rows)) {
     const int sure = std::min(expect - tail / 2, opt->pcg_max_iters);
     while (queued + batch <= sure) {
       BA_TRY(launch_batch(queued, batch));
@@ -2340,6 +2395,22 @@ int ba_set_device(int32_t device) {
   return 0;
 }
 
+int ba_shard_reduced_solve(ba_problem *p, int32_t rank, int32_t n_ranks, int32_t mode) {
+  if (!p || n_ranks < 1 || rank < 0 || rank >= n_ranks || mode < -1 || mode > 1)
+    return fail(BA_ERR_INVALID, "ba_shard_reduced_solve: bad argument");
+  p->shard_rank = rank;
+  p->shard_world = n_ranks;
+  p->shard_mode = mode;
+  return 0;
+}
+
+int ba_reduced_solve_rows(const ba_problem *p, int32_t *row_begin, int32_t *row_end) {
+  if (!p || !row_begin || !row_end) return fail(BA_ERR_INVALID, "ba_reduced_solve_rows: null argument");
+  *row_begin = p->last_row0;
+  *row_end = p->last_row_end;
+  return 0;
+}
+
 int ba_set_allreduce(ba_problem *p, ba_allreduce_fn fn, void *user) {
   if (!p) return fail(BA_ERR_INVALID, "ba_set_allreduce: null problem");
   p->ar = fn;
@@ -2383,6 +2454,8 @@ int ba_use_rccl(ba_problem *p, int32_t n_ranks, int32_t rank, const void *unique
   std::memcpy(&id, unique_id_128, sizeof id);
   const ncclResult_t r = ncclCommInitRank(&p->comm, n_ranks, id, rank);
   if (r != ncclSuccess) return fail(BA_ERR_COMM, "ncclCommInitRank: %s", ncclGetErrorString(r));
+  p->shard_rank = rank;
+  p->shard_world = n_ranks;
   return ba_set_allreduce(p, rccl_allreduce, p);
 }
 

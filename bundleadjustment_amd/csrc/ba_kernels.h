@@ -182,6 +182,9 @@ struct BsrCgArgs {
   // null, or PCG_TRACE_KERNELS x PCG_TRACE_MAXWG x PCG_TRACE_SLOTS time stamps (100 MHz counter) that thread 0 of every
   // workgroup leaves at the phase marks of the iteration's kernels (ba_time_kernel, which = 9)
   unsigned long long *trace;
+  // Several ranks, product sharded by rows: this rank forms rows [row0, row_end) of q = S p (and their share of the
+  // partial sums) and the ranks add their pieces up before the next kernel; rows_sharded == 0: all rows.
+  int rows_sharded, row0, row_end;
 };
 enum { PCG_TRACE_KERNELS = 5, PCG_TRACE_MAXWG = 2048, PCG_TRACE_SLOTS = 8 };
 void launch_schur_blocks(hipStream_t s, int nu, const int *cstart, const int2 *dst, const int2 *pairs, const double *Y, double *val);
@@ -237,6 +240,9 @@ int amg_build(Amg *a, hipStream_t s, int nb0, const std::vector<int> &rowptr, co
 void amg_numeric(Amg *a, hipStream_t s, const double *d_val, const double *d_Dinv);
 void launch_amg_cg_init(hipStream_t s, const BsrCgArgs &cg, const Amg *a, double rtol);
 void launch_amg_cg_iteration(hipStream_t s, const BsrCgArgs &cg, const Amg *a, int parity);
+// the same in two halves, for callers that put a sum over ranks between the product q = S p (launch_bsr_spmv) and the rest
+bool amg_cg_iteration_splits(const BsrCgArgs &cg, const Amg *a);
+void launch_amg_cg_iteration_after_product(hipStream_t s, const BsrCgArgs &cg, const Amg *a, int parity);
 
 // ba_chol.hip: in-place lower Cholesky of a dense row-major n x n matrix (ld = n) and the
 // solve L L^T x = b (b overwritten).  info[0] != 0 after the factorisation when a pivot was

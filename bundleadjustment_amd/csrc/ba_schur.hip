@@ -351,7 +351,8 @@ k_bsr_spmv(BsrCgArgs a, int parity) {
   double pq = 0.0;
   double tcam0 = 0.0, tcam1 = 0.0;  // camera-row partials of this lane: columns lane and lane + 64
   const double *pcam = a.p + 6 * (int64_t)a.S;
-  for (int i = blockIdx.x * SPMV_WAVES + w; i < a.S; i += gridDim.x * SPMV_WAVES) {
+  const int row_begin = a.rows_sharded ? a.row0 : 0, row_end = a.rows_sharded ? a.row_end : a.S;
+  for (int i = row_begin + blockIdx.x * SPMV_WAVES + w; i < row_end; i += gridDim.x * SPMV_WAVES) {
     double s = 0.0;
     // The row's blocks are contiguous in memory (288 B each).  Lanes 0..53 read them as one stream,
     // 16 B per lane: lane l holds piece l % 18 of block l / 18 of each triple, i.e. always the same

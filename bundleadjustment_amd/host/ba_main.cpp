@@ -88,7 +88,7 @@ static void usage() {
           "               [--solver auto|dense|pcg|implicit] [--pcg-rtol X] [--max-iter N] [--covariance] [--model M]\n"
           "               [--bins B] [--truth file.xyz] [--iop-bounds]\n"
           "       ba_main --synth C S P RAYS [same options]\n"
-          "       ba_main ... --ranks N --rank R --id-file PATH [--comm rccl|shm]\n"
+          "       ba_main ... --ranks N --rank R --id-file PATH [--comm rccl|shm] [--pcg-rows auto|never|always]\n"
           "                                          one process per GPU: start N of these, R = 0..N-1\n"
           "  MASK: bit k of --free-ap frees AP[k] (a1 a2 k1 k2 k3 p1 p2 ep1..ep9); default 0x4 = k1 only,\n"
           "        the reference's choice (src/main.cpp:4487-4504).  --free-iop: bits xp yp c, default 7.\n"
@@ -105,6 +105,8 @@ static void usage() {
           "        visible, and the ranks sum the reduced camera system over RCCL.  Rank 0 writes the communicator's id to\n"
           "        PATH, the others wait for it.  Every rank writes the results of its own points to DIR/rank<R>.\n"
           "        --comm shm sums through a memory-mapped file at PATH instead (ranks on one machine that share GPUs).\n"
+          "        --pcg-rows: whether the ranks split the rows of the product inside the block-sparse PCG (one more sum per\n"
+          "        PCG iteration); auto: when the network is large enough for that to pay.\n"
           "  --covariance: standard deviations of all parameters in the result files (the reference's COMPUTECX\n"
           "        branch, src/main.cpp:5261); small networks only.\n");
 }
@@ -115,7 +117,7 @@ int main(int argc, char **argv) {
   unsigned ap_mask = 0x4, iop_mask = 7;
   bool synth = false, covariance = false, iop_bounds = false;
   int model = 0, bins = 30;
-  std::string truth, id_file, comm = "rccl";
+  std::string truth, id_file, comm = "rccl", pcg_rows = "auto";
   ShmComm shm;
   int ranks = 1, rank = 0;
   ba_options opt;
@@ -142,6 +144,7 @@ int main(int argc, char **argv) {
     else if (a == "--rank") rank = atoi(next());
     else if (a == "--id-file") id_file = next();
     else if (a == "--comm") comm = next();
+    else if (a == "--pcg-rows") pcg_rows = next();
     else pos.push_back(a);
   }
   ba_network *net = nullptr;
@@ -209,6 +212,10 @@ int main(int argc, char **argv) {
       fclose(f);
     }
     if (ba_use_rccl(p, ranks, rank, id)) { fprintf(stderr, "error: %s\n", ba_last_error()); return 1; }
+  }
+  if (ranks > 1) {
+    const int mode = pcg_rows == "never" ? -1 : pcg_rows == "always" ? 1 : 0;
+    if (ba_shard_reduced_solve(p, rank, ranks, mode)) { fprintf(stderr, "error: %s\n", ba_last_error()); return 1; }
   }
   if (iop_bounds) {
     std::vector<double> lo(3 * (size_t)d.n_cam), hi(3 * (size_t)d.n_cam);

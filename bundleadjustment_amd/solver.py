@@ -23,6 +23,7 @@ EXPORTS = ("ba_default_options", "ba_create", "ba_destroy", "ba_set_parameters",
            "ba_solve_resident", "ba_solve", "ba_evaluate", "ba_covariance", "ba_sparsity", "ba_residual_jacobian", "ba_time_kernel",
            "ba_set_allreduce", "ba_copy_to_host", "ba_copy_to_device", "ba_rccl_unique_id", "ba_use_rccl", "ba_evaluate_noalloc",
            "ba_device_count", "ba_set_device", "ba_reduction_timing", "ba_reduction_stats",
+           "ba_shard_reduced_solve", "ba_reduced_solve_rows",
            "ba_last_error")
 
 
@@ -72,6 +73,8 @@ def lib():
         L.ba_reduction_timing.argtypes = [C.c_void_p, C.c_int32]
         L.ba_reduction_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.ba_set_device.argtypes = [C.c_int32]
+        L.ba_shard_reduced_solve.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        L.ba_reduced_solve_rows.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.ba_use_rccl.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.ba_evaluate_noalloc.argtypes = [C.POINTER(BaDims), C.POINTER(BaInputs)] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 3
         _lib = L
@@ -245,6 +248,17 @@ class Problem:
         n, b, t = C.c_int64(), C.c_double(), C.c_double()
         _check(lib().ba_reduction_stats(self._h, C.byref(n), C.byref(b), C.byref(t)))
         return n.value, b.value, t.value
+
+    def shard_reduced_solve(self, rank, n_ranks, mode=0):
+        """This problem is rank `rank` of `n_ranks`; the block-sparse PCG forms its product by rows never (-1), when the
+        library's model says it pays (0) or always (1)."""
+        _check(lib().ba_shard_reduced_solve(self._h, rank, n_ranks, mode))
+
+    def reduced_solve_rows(self):
+        """Station rows of the product that the last block-sparse PCG solve gave this rank; (0, 0): all of them on every rank."""
+        a, b = C.c_int32(), C.c_int32()
+        _check(lib().ba_reduced_solve_rows(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def use_rccl(self, n_ranks, rank, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, 128)

@@ -341,6 +341,18 @@ int ba_set_allreduce(ba_problem *p, ba_allreduce_fn fn, void *user);
 int ba_reduction_timing(ba_problem *p, int32_t on);
 int ba_reduction_stats(ba_problem *p, int64_t *count, double *bytes, double *seconds);
 
+/* Which rank of how many this problem is, and whether the block-sparse PCG forms its product q = S p by rows: every rank
+ * then takes a slice of the station rows holding an equal share of the 6x6 blocks, and one more reduction per PCG
+ * iteration -- [q | partial sums], 6 n_sta + a few thousand doubles -- completes the vector on all ranks (everything else
+ * of the iteration stays replicated: the vectors are bitwise equal on all ranks either way).  mode -1: never; 0: when the
+ * time of the product that the other ranks take over exceeds the time of that reduction (a ring over xGMI links of
+ * about 150 GB/s plus 30 us: true from a few ten thousand stations on); 1: always.  Without this call every rank forms
+ * the whole product; ba_use_rccl makes it with mode 0.  ba_reduced_solve_rows returns the rows that the last
+ * block-sparse PCG solve gave this rank (0, 0: the whole product on every rank).
+ * No counterpart in the reference (single-process, src/main.cpp:4705-4721). */
+int ba_shard_reduced_solve(ba_problem *p, int32_t rank, int32_t n_ranks, int32_t mode);
+int ba_reduced_solve_rows(const ba_problem *p, int32_t *row_begin, int32_t *row_end);
+
 /* Helpers for callbacks that stage through host memory (e.g. a gloo or MPI reduction in tests):
  * synchronous copies ordered after the work already queued on hip_stream. */
 int ba_copy_to_host(void *host_dst, const double *device_src, int64_t count, void *hip_stream);

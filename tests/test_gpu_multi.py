@@ -40,7 +40,7 @@ def _options(ls, bounded):
     return opt
 
 
-def _worker(rank, world, port, ls, n_cam, out, bounded=False):
+def _worker(rank, world, port, ls, n_cam, out, bounded=False, by_rows=False):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -62,10 +62,13 @@ def _worker(rank, world, port, ls, n_cam, out, bounded=False):
         P.set_allreduce_host_staged(reduce_fn)
         if bounded:
             P.set_iop_bounds(*_box(net))
+        if by_rows:
+            P.shard_reduced_solve(rank, world, 1)
         opt = _options(ls, bounded)
         n_setup = len(calls)
         eop, xyz, iop, ap, sm, rows = P.solve(opt)
         sm["reductions_in_solve"] = len(calls) - n_setup
+        sm["rows_of_the_product"] = P.reduced_solve_rows()
     gathered = [None] * world
     dist.all_gather_object(gathered, (sl.start, sl.stop, xyz))
     if rank == 0:
@@ -108,7 +111,41 @@ def test_two_ranks_match_oracle(ls, n_cam, bounded):
         assert res[4]["reductions_in_solve"] <= 4 * len(res[5]) + 4, (res[4]["reductions_in_solve"], len(res[5]))
 
 
-def test_two_ranks_of_the_command_line_program(tmp_path):
+@pytest.mark.parametrize("n_cam", [1, 3])
+def test_two_ranks_product_by_rows(n_cam):
+    """The block-sparse PCG with its product q = S p formed by rows: each rank takes half of the blocks and one more sum
+    per PCG iteration completes the vector.  Same answer as the oracle's solve of the whole network; one reduction per
+    PCG iteration on top of the four per LM iteration."""
+    from oracle import py_oracle as po
+    from util import assert_solve_parity
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 1, n_cam, q, False, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    net = _make_net(n_cam)
+    o = po.solve(net, _options(1, False), po.SCHUR_DENSE)
+    g = list(res)
+    for k in ("num_residuals_reduced", "num_parameters_reduced", "num_effective_parameters_reduced", "num_parameters",
+              "num_residuals"):
+        g[4][k] = o[4][k]
+    assert_solve_parity(tuple(g), o)
+    r0, r1 = res[4]["rows_of_the_product"]
+    assert r0 == 0 and 0 < r1 < net.n_sta  # rank 0 reports: the first rows, not all of them
+    # one sum per PCG iteration queued; a batch of iterations (at most 32) is queued before the stopping flag is looked at
+    n_pcg = res[4]["total_linear_iterations"]
+    n_lm = len(res[5])
+    assert res[4]["reductions_in_solve"] >= n_pcg  # at least one per PCG iteration
+    assert res[4]["reductions_in_solve"] <= 4 * n_lm + 4 + n_pcg + 32 * n_lm
+
+
+@pytest.mark.parametrize("pcg_rows", ["auto", "always"])
+def test_two_ranks_of_the_command_line_program(tmp_path, pcg_rows):
     """ba_main --ranks 2: two processes on the one GPU, summing through a mapped file (RCCL wants a GPU per rank), against
     the one-rank run of the same files."""
     import subprocess
@@ -124,7 +161,7 @@ def test_two_ranks_of_the_command_line_program(tmp_path):
     two = tmp_path / "two"
     two.mkdir()
     idf = str(tmp_path / "rccl.id")
-    procs = [subprocess.Popen([build.MAIN_BIN] + common + ["--out", str(two), "--ranks", "2", "--rank", str(r), "--id-file", idf, "--comm", "shm"],
+    procs = [subprocess.Popen([build.MAIN_BIN] + common + ["--out", str(two), "--ranks", "2", "--rank", str(r), "--id-file", idf, "--comm", "shm", "--pcg-rows", pcg_rows],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
     outs = [p.communicate(timeout=240) for p in procs]
     for p, (so, se) in zip(procs, outs):
