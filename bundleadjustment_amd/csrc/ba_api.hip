@@ -79,6 +79,10 @@ int fail_msg(int code, const char *fmt, ...) {
 }
 }  // namespace ba
 
+// Most bytes of 6x6 blocks the explicit reduced system may take (beyond: the matrix-free operator): the product kernel of
+// the PCG addresses the values with 32-bit byte offsets.  14 million blocks -- 600 000 stations with 22 neighbours each.
+static const double BSR_MAX_BYTES = 4.0e9;
+
 struct ba_problem {
   int N = 0, S = 0, P = 0, C = 0;
   int ncam = 0, ncmax = 0, nr = 0, n_chunks = 0;
@@ -528,7 +532,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
       bsr_rowptr.assign(S + 1, 0);
       for (int i = 0; i < S; ++i) bsr_rowptr[i + 1] = bsr_rowptr[i] + nnb[i];
       const int64_t nb_total = bsr_rowptr[S];
-      if ((double)nb_total * 288.0 <= 48e9 && tot < 2000000000LL) {
+      if ((double)nb_total * 288.0 <= BSR_MAX_BYTES && tot < 2000000000LL) {
         bsr_col.assign(nb_total, 0);
         std::vector<int> fillb(S);
         for (int i = 0; i < S; ++i) { bsr_col[bsr_rowptr[i]] = i; fillb[i] = bsr_rowptr[i] + 1; }
@@ -2335,6 +2339,10 @@ static int sync_shards(ba_problem *p) {
   for (int u = 0; u < p->n_ublk; ++u) {
     const int lo = p->ub_lo_h[u], hi = p->ub_hi_h[u];
     dst[u] = (lo == hi) ? make_int2(rowptr[lo], -1) : make_int2(find(lo, hi), find(hi, lo));
+  }
+  if ((double)rowptr[S] * 288.0 > BSR_MAX_BYTES) {  // the same on every rank: the pattern is the union
+    p->explicit_ok = false;
+    return 0;
   }
   p->bsr_rowptr_h = rowptr;
   p->bsr_col_h = col;

@@ -340,54 +340,100 @@ __global__ void k_border_general_corner(int ncam, const double *__restrict__ cor
 // q = S p for station rows (one wave per row) with per-workgroup partials of p.q and of the
 // camera rows Ssc^T p.
 #define SPMV_WAVES 8
-__global__ void __launch_bounds__(64 * SPMV_WAVES)
+#define SPMV_NT 8  // triples of blocks in flight per wave: a row of up to 24 blocks is one pass
+// The kernel is a chain of dependent loads per row (row pointer -> columns -> blocks and entries of p), and a wave has
+// two or three rows: the row pointers of the next two rows and the columns of the next row are requested together with
+// the blocks of the current one, so a row costs one round trip after the first (two for the wave's start), and the
+// camera columns of the row travel with its blocks.  The grid is sized so that every wave gets the same number of rows
+// (cg2_blocks_spmv).
+__global__ void __launch_bounds__(64 * SPMV_WAVES, 4)
 k_bsr_spmv(BsrCgArgs a, int parity) {
   __shared__ double lds_pq[SPMV_WAVES];
   __shared__ double lds_qc[SPMV_WAVES][CG2_MAX_CAM + 1];
   pcg_mark(a.trace, 0, 0, blockIdx.x);
-  if (a.scal[8 + parity] != 0.0) return;
-  pcg_mark(a.trace, 0, 1, blockIdx.x);
+  const double done = a.scal[8 + parity];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double pq = 0.0;
-  double tcam0 = 0.0, tcam1 = 0.0;  // camera-row partials of this lane: columns lane and lane + 64
-  const double *pcam = a.p + 6 * (int64_t)a.S;
   const int row_begin = a.rows_sharded ? a.row0 : 0, row_end = a.rows_sharded ? a.row_end : a.S;
-  for (int i = row_begin + blockIdx.x * SPMV_WAVES + w; i < row_end; i += gridDim.x * SPMV_WAVES) {
+  const int stride = gridDim.x * SPMV_WAVES;
+  int i = row_begin + blockIdx.x * SPMV_WAVES + w;
+  int rb = 0, re = 0, rbn = 0, ren = 0;
+  if (i < row_end) {
+    rb = a.rowptr[i];
+    re = a.rowptr[i + 1];
+  }
+  if (i + stride < row_end) {
+    rbn = a.rowptr[i + stride];
+    ren = a.rowptr[i + stride + 1];
+  }
+  int mycol = lane < re - rb ? a.col[rb + lane] : 0;  // the row's first 64 columns
+  // camera columns 0..7 of a row: lane (r, k) = (lane >> 3, lane & 7) holds Ssc[6 i + r][k]
+  const int cr = lane >> 3, ck = lane & 7;
+  const bool cam_lane = cr < 6 && ck < a.ncam;
+  const double *pcam = a.p + 6 * (int64_t)a.S;
+  const double pk = cam_lane ? pcam[ck] : 0.0;
+  if (done != 0.0) return;  // waits for the flag alone
+  pcg_mark(a.trace, 0, 1, blockIdx.x);
+  double pq = 0.0;
+  double tacc = 0.0;                // camera-row partial of column ck from block row cr (columns 0..7)
+  double tcam0 = 0.0, tcam1 = 0.0;  // camera-row partials of columns lane (from 8 on) and lane + 64
+  // Lanes 0..53 read a row's blocks (288 B each, contiguous) as one stream, 16 B per lane: lane l holds piece l % 18
+  // of block l / 18 of each triple, i.e. always the same block row (l % 18) / 3 and column pair 2 * (l % 3).
+  const int tri = lane / 18, piece = lane - 18 * tri;  // tri == 3 for the idle lanes 54..63
+  const int cpair = 2 * (piece % 3);
+  for (; i < row_end; i += stride) {
+    const int inn = i + 2 * stride;
+    const int mycoln = lane < ren - rbn ? a.col[rbn + lane] : 0;
+    int rbnn = 0, renn = 0;
+    if (inn < row_end) {
+      rbnn = a.rowptr[inn];
+      renn = a.rowptr[inn + 1];
+    }
+    const double cx = cam_lane ? a.Ssc[(6 * (int64_t)i + cr) * a.ncam + ck] : 0.0;
+    const double pr = cr < 6 ? a.p[6 * (int64_t)i + cr] : 0.0;
     double s = 0.0;
-    // The row's blocks are contiguous in memory (288 B each).  Lanes 0..53 read them as one stream,
-    // 16 B per lane: lane l holds piece l % 18 of block l / 18 of each triple, i.e. always the same
-    // block row (l % 18) / 3 and column pair 2 * (l % 3).  Four triples (12 blocks) per pass; their
-    // column indices come from one coalesced load and shuffles, so all loads of a pass are independent.
-    const int rb = a.rowptr[i], re = a.rowptr[i + 1];
-    const int tri = lane / 18, piece = lane - 18 * tri;  // tri == 3 for the idle lanes 54..63
-    const int cpair = 2 * (piece % 3);
-    for (int base = rb; base < re; base += 12) {
-      const int nb = min(12, re - base);
-      const int mycol = lane < nb ? a.col[base + lane] : 0;
-      double2 bv[4], pv[4];
+    for (int base = rb; base < re; base += 3 * SPMV_NT) {
+      const int nb = min(3 * SPMV_NT, re - base);
+      int off = base - rb, cols = mycol;
+      if (off + 3 * SPMV_NT > 64) {  // beyond the columns held in registers (uniform over the wave)
+        cols = lane < nb ? a.col[base + lane] : 0;
+        off = 0;
+      }
+      double2 bv[SPMV_NT], pv[SPMV_NT];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SPMV_NT; ++u) {
         const int bi = 3 * u + tri;
-        const int cb = __shfl(mycol, bi < 12 ? bi : 0, 64);
+        const int cb = __shfl(cols, off + (bi < 3 * SPMV_NT ? bi : 0), 64);
         const bool on = tri < 3 && bi < nb;
-        bv[u] = on ? *reinterpret_cast<const double2 *>(a.val + 36 * (int64_t)(base + bi) + 2 * piece) : make_double2(0.0, 0.0);
-        pv[u] = on ? *reinterpret_cast<const double2 *>(a.p + 6 * (int64_t)cb + cpair) : make_double2(0.0, 0.0);
+        // 32-bit byte offsets from the array bases (the block values stay below 4 GB: checked where the blocks are
+        // allocated): one address register per load instead of two
+        const unsigned vo = 288u * (unsigned)(base + bi) + 16u * (unsigned)piece, po = 48u * (unsigned)cb + 8u * (unsigned)cpair;
+        bv[u] = on ? *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.val) + vo) : make_double2(0.0, 0.0);
+        pv[u] = on ? *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.p) + po) : make_double2(0.0, 0.0);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) s += bv[u].x * pv[u].x + bv[u].y * pv[u].y;
+      for (int u = 0; u < SPMV_NT; ++u) s += bv[u].x * pv[u].x + bv[u].y * pv[u].y;
     }
     // block row r: pieces 3r..3r+2 of the three triples -> lanes 3r + {0,1,2} + {0,18,36}
     s += __shfl_down(s, 1, 64) + __shfl_down(s, 2, 64);   // valid where piece % 3 == 0
     s += __shfl_down(s, 18, 64) + __shfl_down(s, 36, 64);  // valid for lanes 0,3,..,15
     s = __shfl(s, 3 * (lane < 6 ? lane : 0), 64);          // lanes 0..5: rows 0..5
+    // camera columns 0..7: row sums over the 8 lanes of a block row, column sums kept per lane until the end
+    double cd = cx * pk;
+    cd += __shfl_xor(cd, 1, 64);
+    cd += __shfl_xor(cd, 2, 64);
+    cd += __shfl_xor(cd, 4, 64);
+    cd = __shfl(cd, 8 * (lane < 6 ? lane : 0), 64);
+    const double pown = __shfl(pr, 8 * (lane < 6 ? lane : 0), 64);
+    tacc += cx * pr;
     if (lane < 6) {
+      s += cd;
       const double *row = a.Ssc + (6 * (int64_t)i + lane) * a.ncam;
-      for (int k = 0; k < a.ncam; ++k) s += row[k] * pcam[k];
+      for (int k = 8; k < a.ncam; ++k) s += row[k] * pcam[k];
       a.q[6 * (int64_t)i + lane] = s;
-      pq += s * a.p[6 * (int64_t)i + lane];
+      pq += s * pown;
     }
-    // camera rows: t_k += sum_r Ssc[i][r][k] p_i[r]
-    if (lane < a.ncam) {
+    // camera columns from 8 on: t_k += sum_r Ssc[i][r][k] p_i[r]
+    if (lane >= 8 && lane < a.ncam) {
       const double *pi = a.p + 6 * (int64_t)i;
 #pragma unroll
       for (int rr = 0; rr < 6; ++rr) tcam0 += a.Ssc[(6 * (int64_t)i + rr) * a.ncam + lane] * pi[rr];
@@ -397,8 +443,17 @@ k_bsr_spmv(BsrCgArgs a, int parity) {
 #pragma unroll
       for (int rr = 0; rr < 6; ++rr) tcam1 += a.Ssc[(6 * (int64_t)i + rr) * a.ncam + lane + 64] * pi[rr];
     }
+    rb = rbn;
+    re = ren;
+    rbn = rbnn;
+    ren = renn;
+    mycol = mycoln;
   }
   pcg_mark(a.trace, 0, 2, blockIdx.x);
+  tacc += __shfl_xor(tacc, 8, 64);
+  tacc += __shfl_xor(tacc, 16, 64);
+  tacc += __shfl_xor(tacc, 32, 64);  // lanes 0..7: columns 0..7 (block rows 6 and 7 do not exist: zeros)
+  if (lane < 8) tcam0 = tacc;
   pq = wave_sum(pq);
   if (lane == 0) lds_pq[w] = pq;
   if (lane < a.ncam) lds_qc[w][lane] = tcam0;
@@ -696,7 +751,10 @@ int cg2_blocks_spmv(int S) {
       cap = 512;
     (void)hipGetLastError();
   }
-  return nb > cap ? cap : nb;
+  if (nb <= cap) return nb;
+  // the same number of rows for every wave: the kernel ends when the waves with the most rows do
+  const int rows_per_wave = nblk(S, cap * SPMV_WAVES);
+  return nblk(S, rows_per_wave * SPMV_WAVES);
 }
 int cg2_blocks_vec(int S) { return nblk(S, 256) > 0 ? nblk(S, 256) : 1; }
 void launch_cg2_init(hipStream_t s, const BsrCgArgs &a, double rtol) {
