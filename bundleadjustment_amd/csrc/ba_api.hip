@@ -2171,17 +2171,21 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
       if (tr[k] && tr[k] < t0) t0 = tr[k];
     static const char *names[PCG_TRACE_KERNELS] = {"spmv", "update1_restrict", "restrict", "prolong", "update2"};
     fprintf(stderr, "PCG iteration trace (us since the first stamp; min / median / max over workgroups)\n");
+    const int nbv = cg2_blocks_vec(p->S);  // the second kernel: vector workgroups first, then the restricting ones
     for (int kk = 0; kk < PCG_TRACE_KERNELS; ++kk)
-      for (int m = 0; m < PCG_TRACE_SLOTS; ++m) {
-        std::vector<double> v;
-        for (int w = 0; w < PCG_TRACE_MAXWG; ++w) {
-          const unsigned long long x = tr[((size_t)kk * PCG_TRACE_MAXWG + w) * PCG_TRACE_SLOTS + m];
-          if (x) v.push_back(0.01 * (double)(x - t0));
+      for (int part = 0; part < (kk == 1 ? 2 : 1); ++part)
+        for (int m = 0; m < PCG_TRACE_SLOTS; ++m) {
+          std::vector<double> v;
+          const int w0 = (kk == 1 && part == 1) ? nbv : 0, w1 = (kk == 1 && part == 0) ? std::min(nbv, (int)PCG_TRACE_MAXWG) : (int)PCG_TRACE_MAXWG;
+          for (int w = w0; w < w1; ++w) {
+            const unsigned long long x = tr[((size_t)kk * PCG_TRACE_MAXWG + w) * PCG_TRACE_SLOTS + m];
+            if (x) v.push_back(0.01 * (double)(x - t0));
+          }
+          if (v.empty()) continue;
+          std::sort(v.begin(), v.end());
+          fprintf(stderr, "  %-18s mark %d  n=%4zu  %7.2f %7.2f %7.2f\n", kk == 1 ? (part ? "update1 (restrict)" : "update1 (vectors)") : names[kk], m,
+                  v.size(), v.front(), v[v.size() / 2], v.back());
         }
-        if (v.empty()) continue;
-        std::sort(v.begin(), v.end());
-        fprintf(stderr, "  %-18s mark %d  n=%4zu  %7.2f %7.2f %7.2f\n", names[kk], m, v.size(), v.front(), v[v.size() / 2], v.back());
-      }
     *seconds_per_launch = 0.0;
     return p->check_kernels();
   }
