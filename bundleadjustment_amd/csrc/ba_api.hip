@@ -1123,6 +1123,8 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
     if (p->cg_graph_tail) hipGraphExecDestroy(p->cg_graph_tail);
     p->cg_graph = p->cg_graph_tail = nullptr;
   }
+  if (const char *e = std::getenv("BA_PCG_GRAPH"))  // 0: queue the iterations launch by launch (for comparisons)
+    if (std::atoi(e) == 0) p->cg_graph_failed = true;
   if (!p->cg_graph && !p->cg_graph_failed && !shard_rows) {
     p->cg_graph_precond = precond;
     // the launch sequence of a batch never changes for this problem: capture it into a graph once
@@ -1162,7 +1164,7 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
   // What the previous solve says will be needed is queued without a look at the flag in between (the device is never
   // left waiting for the host's answer and the next launch); only the last few iterations go one short batch at a time.
   int queued = 0;
-  if (expect > 0 && ((p->cg_graph && p->cg_graph_tail) || shard_rows)) {
+  if (expect > 0 && ((p->cg_graph && p->cg_graph_tail) || shard_rows || p->cg_graph_failed)) {
     const int sure = std::min(expect - tail / 2, opt->pcg_max_iters);
     while (queued + batch <= sure) {
       BA_TRY(launch_batch(queued, batch));
@@ -2087,6 +2089,14 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
   if ((which == 5 || which == 6) && p->ncam > cg2_max_cam()) return fail(BA_ERR_UNSUPPORTED, "ba_time_kernel: too many free camera parameters for the block-sparse PCG");
   // the PCG iteration is timed with the preconditioner the last solve used (multilevel once it has been built)
   const bool with_amg = p->amg && amg_levels(p->amg) >= 2;
+  if ((which == 5 || which == 9) && with_amg && p->have_G && p->ncam > 0 && p->ncam <= defl_max_cam()) {
+    // the camera coarse space of the last solve: its matrix belongs to that solve's last linearisation, which is all the
+    // timing needs
+    ba.G = p->d_G;
+    ba.GT = p->d_GT;
+    ba.Lcc = p->d_E;
+    ba.part_gr = p->d_part_gr;
+  }
   if (which == 5 || which == 6) {
     if (with_amg) {
       amg_numeric(p->amg, s, p->d_bsr_val, p->d_Minv);
@@ -2110,9 +2120,11 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
       case 2: launch_station_pass(s, sa, SMODE_GATHER); break;
       case 3: launch_cost_obs(s, ca, cost_blocks(p->N)); break;
       case 4: launch_schur_blocks(s, p->n_ublk, p->d_ublk_cstart, p->d_ublk_dst, p->d_pairs, p->d_Y, p->d_bsr_val); break;
-      case 5:
-        if (with_amg) launch_amg_cg_iteration(s, ba, p->amg, 0);
-        else launch_cg2_iteration(s, ba, 0);
+      case 5:  // two iterations, as the parity of the scalar slots alternates
+        for (int par = 0; par < 2; ++par) {
+          if (with_amg) launch_amg_cg_iteration(s, ba, p->amg, par);
+          else launch_cg2_iteration(s, ba, par);
+        }
         break;
       case 6: launch_bsr_spmv(s, ba, 0); break;
       case 7: launch_linearize(s, la, 1); break;
@@ -2199,7 +2211,7 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
   HIP_OK(hipEventElapsedTime(&ms, e0, e1));
   hipEventDestroy(e0);
   hipEventDestroy(e1);
-  *seconds_per_launch = 1e-3 * ms / repeats;
+  *seconds_per_launch = 1e-3 * ms / repeats / (which == 5 ? 2 : 1);
   return p->check_kernels();
 }
 

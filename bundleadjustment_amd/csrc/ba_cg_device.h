@@ -29,27 +29,13 @@ __device__ __forceinline__ double station_precond(const double *__restrict__ Min
   return dot;
 }
 
-// per-workgroup partials of G^T r_s (thread i holds station i; 256 threads)
+// per-workgroup partials of G^T r_s from the per-station products gr (thread i holds station i; 256 threads)
 #define DEFL_NC 8
 // Most free camera parameters (summed over the cameras) the kernels of the explicit block-sparse PCG hold in LDS;
 // networks with more take the matrix-free PCG (ba_solve_resident) or the dense solver.
 #define CG2_MAX_CAM 79
-__device__ __forceinline__ void defl_partials(const BsrCgArgs &a, const double (&ri)[6], int i, int vblock) {
+__device__ __forceinline__ void defl_partials(const BsrCgArgs &a, const double (&gr)[DEFL_NC], int vblock) {
   __shared__ double lds_gr[4][DEFL_NC];
-  double gr[DEFL_NC];
-#pragma unroll
-  for (int k = 0; k < DEFL_NC; ++k) gr[k] = 0.0;
-  if (i < a.S) {
-    // GT is G by columns: the six entries of a station are contiguous, neighbouring threads adjoin
-    const int64_t ld = 6 * (int64_t)a.S;
-#pragma unroll
-    for (int k = 0; k < DEFL_NC; ++k)
-      if (k < a.ncam) {
-        const double2 *g = reinterpret_cast<const double2 *>(a.GT + k * ld + 6 * (int64_t)i);
-        const double2 g0 = g[0], g1 = g[1], g2 = g[2];
-        gr[k] = g0.x * ri[0] + g0.y * ri[1] + g1.x * ri[2] + g1.y * ri[3] + g2.x * ri[4] + g2.y * ri[5];
-      }
-  }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < DEFL_NC; ++k) {
@@ -60,6 +46,22 @@ __device__ __forceinline__ void defl_partials(const BsrCgArgs &a, const double (
   if (threadIdx.x < a.ncam)
     a.part_gr[(int64_t)vblock * a.ncam + threadIdx.x] =
         (lds_gr[0][threadIdx.x] + lds_gr[1][threadIdx.x]) + (lds_gr[2][threadIdx.x] + lds_gr[3][threadIdx.x]);
+}
+
+// gr[k] = column k of G times the six entries ri of station i (zeros beyond the stations and the columns)
+__device__ __forceinline__ void defl_products(const BsrCgArgs &a, const double (&ri)[6], int i, double (&gr)[DEFL_NC]) {
+#pragma unroll
+  for (int k = 0; k < DEFL_NC; ++k) gr[k] = 0.0;
+  if (i < a.S) {
+    const int64_t ld = 6 * (int64_t)a.S;
+#pragma unroll
+    for (int k = 0; k < DEFL_NC; ++k)
+      if (k < a.ncam) {
+        const double2 *g = reinterpret_cast<const double2 *>(a.GT + k * ld + 6 * (int64_t)i);
+        const double2 g0 = g[0], g1 = g[1], g2 = g[2];
+        gr[k] = g0.x * ri[0] + g0.y * ri[1] + g1.x * ri[2] + g1.y * ri[3] + g2.x * ri[4] + g2.y * ri[5];
+      }
+  }
 }
 
 // ---- second kernel of a PCG iteration ---------------------------------------------------------------------------
@@ -80,7 +82,7 @@ struct Cg2Shared {
 
 // Eight sums at a time (q0 .. q0 + 7 of the 1 + ncam): thread t takes sum (t & 7) and every 32nd partial from
 // (t >> 3) on; at most CG2_MAX_SPMV_BLOCKS partials (cg2_blocks_spmv).
-#define CG2_FOLD_LOADS 24
+#define CG2_FOLD_LOADS 16
 #define CG2_MAX_SPMV_BLOCKS (32 * CG2_FOLD_LOADS)
 struct FoldLoads {
   double v[CG2_FOLD_LOADS];
@@ -114,7 +116,7 @@ __device__ __forceinline__ double cg2_alpha(const BsrCgArgs &a, double rz, int n
   for (int q0 = 0; q0 < 1 + a.ncam; q0 += 8) {
     if (q0 > 0) fold_issue(a, nblk_spmv, q0, f);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f.v[j] += f.v[j + 8] + f.v[j + 16];  // fixed order
+    for (int j = 0; j < 8; ++j) f.v[j] += f.v[j + 8];  // fixed order
 #pragma unroll
     for (int w2 = 4; w2 >= 1; w2 >>= 1)
 #pragma unroll
@@ -160,6 +162,7 @@ struct VecLoads {
   double2 x[3], p[3];
   double r[6], q[6], u[6], w[6];
   double rc;  // camera entry threadIdx.x of r_in (last vector workgroup)
+  double gr[DEFL_NC], gq[DEFL_NC];  // camera coarse space: column k of G times r_in and times q (station i)
 };
 __device__ __forceinline__ void vec_issue(const BsrCgArgs &a, const double *rin, int vblock, int n_vblocks, VecLoads &v) {
   const int i = vblock * blockDim.x + threadIdx.x;
@@ -190,6 +193,30 @@ __device__ __forceinline__ void vec_issue(const BsrCgArgs &a, const double *rin,
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+#pragma unroll
+  for (int k = 0; k < DEFL_NC; ++k) v.gr[k] = v.gq[k] = 0.0;
+  if (a.G && i < a.S) {
+    // G^T r_out = G^T r_in - alpha G^T q: both products before alpha is known, like u and w.  GT is G by columns:
+    // the six entries of a station are contiguous, neighbouring threads adjoin.
+    const int64_t ld = 6 * (int64_t)a.S;
+#pragma unroll
+    for (int h = 0; h < DEFL_NC; h += 4) {  // four columns in flight at a time
+      double2 g[4][3];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (h + k < a.ncam) {
+          const double2 *gp = reinterpret_cast<const double2 *>(a.GT + (h + k) * ld + 6 * (int64_t)i);
+          g[k][0] = gp[0]; g[k][1] = gp[1]; g[k][2] = gp[2];
+        }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (h + k < a.ncam) {
+          v.gr[h + k] = g[k][0].x * v.r[0] + g[k][0].y * v.r[1] + g[k][1].x * v.r[2] + g[k][1].y * v.r[3] + g[k][2].x * v.r[4] + g[k][2].y * v.r[5];
+          v.gq[h + k] = g[k][0].x * v.q[0] + g[k][0].y * v.q[1] + g[k][1].x * v.q[2] + g[k][1].y * v.q[3] + g[k][2].x * v.q[4] + g[k][2].y * v.q[5];
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
   v.rc = (vblock == n_vblocks - 1 && threadIdx.x < a.ncam) ? rin[6 * (int64_t)a.S + threadIdx.x] : 0.0;
 }
 __device__ __forceinline__ void vec_finish(const BsrCgArgs &a, double alpha, double *rout, int vblock, int n_vblocks, const VecLoads &v,
@@ -215,7 +242,12 @@ __device__ __forceinline__ void vec_finish(const BsrCgArgs &a, double alpha, dou
       zo[k] = make_double2(z[2 * k], z[2 * k + 1]);
     }
   }
-  if (a.G) defl_partials(a, r, i, vblock);
+  if (a.G) {
+    double gr[DEFL_NC];
+#pragma unroll
+    for (int k = 0; k < DEFL_NC; ++k) gr[k] = v.gr[k] - alpha * v.gq[k];
+    defl_partials(a, gr, vblock);
+  }
   if (vblock == n_vblocks - 1) {
     // the last workgroup is the least loaded one: it also carries the camera entries (ncam <= CG2_MAX_CAM).
     // z_c = Scc^-1 r_c with the explicit inverse, one thread per row; with the camera coarse space only

@@ -495,7 +495,9 @@ k_cg2_init(BsrCgArgs a) {
     if (i < a.S)
 #pragma unroll
       for (int k = 0; k < 6; ++k) ri[k] = a.b[6 * (int64_t)i + k];
-    defl_partials(a, ri, i, blockIdx.x);
+    double gr[DEFL_NC];
+    defl_products(a, ri, i, gr);
+    defl_partials(a, gr, blockIdx.x);
   }
   if (blockIdx.x == 0 && a.ncam > 0) {
     // camera entries: x = 0, r = b and (without the coarse space) z = Scc^-1 r with the explicit inverse,
