@@ -329,9 +329,11 @@ k_amg_restrict(AmgTransfer t, const double *__restrict__ v, double *__restrict__
 }
 
 // Second kernel of a multilevel PCG iteration: the vector update and the first restriction in one
-// launch.  Workgroups [0, nbv) update x, r, z (thread per station); the others restrict the NEW residual
-// r_in - alpha q: P^T r_in and P^T q are summed before alpha is known, so nothing but arithmetic waits for the fold.
-// The residual is double buffered by iteration parity because the two groups run concurrently.
+// launch.  Workgroups [0, nbv) update x, r, z -- 8 lanes per station, lane r < 6 holding entry r, so that every load of
+// the role is independent and issued at once (a thread per station needs 800 bytes in four dependent batches, on forty
+// CUs) --; the others restrict the NEW residual r_in - alpha q: P^T r_in and P^T q are summed before alpha is known, so
+// nothing but arithmetic waits for the fold.  The residual is double buffered by iteration parity because the two
+// groups run concurrently.
 __global__ void __launch_bounds__(256, 2)
 k_amg_update1_restrict(BsrCgArgs a, AmgTransfer t, int parity, int nblk_spmv, int nbv, double *__restrict__ part) {
   __shared__ Cg2Shared sh;
@@ -342,13 +344,86 @@ k_amg_update1_restrict(BsrCgArgs a, AmgTransfer t, int parity, int nblk_spmv, in
   FoldLoads f;
   fold_issue(a, nblk_spmv, 0, f);
   if ((int)blockIdx.x < nbv) {
+    // 64 stations per workgroup, two per group of 8 lanes (so that the vector and the restricting workgroups are all
+    // resident at once: two per CU at this kernel's register count)
+    const int r = threadIdx.x & 7;
+    const int64_t o = 6 * (int64_t)a.S;
+    bool mine[2];
+    int64_t e[2];
+    double2 mv[2][3], rv[2][3], qv[2][3];
+    double r_own[2], q_own[2], x_own[2], p_own[2], g[2][DEFL_NC];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i = blockIdx.x * 64 + 32 * h + (threadIdx.x >> 3);
+      mine[h] = i < a.S && r < 6;
+      const int64_t e0 = 6 * (int64_t)(i < a.S ? i : 0);
+      e[h] = e0 + (r < 6 ? r : 0);
+      const double2 *M = reinterpret_cast<const double2 *>(a.Minv + 6 * e[h]);  // row r of the station's inverse block
+      const double2 *R = reinterpret_cast<const double2 *>(rin + e0), *Q = reinterpret_cast<const double2 *>(a.q + e0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        mv[h][k] = M[k];
+        rv[h][k] = R[k];
+        qv[h][k] = Q[k];
+      }
+      r_own[h] = rin[e[h]];
+      q_own[h] = a.q[e[h]];
+      x_own[h] = a.x[e[h]];
+      p_own[h] = a.p[e[h]];
+#pragma unroll
+      for (int k = 0; k < DEFL_NC; ++k) g[h][k] = (a.G && mine[h] && k < a.ncam) ? a.GT[k * o + e[h]] : 0.0;  // G by columns
+    }
+    const bool last = (int)blockIdx.x == nbv - 1;
+    const double rc = (last && (int)threadIdx.x < a.ncam) ? rin[o + threadIdx.x] : 0.0;
     if (done != 0.0) return;  // waits for the flag alone: the loads above stay in flight
-    VecLoads v;
-    vec_issue(a, rin, blockIdx.x, nbv, v);
     pcg_mark(a.trace, 1, 1, blockIdx.x);
+    double u[2], w[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      u[h] = mv[h][0].x * rv[h][0].x + mv[h][0].y * rv[h][0].y + mv[h][1].x * rv[h][1].x + mv[h][1].y * rv[h][1].y + mv[h][2].x * rv[h][2].x + mv[h][2].y * rv[h][2].y;
+      w[h] = mv[h][0].x * qv[h][0].x + mv[h][0].y * qv[h][0].y + mv[h][1].x * qv[h][1].x + mv[h][1].y * qv[h][1].y + mv[h][2].x * qv[h][2].x + mv[h][2].y * qv[h][2].y;
+    }
     const double alpha = cg2_alpha(a, rz, nblk_spmv, f, sh);
     pcg_mark(a.trace, 1, 2, blockIdx.x);
-    vec_finish(a, alpha, rout, blockIdx.x, nbv, v, sh);
+    double dot = 0.0;
+    double gr[DEFL_NC];
+#pragma unroll
+    for (int k = 0; k < DEFL_NC; ++k) gr[k] = 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const double rn = r_own[h] - alpha * q_own[h], z = u[h] - alpha * w[h];
+      if (mine[h]) {
+        a.x[e[h]] = x_own[h] + alpha * p_own[h];
+        rout[e[h]] = rn;
+        a.z[e[h]] = z;
+        dot += z * rn;
+      }
+#pragma unroll
+      for (int k = 0; k < DEFL_NC; ++k) gr[k] += g[h][k] * rn;  // g is zero in the lanes that hold nothing
+    }
+    if (a.G) defl_partials(a, gr, blockIdx.x);
+    if (last) {
+      // the camera entries (ncam <= CG2_MAX_CAM): z_c = Scc^-1 r_c with the explicit inverse, one thread per row; with
+      // the camera coarse space only x and r here, the camera part of z follows in the last kernel
+      if ((int)threadIdx.x < a.ncam) {
+        a.x[o + threadIdx.x] += alpha * sh.pcs[threadIdx.x];
+        const double rk = rc - alpha * sh.red[1 + threadIdx.x];
+        rout[o + threadIdx.x] = rk;
+        sh.rcs[threadIdx.x] = rk;
+      }
+      __syncthreads();
+      if (!a.G && (int)threadIdx.x < a.ncam) {
+        double zc = 0.0;
+        for (int m = 0; m < a.ncam; ++m) zc += a.Lcc[threadIdx.x * a.ncam + m] * sh.rcs[m];
+        a.z[o + threadIdx.x] = zc;
+        dot += sh.rcs[threadIdx.x] * zc;
+      }
+      if (threadIdx.x == 0) a.scal[4] = sh.pq;
+    }
+    pcg_mark(a.trace, 1, 3, blockIdx.x);
+    const double tot = block_sum(dot, sh.lds);
+    if (threadIdx.x == 0) a.part_rz[blockIdx.x] = tot;
+    pcg_mark(a.trace, 1, 4, blockIdx.x);
     return;
   }
   const int cb = blockIdx.x - nbv;
@@ -917,7 +992,9 @@ static AmgApplyArgs apply_args(const Amg *a) {
 // preconditioner part of one PCG iteration: after the vector kernel has left r, z = D0^-1 r and
 // the partials of r.z, finish z, the scalars and p.  mode 0 right after the start-up kernel.
 // first_done: the restriction into level 1 has already run (fused into the vector kernel)
-static void amg_finish_iteration(hipStream_t s, const BsrCgArgs &cg, const Amg *a, int parity, int mode, double rtol, int first_done) {
+// n_part_rz: how many partials of r.z (and of G^T r) the vector kernel before this has left
+static void amg_finish_iteration(hipStream_t s, const BsrCgArgs &cg, const Amg *a, int parity, int mode, double rtol, int first_done,
+                                 int n_part_rz) {
   const AmgApplyArgs aa = apply_args(a);
   int off = 0;
   for (int l = 0; l < aa.n_transfers; ++l) {
@@ -933,21 +1010,21 @@ static void amg_finish_iteration(hipStream_t s, const BsrCgArgs &cg, const Amg *
     hipLaunchKernelGGL(k_amg_prolong, dim3(nblk(aa.t[l].nb, 32)), dim3(256), 0, s, aa.t[l], aa.t[l - 1].y,
                        AMG_DEEP_WEIGHT, cg.trace);
   hipLaunchKernelGGL(k_amg_update2, dim3(nblk(cg.S, 32) > 0 ? nblk(cg.S, 32) : 1), dim3(256), 0, s, cg, aa.t[0],
-                     aa.n_transfers > 0 ? 1 : 0, aa.part, aa.n_part, cg2_blocks_vec(cg.S), parity, mode, rtol,
+                     aa.n_transfers > 0 ? 1 : 0, aa.part, aa.n_part, n_part_rz, parity, mode, rtol,
                      AMG_COARSE_WEIGHT, AMG_DEEP_WEIGHT,
                      aa.n_transfers > 0 ? nblk(aa.t[0].nc, 4) : 0);
 }
 
 void launch_amg_cg_init(hipStream_t s, const BsrCgArgs &cg, const Amg *a, double rtol) {
   launch_cg2_start(s, cg);
-  amg_finish_iteration(s, cg, a, 0, 0, rtol, 0);
+  amg_finish_iteration(s, cg, a, 0, 0, rtol, 0, cg2_blocks_vec(cg.S));
 }
 
 void launch_amg_cg_iteration(hipStream_t s, const BsrCgArgs &cg, const Amg *a, int parity) {
   const AmgApplyArgs aa = apply_args(a);
   if (aa.n_transfers == 0 || !cg.r2) {
     launch_cg2_spmv_update1(s, cg, parity);
-    amg_finish_iteration(s, cg, a, parity, 1, 0.0, 0);
+    amg_finish_iteration(s, cg, a, parity, 1, 0.0, 0, cg2_blocks_vec(cg.S));
     return;
   }
   launch_bsr_spmv(s, cg, parity);
@@ -958,9 +1035,9 @@ bool amg_cg_iteration_splits(const BsrCgArgs &cg, const Amg *a) { return apply_a
 
 void launch_amg_cg_iteration_after_product(hipStream_t s, const BsrCgArgs &cg, const Amg *a, int parity) {
   const AmgApplyArgs aa = apply_args(a);
-  const int nbv = cg2_blocks_vec(cg.S), nbr = nblk(aa.t[0].nc, 4);
+  const int nbv = cg2_blocks_vec8(cg.S), nbr = nblk(aa.t[0].nc, 4);
   hipLaunchKernelGGL(k_amg_update1_restrict, dim3(nbv + nbr), dim3(256), 0, s, cg, aa.t[0], parity, cg2_blocks_spmv(cg.S), nbv, aa.part);
-  amg_finish_iteration(s, cg, a, parity, 1, 0.0, 1);
+  amg_finish_iteration(s, cg, a, parity, 1, 0.0, 1, nbv);
 }
 
 }  // namespace ba

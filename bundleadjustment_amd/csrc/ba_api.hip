@@ -633,7 +633,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
     BA_TRY(p->upload(&p->d_ublk_dst, ublk_dst));
     if (!on_device) BA_TRY(p->upload(&p->d_pairs, pairs));
     BA_TRY(p->dalloc(&p->d_Y, (size_t)BA_Y_STRIDE * N));
-    const size_t npart = (size_t)std::max(std::max(cg2_blocks_spmv(S), cg2_blocks_vec(S)), 1024) + 1;
+    const size_t npart = (size_t)std::max(std::max(cg2_blocks_spmv(S), cg2_blocks_vec8(S)), 1024) + 1;
     BA_TRY(p->dalloc(&p->d_part_pq, npart));
     BA_TRY(p->dalloc(&p->d_part_qc, npart * std::max(p->ncam, 1)));
     BA_TRY(p->dalloc(&p->d_part_rz, npart));
@@ -1043,7 +1043,7 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
       BA_TRY(p->dalloc(&p->d_defl_part, (size_t)defl_gram_blocks(p->S) * 64));
       BA_TRY(p->dalloc(&p->d_E, 64));
       BA_TRY(p->dalloc(&p->d_Lcc_defl, 64));
-      BA_TRY(p->dalloc(&p->d_part_gr, ((size_t)cg2_blocks_vec(p->S) + 1) * defl_max_cam()));
+      BA_TRY(p->dalloc(&p->d_part_gr, ((size_t)cg2_blocks_vec8(p->S) + 1) * defl_max_cam()));
       BA_TRY(p->dalloc(&p->d_defl_b, ns));
     }
     if (!p->have_G) {
@@ -2183,7 +2183,7 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
       if (tr[k] && tr[k] < t0) t0 = tr[k];
     static const char *names[PCG_TRACE_KERNELS] = {"spmv", "update1_restrict", "restrict", "prolong", "update2"};
     fprintf(stderr, "PCG iteration trace (us since the first stamp; min / median / max over workgroups)\n");
-    const int nbv = cg2_blocks_vec(p->S);  // the second kernel: vector workgroups first, then the restricting ones
+    const int nbv = cg2_blocks_vec8(p->S);  // the second kernel: vector workgroups first, then the restricting ones
     for (int kk = 0; kk < PCG_TRACE_KERNELS; ++kk)
       for (int part = 0; part < (kk == 1 ? 2 : 1); ++part)
         for (int m = 0; m < PCG_TRACE_SLOTS; ++m) {

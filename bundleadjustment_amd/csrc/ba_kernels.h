@@ -212,6 +212,7 @@ void launch_border_general(hipStream_t s, const GenBorderArgs &a);
 void launch_border_general_corner(hipStream_t s, int ncam, const double *corner, const double *camdiag, double *Scc);
 int cg2_blocks_spmv(int S);
 int cg2_blocks_vec(int S);
+int cg2_blocks_vec8(int S);  // vector workgroups of the multilevel iteration: 8 lanes per station, 64 stations each
 void launch_cg2_init(hipStream_t s, const BsrCgArgs &a, double rtol);
 void launch_cg2_iteration(hipStream_t s, const BsrCgArgs &a, int parity);
 void launch_bsr_spmv(hipStream_t s, const BsrCgArgs &a, int parity);

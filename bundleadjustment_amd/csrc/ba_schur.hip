@@ -759,6 +759,7 @@ int cg2_blocks_spmv(int S) {
   return nblk(S, rows_per_wave * SPMV_WAVES);
 }
 int cg2_blocks_vec(int S) { return nblk(S, 256) > 0 ? nblk(S, 256) : 1; }
+int cg2_blocks_vec8(int S) { return nblk(S, 64) > 0 ? nblk(S, 64) : 1; }
 void launch_cg2_init(hipStream_t s, const BsrCgArgs &a, double rtol) {
   const int nb = cg2_blocks_vec(a.S);
   hipLaunchKernelGGL(k_cg2_init, dim3(nb), dim3(256), 0, s, a);
