@@ -340,7 +340,7 @@ __global__ void k_border_general_corner(int ncam, const double *__restrict__ cor
 // q = S p for station rows (one wave per row) with per-workgroup partials of p.q and of the
 // camera rows Ssc^T p.
 #define SPMV_WAVES 8
-#define SPMV_NT 8  // triples of blocks in flight per wave: a row of up to 24 blocks is one pass
+#define SPMV_NT 7  // triples of blocks in flight per wave: a row of up to 21 blocks is one pass (24 would spill registers)
 // The kernel is a chain of dependent loads per row (row pointer -> columns -> blocks and entries of p), and a wave has
 // two or three rows: the row pointers of the next two rows and the columns of the next row are requested together with
 // the blocks of the current one, so a row costs one round trip after the first (two for the wave's start), and the
