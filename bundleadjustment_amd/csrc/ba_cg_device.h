@@ -66,7 +66,7 @@ __device__ __forceinline__ void defl_products(const BsrCgArgs &a, const double (
 
 // ---- second kernel of a PCG iteration ---------------------------------------------------------------------------
 // Every workgroup folds the per-workgroup partials of the SpMV (p.q over the station rows and the camera rows of
-// S p) in the same fixed order, so alpha = r.z / p.Sp is identical everywhere; the vector workgroups (one thread per
+// S p, corner included) in the same fixed order, so alpha = r.z / p.Sp is identical everywhere; the vector workgroups (one thread per
 // station) then do x += alpha p, r_out = r_in - alpha q, z = D^-1 r_out and leave partials of r.z.
 // The kernels are bounded by the latency of dependent loads, not by bytes, so the work is cut into an ISSUE half that
 // only loads (nothing in it depends on alpha) and a FINISH half that only computes and stores: a kernel issues all
@@ -87,7 +87,6 @@ struct Cg2Shared {
 struct FoldLoads {
   double v[CG2_FOLD_LOADS];
   double pc;        // camera entry threadIdx.x of p
-  double scc[8];    // row threadIdx.x of Scc when ncam <= 8
 };
 __device__ __forceinline__ void fold_issue(const BsrCgArgs &a, int nblk_spmv, int q0, FoldLoads &f) {
   const int qn = q0 + (threadIdx.x & 7);
@@ -102,10 +101,6 @@ __device__ __forceinline__ void fold_issue(const BsrCgArgs &a, int nblk_spmv, in
   if (q0 == 0) {
     const int t = threadIdx.x;
     f.pc = (t < a.ncam) ? a.p[6 * (int64_t)a.S + t] : 0.0;
-    if (a.ncam <= 8) {
-#pragma unroll
-      for (int m = 0; m < 8; ++m) f.scc[m] = (t < a.ncam && m < a.ncam) ? a.Scc[t * a.ncam + m] : 0.0;
-    }
   }
 }
 
@@ -132,21 +127,7 @@ __device__ __forceinline__ double cg2_alpha(const BsrCgArgs &a, double rz, int n
       sh.red[q0 + threadIdx.x] = (sh.fold4[0][threadIdx.x] + sh.fold4[1][threadIdx.x]) + (sh.fold4[2][threadIdx.x] + sh.fold4[3][threadIdx.x]);
   }
   __syncthreads();
-  // camera rows: add the corner, S_cc p_c
-  double qk = 0.0;
-  if (threadIdx.x < a.ncam) {
-    qk = sh.red[1 + threadIdx.x];
-    if (a.ncam <= 8) {
-#pragma unroll
-      for (int m = 0; m < 8; ++m)
-        if (m < a.ncam) qk += f.scc[m] * sh.pcs[m];
-    } else {
-      for (int m = 0; m < a.ncam; ++m) qk += a.Scc[threadIdx.x * a.ncam + m] * sh.pcs[m];
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < a.ncam) sh.red[1 + threadIdx.x] = qk;
-  __syncthreads();
+  // (the camera rows are complete: the product kernel's first workgroup has added the corner, S_cc p_c, to its partial)
   if (threadIdx.x == 0) {
     double pq = sh.red[0];
     for (int k = 0; k < a.ncam; ++k) pq += sh.red[1 + k] * sh.pcs[k];

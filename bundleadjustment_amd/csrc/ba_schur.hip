@@ -371,6 +371,11 @@ k_bsr_spmv(BsrCgArgs a, int parity) {
   const bool cam_lane = cr < 6 && ck < a.ncam;
   const double *pcam = a.p + 6 * (int64_t)a.S;
   const double pk = cam_lane ? pcam[ck] : 0.0;
+  // the corner of the camera rows, S_cc p_c: row threadIdx.x by the first workgroup (of the rank that holds the first
+  // rows, when the rows are shared out), added to its partial of the camera rows
+  double corner = 0.0;
+  if (blockIdx.x == 0 && (!a.rows_sharded || a.row0 == 0) && (int)threadIdx.x < a.ncam)
+    for (int m = 0; m < a.ncam; ++m) corner += a.Scc[threadIdx.x * a.ncam + m] * pcam[m];
   if (done != 0.0) return;  // waits for the flag alone
   pcg_mark(a.trace, 0, 1, blockIdx.x);
   double pq = 0.0;
@@ -469,7 +474,7 @@ k_bsr_spmv(BsrCgArgs a, int parity) {
     double t = 0.0;
 #pragma unroll
     for (int m = 0; m < SPMV_WAVES; ++m) t += lds_qc[m][k];
-    a.part_qc[(int64_t)blockIdx.x * a.ncam + k] = t;
+    a.part_qc[(int64_t)blockIdx.x * a.ncam + k] = t + corner;  // k == threadIdx.x: ncam is below the workgroup size
   }
   pcg_mark(a.trace, 0, 3, blockIdx.x);
 }
