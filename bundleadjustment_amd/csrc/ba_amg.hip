@@ -552,12 +552,31 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restr
   if (defl) {
     // G^T r_s: 16 lanes per sum, the partials dealt round-robin; then across the wave and the waves
     const int k = threadIdx.x & 15, j = threadIdx.x >> 4;
+    // eight loads at a time: a loop of single loads would wait for each in turn
     if (k < cg.ncam)
-      for (int m = j; m < n_part_rz; m += 16) g += cg.part_gr[(int64_t)m * cg.ncam + k];
+      for (int m = j; m < n_part_rz; m += 128) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (m + 16 * u < n_part_rz) ? cg.part_gr[(int64_t)(m + 16 * u) * cg.ncam + k] : 0.0;
+        g += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      }
   }
   double s = 0.0;
-  for (int k = threadIdx.x; k < n_part_rz; k += blockDim.x) s += cg.part_rz[k];
-  for (int k = threadIdx.x; k < n_part; k += blockDim.x) s += (k < np0 ? sigma : sigma * tau) * part[k];
+  for (int k = threadIdx.x; k < n_part_rz; k += 4 * blockDim.x) {
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = (k + u * (int)blockDim.x < n_part_rz) ? cg.part_rz[k + u * blockDim.x] : 0.0;
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+  }
+  for (int k = threadIdx.x; k < n_part; k += 4 * blockDim.x) {
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kk = k + u * (int)blockDim.x;
+      v[u] = (kk < n_part) ? (kk < np0 ? sigma : sigma * tau) * part[kk] : 0.0;
+    }
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+  }
   const double corr = has_coarse ? prolong_finish(t, pi, threadIdx.x & 63) : 0.0;
   pcg_mark(cg.trace, 4, 1, blockIdx.x);
   // ---- scalars
