@@ -53,7 +53,22 @@ k_amg_build_P(int nP, const int *__restrict__ P_row, const int *__restrict__ P_o
   if (t >= nP) return;
   const int e = lane < 36 ? lane : 0, r = e / 6, c = e % 6;
   double sum = 0.0;
-  for (int k = Pa_ptr[t]; k < Pa_ptr[t + 1]; ++k) sum += A_val[36 * (int64_t)Pa_idx[k] + e];
+  // the list's indices by one load per 64 entries, its blocks eight at a time: a loop of single loads would wait for
+  // each index and each block in turn
+  const int beg = Pa_ptr[t], end = Pa_ptr[t + 1];
+  for (int base = beg; base < end; base += 64) {
+    const int n = min(64, end - base);
+    const int mine = lane < n ? Pa_idx[base + lane] : 0;
+    for (int u0 = 0; u0 < n; u0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = __shfl(mine, (u0 + u) & 63, 64);
+        v[u] = (u0 + u < n) ? A_val[36 * (int64_t)idx + e] : 0.0;
+      }
+      sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+  }
   const double *D = Dinv + 36 * (int64_t)P_row[t];
   double acc = 0.0;
 #pragma unroll

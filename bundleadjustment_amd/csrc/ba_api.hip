@@ -61,7 +61,9 @@ int popcount32(unsigned v) { return __builtin_popcount(v); }
 // (the step phase), and for the maximum SC_GMAX_P, SC_NOTPD_P (the linearisation).
 enum Scal {
   SC_COST = 0, SC_FIXED, SC_GMAX, SC_STEP2_SC, SC_CNORM2_SC, SC_MCC, SC_STEP2_P, SC_CNORM2_P, SC_CCOST, SC_XNORM2_SC,
-  SC_XNORM2_P, SC_GMAX_P, SC_NOTPD_P, SC_GMAX_SC, SC_LS_DOT_P, SC_LS_DOT_SC, SC_LS_MAX_P, SC_LS_MAX_SC, SC_FLAGS, SC_COUNT = 32
+  SC_XNORM2_P, SC_GMAX_P, SC_NOTPD_P, SC_GMAX_SC, SC_LS_DOT_P, SC_LS_DOT_SC, SC_LS_MAX_P, SC_LS_MAX_SC, SC_FLAGS,
+  SC_CAMINFO,  // what the Cholesky of the camera block of the reduced system reports (0, or 1 + the failing column)
+  SC_COUNT = 32
 };
 
 }  // namespace
@@ -153,6 +155,8 @@ struct ba_problem {
   double *d_G = nullptr, *d_GT = nullptr, *d_SG = nullptr, *d_defl_part = nullptr, *d_E = nullptr, *d_Lcc_defl = nullptr, *d_part_gr = nullptr;
   double *d_defl_b = nullptr, *d_r2 = nullptr;
   bool have_G = false;
+  bool cam_info_pending = false;  // build_reduced has left the camera block's factorisation report in SC_CAMINFO
+  bool defl_failed = false;       // the coarse-space matrix was not positive definite once: solves go without it
   // general explicit border (several cameras or many free camera parameters); null -> one probe per camera column
   double *d_Zc = nullptr, *d_part_cc = nullptr, *d_corner_gen = nullptr;
   int *d_col_cam = nullptr, *d_col_pos = nullptr;
@@ -847,11 +851,14 @@ int linearize(ba_problem *p, const LmState &st) {
   } else {
     HIP_OK(hipMemsetAsync(p->d_scal + SC_GMAX, 0, sizeof(double), s));
   }
+  p->cam_info_pending = false;
   if (st.reduced) BA_TRY(build_reduced(p, st.reduced == 2));
   launch_flag_to_scal(s, p->d_flags, p->d_scal, SC_FLAGS);  // the flag word comes back with the scalars: one read-back
   BA_TRY(p->check_kernels());
   BA_TRY(p->read_scal());
   p->h_scal[SC_GMAX] = std::max(p->h_scal[SC_GMAX], std::max(p->h_scal[SC_GMAX_P], p->h_scal[SC_GMAX_SC]));
+  if (p->cam_info_pending && p->h_scal[SC_CAMINFO] != 0.0)
+    return fail(BA_ERR_NUMERIC, "camera block of the reduced system is not positive definite (column %d)", (int)p->h_scal[SC_CAMINFO] - 1);
   unsigned flag = (unsigned)p->h_scal[SC_FLAGS];
   if (p->ar && p->h_scal[SC_NOTPD_P] != 0.0 && !flag) flag = 1u;  // another rank's point block
   if (flag) {
@@ -975,10 +982,9 @@ int build_reduced(ba_problem *p, bool explicit_blocks) {
   launch_copy(s, (int64_t)p->ncam * p->ncam, p->d_Scc, p->d_Lcc);
   launch_cholesky(s, p->d_Lcc, p->ncam, p->d_info);
   launch_chol_inverse(s, p->d_Lcc, p->ncam, p->d_Sccinv);  // the block-sparse PCG applies the camera block as a product
-  int info = 0;
-  HIP_OK(hipMemcpyAsync(&info, p->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
-  HIP_OK(hipStreamSynchronize(s));
-  if (info) return fail(BA_ERR_NUMERIC, "camera block of the reduced system is not positive definite (column %d)", info - 1);
+  // the factorisation's report travels with the scalars that linearize reads back: no wait of its own
+  launch_flag_to_scal(s, reinterpret_cast<const unsigned *>(p->d_info), p->d_scal, SC_CAMINFO);
+  p->cam_info_pending = true;
   return 0;
 }
 
@@ -1033,7 +1039,7 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
   // problem: it only has to be roughly right) the vectors Q = [-G; I] are added as a coarse space,
   //   z = [M_ss^-1 r_s; 0] + Q (Q^T S Q)^-1 Q^T r,
   // which is symmetric positive definite for any G.
-  bool use_defl = use_amg && p->ncam > 0 && p->ncam <= defl_max_cam();
+  bool use_defl = use_amg && p->ncam > 0 && p->ncam <= defl_max_cam() && !p->defl_failed;
   if (use_defl) {
     const size_t ns = 6 * (size_t)p->S;
     if (!p->d_G) {
@@ -1059,17 +1065,12 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
       p->have_G = true;
     }
     launch_defl_corner(s, a, p->d_G, p->d_SG, p->d_defl_part, p->d_E, p->d_Lcc_defl, p->d_info);
-    int info = 0;
-    HIP_OK(hipMemcpyAsync(&info, p->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_OK(hipStreamSynchronize(s));
-    if (info) {
-      use_defl = false;  // cannot happen for a positive definite S; be safe and drop the coarse space
-    } else {
-      a.G = p->d_G;
-      a.GT = p->d_GT;
-      a.Lcc = p->d_E;  // the explicit inverse
-      a.part_gr = p->d_part_gr;
-    }
+    // its factorisation's report rides in a free slot of the PCG's scalars and is looked at with the first stopping flag
+    launch_flag_to_scal(s, reinterpret_cast<const unsigned *>(p->d_info), p->d_cg2scal, 7);
+    a.G = p->d_G;
+    a.GT = p->d_GT;
+    a.Lcc = p->d_E;  // the explicit inverse
+    a.part_gr = p->d_part_gr;
   }
   const int precond = use_amg ? (use_defl ? 2 : 0) : 1;
   // Several ranks: every rank runs the whole iteration on the summed system (all scalars and vectors are bitwise equal
@@ -1178,6 +1179,11 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
   for (;;) {
     HIP_OK(hipMemcpyAsync(p->h_cgscal, p->d_cg2scal, 10 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
+    if (use_defl && p->h_cgscal[7] != 0.0) {
+      // cannot happen for a positive definite S; be safe: drop the coarse space and start the solve again
+      p->defl_failed = true;
+      return solve_pcg_explicit(p, opt, iters);
+    }
     it = (int)p->h_cgscal[3];
     done = std::max(p->h_cgscal[8], p->h_cgscal[9]);
     if (done != 0.0 || it >= opt->pcg_max_iters) break;
