@@ -177,6 +177,22 @@ def test_multilevel_preconditioner_several_cameras():
     assert_solve_parity(g, o)
 
 
+def test_long_rows_of_the_reduced_matrix():
+    # points seen from 40 stations each: station rows of the block-sparse reduced matrix with more than 64 blocks -- the
+    # product kernel of the PCG keeps a row's first 64 column indices in registers and 21 blocks in flight per pass
+    net = host.synth(n_cam=1, n_sta=100, n_pts=600, rays_per_point=40, ap_free_mask=host.AP_K1K2P1P2, seed=11).net
+    pt, st = np.asarray(net.obs_pt), np.asarray(net.obs_sta)
+    seen = np.zeros((net.n_sta, net.n_sta), dtype=bool)
+    for p_ in range(net.n_pts):
+        ss = st[pt == p_]
+        seen[np.ix_(ss, ss)] = True
+    assert seen.sum(axis=1).max() > 64
+    o = po.solve(net, options(capi.SOLVER_PCG_SCHUR), po.SCHUR_DENSE)
+    assert o[4]["termination"] == capi.CONVERGENCE
+    for precond in (0, 1):
+        assert_solve_parity(gpu_solve(net, options(capi.SOLVER_PCG_SCHUR, preconditioner=precond)), o)
+
+
 @pytest.mark.parametrize("which", ["cfg1", "three_cameras", "fixed_camera"])
 def test_covariance_after_the_solve(which):
     # a-posteriori variances (src/main.cpp:5261-5279, 5443-5565) at the adjusted parameters: the GPU's
