@@ -989,14 +989,14 @@ int build_reduced(ba_problem *p, bool explicit_blocks) {
 }
 
 // Whether forming q = S p by rows pays on `world` ranks: the time of the product that the other ranks take over against
-// the time of the sum that completes q.  The product streams 292 B per block and 96 B per station at the 3.5 TB/s the
+// the time of the sum that completes q.  The product streams 292 B per block and 96 B per station at the 4.8 TB/s the
 // kernel reaches; the sum is a ring all-reduce over xGMI links of about 150 GB/s (2 (W-1)/W of the buffer crosses each
 // link) plus 30 us for a small collective and for queueing the iteration launch by launch instead of as a graph.
-// 10 000 stations / 220 000 blocks on 8 ranks: 16 us saved, 36 us spent -- every rank keeps the whole product;
-// 50 000 stations / 1.1 M blocks: 79 us saved, 58 us spent -- by rows.
+// 8 ranks: 10 000 stations / 220 000 blocks: 12 us saved, 36 us spent -- every rank keeps the whole product;
+// 50 000 stations / 1.1 M blocks: 58 us saved, 59 us spent -- the break-even; 100 000 stations: 116 against 87 -- by rows.
 bool row_sharding_pays(const ba_problem *p, int nbs) {
   const double W = p->shard_world;
-  const double t_product = (292.0 * (double)p->n_bsr + 96.0 * (double)p->S) / 3.5e12;
+  const double t_product = (292.0 * (double)p->n_bsr + 96.0 * (double)p->S) / 4.8e12;
   const double bytes = 8.0 * (6.0 * (double)p->S + (double)nbs * (1 + p->ncam));
   const double t_sum = 30e-6 + 2.0 * (W - 1.0) / W * bytes / 150e9;
   return t_product * (1.0 - 1.0 / W) > t_sum;

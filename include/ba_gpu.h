@@ -346,7 +346,7 @@ int ba_reduction_stats(ba_problem *p, int64_t *count, double *bytes, double *sec
  * iteration -- [q | partial sums], 6 n_sta + a few thousand doubles -- completes the vector on all ranks (everything else
  * of the iteration stays replicated: the vectors are bitwise equal on all ranks either way).  mode -1: never; 0: when the
  * time of the product that the other ranks take over exceeds the time of that reduction (a ring over xGMI links of
- * about 150 GB/s plus 30 us: true from a few ten thousand stations on); 1: always.  Without this call every rank forms
+ * about 150 GB/s plus 30 us: true from about 60 000 stations on, on 8 ranks); 1: always.  Without this call every rank forms
  * the whole product; ba_use_rccl makes it with mode 0.  ba_reduced_solve_rows returns the rows that the last
  * block-sparse PCG solve gave this rank (0, 0: the whole product on every rank).
  * No counterpart in the reference (single-process, src/main.cpp:4705-4721). */
