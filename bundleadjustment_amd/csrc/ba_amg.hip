@@ -224,6 +224,7 @@ struct AmgApplyArgs {
   AmgTransfer t[AMG_MAX_LEVELS - 1];
   double *part;  // per-workgroup partials of rc . y from the restrictions that run as kernels of their own
   int n_part;
+  double *totals;  // 1 + AMG_DEFL_NC sums for the last kernel (k_amg_prolong's folding workgroup)
 };
 
 // The kernels below are bounded by the latency of dependent loads (index list -> values), not by bytes: each issues
@@ -515,9 +516,66 @@ __device__ __forceinline__ double prolong_finish(const AmgTransfer &t, ProlongId
   return s;
 }
 
-// prolongation: yf += tau P yc ; 8 lanes per fine block row (whole waves stay converged for the shuffles)
+// What the last kernel of an iteration needs summed: the partials of r.z of the vector kernel (part_rz) and of the
+// restrictions (part, level 0 up to np0 with weight sigma, the deeper ones with sigma tau), and the partials of G^T r
+// (part_gr, n_part_rz rows of ncam; null without the camera coarse space).  totals: [0] r.z, [1 + k] (G^T r)_k.
+struct AmgFoldArgs {
+  const double *part_rz, *part, *part_gr;
+  int n_part_rz, n_part, np0, ncam;
+  double sigma, tau;
+  double *totals;
+};
+// The sums, in a fixed order, by one workgroup of 256 threads (the loads eight / four at a time)
+__device__ __forceinline__ void amg_fold(const AmgFoldArgs &fa) {
+  __shared__ double lds[4];
+  __shared__ double gr4[4][16];
+  double g = 0.0;
+  if (fa.part_gr) {
+    // 16 lanes per sum, the partials dealt round-robin; then across the wave and the waves
+    const int k = threadIdx.x & 15, j = threadIdx.x >> 4;
+    if (k < fa.ncam)
+      for (int m = j; m < fa.n_part_rz; m += 128) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (m + 16 * u < fa.n_part_rz) ? fa.part_gr[(int64_t)(m + 16 * u) * fa.ncam + k] : 0.0;
+        g += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      }
+  }
+  double s = 0.0;
+  for (int k = threadIdx.x; k < fa.n_part_rz; k += 4 * blockDim.x) {
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = (k + u * (int)blockDim.x < fa.n_part_rz) ? fa.part_rz[k + u * blockDim.x] : 0.0;
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+  }
+  for (int k = threadIdx.x; k < fa.n_part; k += 4 * blockDim.x) {
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kk = k + u * (int)blockDim.x;
+      v[u] = (kk < fa.n_part) ? (kk < fa.np0 ? fa.sigma : fa.sigma * fa.tau) * fa.part[kk] : 0.0;
+    }
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+  }
+  g += __shfl_xor(g, 16, 64);
+  g += __shfl_xor(g, 32, 64);
+  if ((threadIdx.x & 63) < 16) gr4[threadIdx.x >> 6][threadIdx.x & 15] = g;
+  const double tot = block_sum(s, lds);  // has the barriers that publish gr4
+  if (threadIdx.x == 0) fa.totals[0] = tot;
+  if (fa.part_gr && (int)threadIdx.x < fa.ncam)
+    fa.totals[1 + threadIdx.x] = (gr4[0][threadIdx.x] + gr4[1][threadIdx.x]) + (gr4[2][threadIdx.x] + gr4[3][threadIdx.x]);
+}
+
+// prolongation: yf += tau P yc ; 8 lanes per fine block row (whole waves stay converged for the shuffles).  With
+// fold.totals set, one more workgroup (the last) forms the sums for the last kernel of the iteration: every partial is
+// final by now, and summed here once instead of by each of that kernel's workgroups -- their number and the number of
+// partials both grow with the stations.
 __global__ void __launch_bounds__(256)
-k_amg_prolong(AmgTransfer t, double *__restrict__ yf, double tau, unsigned long long *trace) {
+k_amg_prolong(AmgTransfer t, double *__restrict__ yf, double tau, AmgFoldArgs fold, unsigned long long *trace) {
+  if (fold.totals && blockIdx.x == gridDim.x - 1) {
+    amg_fold(fold);
+    return;
+  }
   pcg_mark(trace, 3, 0, blockIdx.x);
   const int i = blockIdx.x * 32 + (threadIdx.x >> 3), r = threadIdx.x & 7, lane = threadIdx.x & 63;
   const bool on = i < t.nb;
@@ -537,7 +595,7 @@ k_amg_prolong(AmgTransfer t, double *__restrict__ yf, double tau, unsigned long 
 // Workgroup 0 publishes the scalars for the next iteration in the other parity slot.
 __global__ void __launch_bounds__(256)
 k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restrict__ part, int n_part, int n_part_rz,
-              int parity, int mode, double rtol, double sigma, double tau, int np0) {
+              int parity, int mode, double rtol, double sigma, double tau, int np0, const double *__restrict__ totals) {
   __shared__ double lds[4];
   __shared__ double rzn_s;
   __shared__ double Ls[AMG_DEFL_NC * AMG_DEFL_NC], gr4[4][16], zcs[AMG_DEFL_NC], tcs[AMG_DEFL_NC], tot_s;
@@ -563,34 +621,39 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restr
     if (blockIdx.x == 0 && threadIdx.x == 0) cg.scal[8 + (parity ^ 1)] = done;  // keep both slots set
     return;
   }
-  double g = 0.0;
-  if (defl) {
-    // G^T r_s: 16 lanes per sum, the partials dealt round-robin; then across the wave and the waves
-    const int k = threadIdx.x & 15, j = threadIdx.x >> 4;
-    // eight loads at a time: a loop of single loads would wait for each in turn
-    if (k < cg.ncam)
-      for (int m = j; m < n_part_rz; m += 128) {
-        double v[8];
+  double g = 0.0, s = 0.0;
+  if (totals) {
+    // summed already (k_amg_prolong's last workgroup): placed where the reductions below expect partial sums
+    if (threadIdx.x == 0) s = totals[0];
+    if (defl && (int)threadIdx.x < cg.ncam) g = totals[1 + threadIdx.x];
+  } else {
+    if (defl) {
+      // G^T r_s: 16 lanes per sum, the partials dealt round-robin; then across the wave and the waves
+      const int k = threadIdx.x & 15, j = threadIdx.x >> 4;
+      // eight loads at a time: a loop of single loads would wait for each in turn
+      if (k < cg.ncam)
+        for (int m = j; m < n_part_rz; m += 128) {
+          double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (m + 16 * u < n_part_rz) ? cg.part_gr[(int64_t)(m + 16 * u) * cg.ncam + k] : 0.0;
-        g += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-      }
-  }
-  double s = 0.0;
-  for (int k = threadIdx.x; k < n_part_rz; k += 4 * blockDim.x) {
-    double v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = (k + u * (int)blockDim.x < n_part_rz) ? cg.part_rz[k + u * blockDim.x] : 0.0;
-    s += (v[0] + v[1]) + (v[2] + v[3]);
-  }
-  for (int k = threadIdx.x; k < n_part; k += 4 * blockDim.x) {
-    double v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int kk = k + u * (int)blockDim.x;
-      v[u] = (kk < n_part) ? (kk < np0 ? sigma : sigma * tau) * part[kk] : 0.0;
+          for (int u = 0; u < 8; ++u) v[u] = (m + 16 * u < n_part_rz) ? cg.part_gr[(int64_t)(m + 16 * u) * cg.ncam + k] : 0.0;
+          g += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
     }
-    s += (v[0] + v[1]) + (v[2] + v[3]);
+    for (int k = threadIdx.x; k < n_part_rz; k += 4 * blockDim.x) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = (k + u * (int)blockDim.x < n_part_rz) ? cg.part_rz[k + u * blockDim.x] : 0.0;
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    for (int k = threadIdx.x; k < n_part; k += 4 * blockDim.x) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kk = k + u * (int)blockDim.x;
+        v[u] = (kk < n_part) ? (kk < np0 ? sigma : sigma * tau) * part[kk] : 0.0;
+      }
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
   }
   const double corr = has_coarse ? prolong_finish(t, pi, threadIdx.x & 63) : 0.0;
   pcg_mark(cg.trace, 4, 1, blockIdx.x);
@@ -687,7 +750,7 @@ struct Level {  // transfer from level l to level l + 1 and everything the numer
 struct Amg {
   std::vector<Level> levels;
   std::vector<void *> allocs;
-  double *d_tmp = nullptr, *d_tmp2 = nullptr, *d_part = nullptr, *d_norm = nullptr;
+  double *d_tmp = nullptr, *d_tmp2 = nullptr, *d_part = nullptr, *d_norm = nullptr, *d_totals = nullptr;
   unsigned *d_flags = nullptr;
   int n_part = 0;  // per-workgroup partials of all restrictions
   char err[256] = {0};
@@ -992,7 +1055,7 @@ int amg_build(Amg *a, hipStream_t s, int nb0, const std::vector<int> &rowptr, co
   }
   a->n_part = 0;
   for (const Level &L : a->levels) a->n_part += nblk(L.nc, 4);
-  if (!a->dalloc(&a->d_part, (size_t)a->n_part)) return -1;
+  if (!a->dalloc(&a->d_part, (size_t)a->n_part) || !a->dalloc(&a->d_totals, 1 + AMG_DEFL_NC)) return -1;
   if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) {
     snprintf(a->err, sizeof a->err, "multilevel preconditioner: set-up kernels failed");
     return -1;
@@ -1020,6 +1083,7 @@ static AmgApplyArgs apply_args(const Amg *a) {
   }
   aa.part = a->d_part;
   aa.n_part = a->n_part;
+  aa.totals = a->d_totals;
   return aa;
 }
 
@@ -1040,13 +1104,22 @@ static void amg_finish_iteration(hipStream_t s, const BsrCgArgs &cg, const Amg *
     hipLaunchKernelGGL(k_amg_restrict, dim3(nb), dim3(256), 0, s, aa.t[l], l == 0 ? cg.r : aa.t[l - 1].rc, aa.part + off, cg.trace);
     off += nb;
   }
-  for (int l = aa.n_transfers - 1; l >= 1; --l)
-    hipLaunchKernelGGL(k_amg_prolong, dim3(nblk(aa.t[l].nb, 32)), dim3(256), 0, s, aa.t[l], aa.t[l - 1].y,
-                       AMG_DEEP_WEIGHT, cg.trace);
+  const int np0 = aa.n_transfers > 0 ? nblk(aa.t[0].nc, 4) : 0;
+  const double *totals = nullptr;
+  for (int l = aa.n_transfers - 1; l >= 1; --l) {
+    AmgFoldArgs fa{};
+    if (l == 1) {  // the last launch before the final kernel: one more workgroup sums what that kernel needs
+      fa.part_rz = cg.part_rz; fa.part = aa.part; fa.part_gr = cg.G ? cg.part_gr : nullptr;
+      fa.n_part_rz = n_part_rz; fa.n_part = aa.n_part; fa.np0 = np0; fa.ncam = cg.ncam;
+      fa.sigma = AMG_COARSE_WEIGHT; fa.tau = AMG_DEEP_WEIGHT; fa.totals = aa.totals;
+      totals = aa.totals;
+    }
+    hipLaunchKernelGGL(k_amg_prolong, dim3(nblk(aa.t[l].nb, 32) + (l == 1 ? 1 : 0)), dim3(256), 0, s, aa.t[l], aa.t[l - 1].y,
+                       AMG_DEEP_WEIGHT, fa, cg.trace);
+  }
   hipLaunchKernelGGL(k_amg_update2, dim3(nblk(cg.S, 32) > 0 ? nblk(cg.S, 32) : 1), dim3(256), 0, s, cg, aa.t[0],
                      aa.n_transfers > 0 ? 1 : 0, aa.part, aa.n_part, n_part_rz, parity, mode, rtol,
-                     AMG_COARSE_WEIGHT, AMG_DEEP_WEIGHT,
-                     aa.n_transfers > 0 ? nblk(aa.t[0].nc, 4) : 0);
+                     AMG_COARSE_WEIGHT, AMG_DEEP_WEIGHT, np0, totals);
 }
 
 void launch_amg_cg_init(hipStream_t s, const BsrCgArgs &cg, const Amg *a, double rtol) {
