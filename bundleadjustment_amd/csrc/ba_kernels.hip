@@ -741,22 +741,21 @@ __global__ void k_station_fold(int S, const int *__restrict__ sta_chunk0, const 
   out[t] = s;
 }
 
-// Camera rows after SMODE_GATHER_CAM / SMODE_CAMNORM: one workgroup per camera sums, in chunk
-// order, the partials of the chunks whose station uses that camera.
+// Camera rows after SMODE_GATHER_CAM / SMODE_CAMNORM: one workgroup per camera and column (blockIdx.y) sums, in
+// chunk order, the partials of the chunks whose station uses that camera.
 __global__ void __launch_bounds__(256)
 k_camera_fold(int n_chunks, const int *__restrict__ chunk_sta, const int *__restrict__ sta_cam,
               const CamRec *__restrict__ cam, const double *__restrict__ part, int stride, int coloff,
               double *__restrict__ out_cam) {
   __shared__ double lds[8];
-  const int c = blockIdx.x;
+  const int c = blockIdx.x, k = blockIdx.y;
   const int nc = cam[c].nc, off = cam[c].off;
-  for (int k = 0; k < nc; ++k) {
-    double s = 0.0;
-    for (int ch = threadIdx.x; ch < n_chunks; ch += blockDim.x)
-      if (sta_cam[chunk_sta[ch]] == c) s += part[(int64_t)stride * ch + coloff + k];
-    const double t = block_sum(s, lds);
-    if (threadIdx.x == 0) out_cam[off + k] = t;
-  }
+  if (k >= nc) return;  // uniform over the workgroup
+  double s = 0.0;
+  for (int ch = threadIdx.x; ch < n_chunks; ch += blockDim.x)
+    if (sta_cam[chunk_sta[ch]] == c) s += part[(int64_t)stride * ch + coloff + k];
+  const double t = block_sum(s, lds);
+  if (threadIdx.x == 0) out_cam[off + k] = t;
 }
 
 // v[k] += diag[k]: the diagonal term of column k of the reduced matrix after a unit-vector probe
@@ -1522,7 +1521,7 @@ void launch_station_fold(hipStream_t s, int S, const int *sta_chunk0, const doub
 }
 void launch_camera_fold(hipStream_t s, int C, int n_chunks, const int *chunk_sta, const int *sta_cam, const CamRec *cam,
                         const double *part, int stride, int coloff, double *out_cam) {
-  if (C > 0) hipLaunchKernelGGL(k_camera_fold, dim3(C), dim3(256), 0, s, n_chunks, chunk_sta, sta_cam, cam, part, stride, coloff, out_cam);
+  if (C > 0) hipLaunchKernelGGL(k_camera_fold, dim3(C, BA_NCAMPAR), dim3(256), 0, s, n_chunks, chunk_sta, sta_cam, cam, part, stride, coloff, out_cam);
 }
 void launch_add_diag_entry(hipStream_t s, double *v, const double *diag, int64_t k) {
   hipLaunchKernelGGL(k_add_diag_entry, dim3(1), dim3(1), 0, s, v, diag, k);
