@@ -82,7 +82,7 @@ struct Cg2Shared {
 
 // Eight sums at a time (q0 .. q0 + 7 of the 1 + ncam): thread t takes sum (t & 7) and every 32nd partial from
 // (t >> 3) on; at most CG2_MAX_SPMV_BLOCKS partials (cg2_blocks_spmv).
-#define CG2_FOLD_LOADS 16
+#define CG2_FOLD_LOADS 8
 #define CG2_MAX_SPMV_BLOCKS (32 * CG2_FOLD_LOADS)
 struct FoldLoads {
   double v[CG2_FOLD_LOADS];
@@ -110,8 +110,6 @@ __device__ __forceinline__ double cg2_alpha(const BsrCgArgs &a, double rz, int n
   if (threadIdx.x < a.ncam) sh.pcs[threadIdx.x] = f.pc;
   for (int q0 = 0; q0 < 1 + a.ncam; q0 += 8) {
     if (q0 > 0) fold_issue(a, nblk_spmv, q0, f);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f.v[j] += f.v[j + 8];  // fixed order
 #pragma unroll
     for (int w2 = 4; w2 >= 1; w2 >>= 1)
 #pragma unroll

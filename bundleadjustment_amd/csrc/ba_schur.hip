@@ -339,7 +339,7 @@ __global__ void k_border_general_corner(int ncam, const double *__restrict__ cor
 //       so no workgroup ever sees a scalar change under it.
 // q = S p for station rows (one wave per row) with per-workgroup partials of p.q and of the
 // camera rows Ssc^T p.
-#define SPMV_WAVES 8
+#define SPMV_WAVES 16  // per workgroup: one partial sum per workgroup, and every workgroup of the next kernel folds them all
 #define SPMV_NT 7  // triples of blocks in flight per wave: a row of up to 21 blocks is one pass (24 would spill registers)
 // The kernel is a chain of dependent loads per row (row pointer -> columns -> blocks and entries of p), and a wave has
 // two or three rows: the row pointers of the next two rows and the columns of the next row are requested together with
@@ -746,8 +746,8 @@ void launch_border_corner(hipStream_t s, int ncam, const double *corner, const d
 int cg2_blocks_spmv(int S) {
   // one resident round of workgroups; also bounds the partials the vector kernel folds
   const int nb = nblk(S, SPMV_WAVES);
-  // as many workgroups as the device holds at once (three per CU on MI355X: 768; a fourth hundred would wait for a
-  // second round and costs 10 %), at most the partials the fold takes
+  // as many workgroups as the device holds at once (one of sixteen waves per CU on MI355X: 256; more would wait for a
+  // second round), at most the partials the fold takes
   static int cap = 0;
   if (!cap) {
     int dev = 0, cus = 0, per_cu = 0;
