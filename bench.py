@@ -187,7 +187,7 @@ def main():
     if rehearsal:
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    from bundleadjustment_amd import capi, host, sharding, solver
+    from bundleadjustment_amd import capi, host, solver
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -199,7 +199,8 @@ def main():
 
     hn = host.synth_config(args.config, scale=args.scale)
     full = hn.net
-    net, _ = sharding.shard_network(full, rank, world)
+    # the rank's points and their observations, cut by the host library (the same partition as sharding.shard_network)
+    net = hn.shard(rank, world)[0].net if world > 1 else full
     P = solver.Problem(net)
     if world > 1 and rehearsal:
         def reduce_fn(buf, op):
