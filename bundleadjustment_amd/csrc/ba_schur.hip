@@ -354,8 +354,9 @@ k_bsr_spmv(BsrCgArgs a, int parity) {
   const double done = a.scal[8 + parity];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row_begin = a.rows_sharded ? a.row0 : 0, row_end = a.rows_sharded ? a.row_end : a.S;
-  const int stride = gridDim.x * SPMV_WAVES;
-  int i = row_begin + blockIdx.x * SPMV_WAVES + w;
+  const int nw = blockDim.x >> 6;  // 16 waves, or 8 on small systems (spmv_waves)
+  const int stride = gridDim.x * nw;
+  int i = row_begin + blockIdx.x * nw + w;
   int rb = 0, re = 0, rbn = 0, ren = 0;
   if (i < row_end) {
     rb = a.rowptr[i];
@@ -466,14 +467,12 @@ k_bsr_spmv(BsrCgArgs a, int parity) {
   __syncthreads();
   if (threadIdx.x == 0) {
     double t = 0.0;
-#pragma unroll
-    for (int m = 0; m < SPMV_WAVES; ++m) t += lds_pq[m];
+    for (int m = 0; m < nw; ++m) t += lds_pq[m];
     a.part_pq[blockIdx.x] = t;
   }
   for (int k = threadIdx.x; k < a.ncam; k += blockDim.x) {
     double t = 0.0;
-#pragma unroll
-    for (int m = 0; m < SPMV_WAVES; ++m) t += lds_qc[m][k];
+    for (int m = 0; m < nw; ++m) t += lds_qc[m][k];
     a.part_qc[(int64_t)blockIdx.x * a.ncam + k] = t + corner;  // k == threadIdx.x: ncam is below the workgroup size
   }
   pcg_mark(a.trace, 0, 3, blockIdx.x);
@@ -743,9 +742,14 @@ void launch_border_general_corner(hipStream_t s, int ncam, const double *corner,
 void launch_border_corner(hipStream_t s, int ncam, const double *corner, const double *camdiag, double *Scc) {
   hipLaunchKernelGGL(k_border_corner, dim3(1), dim3(1), 0, s, ncam, corner, camdiag, Scc);
 }
+// Waves per workgroup of the product kernel: 16 (one partial sum per workgroup, and every workgroup of the next kernel
+// folds them all), 8 on systems so small that workgroups of 16 would leave most CUs without one.
+static int spmv_waves(int S) { return nblk(S, SPMV_WAVES / 2) <= CG2_MAX_SPMV_BLOCKS ? SPMV_WAVES / 2 : SPMV_WAVES; }
 int cg2_blocks_spmv(int S) {
   // one resident round of workgroups; also bounds the partials the vector kernel folds
-  const int nb = nblk(S, SPMV_WAVES);
+  const int nw = spmv_waves(S);
+  const int nb = nblk(S, nw);
+  if (nw < SPMV_WAVES) return nb;  // at most CG2_MAX_SPMV_BLOCKS by the choice of nw, all resident
   // as many workgroups as the device holds at once (one of sixteen waves per CU on MI355X: 256; more would wait for a
   // second round), at most the partials the fold takes
   static int cap = 0;
@@ -755,7 +759,7 @@ int cg2_blocks_spmv(int S) {
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bsr_spmv, 64 * SPMV_WAVES, 0) == hipSuccess && cus > 0 && per_cu > 0)
       cap = std::min((int)CG2_MAX_SPMV_BLOCKS, cus * per_cu);
     else
-      cap = 512;
+      cap = 256;
     (void)hipGetLastError();
   }
   if (nb <= cap) return nb;
@@ -816,23 +820,23 @@ void launch_cg2_start(hipStream_t s, const BsrCgArgs &a) {
 }
 void launch_cg2_spmv_update1(hipStream_t s, const BsrCgArgs &a, int parity) {
   const int nbs = cg2_blocks_spmv(a.S), nbv = cg2_blocks_vec(a.S);
-  if (nbs > 0) hipLaunchKernelGGL(k_bsr_spmv, dim3(nbs), dim3(64 * SPMV_WAVES), 0, s, a, parity);
+  if (nbs > 0) hipLaunchKernelGGL(k_bsr_spmv, dim3(nbs), dim3(64 * spmv_waves(a.S)), 0, s, a, parity);
   hipLaunchKernelGGL(k_cg2_update1, dim3(nbv), dim3(256), 0, s, a, parity, nbs);
 }
 void launch_bsr_spmv(hipStream_t s, const BsrCgArgs &a, int parity) {
   const int nbs = cg2_blocks_spmv(a.S);
-  if (nbs > 0) hipLaunchKernelGGL(k_bsr_spmv, dim3(nbs), dim3(64 * SPMV_WAVES), 0, s, a, parity);
+  if (nbs > 0) hipLaunchKernelGGL(k_bsr_spmv, dim3(nbs), dim3(64 * spmv_waves(a.S)), 0, s, a, parity);
 }
 // out[0] = a.p^T S a.p (a.q is overwritten; a.scal must point to zeros: the stopping flag of a finished solve would
 // make the product return at once)
 void launch_quadratic_form(hipStream_t s, const BsrCgArgs &a, double *out) {
   const int nbs = cg2_blocks_spmv(a.S);
-  if (nbs > 0) hipLaunchKernelGGL(k_bsr_spmv, dim3(nbs), dim3(64 * SPMV_WAVES), 0, s, a, 0);
+  if (nbs > 0) hipLaunchKernelGGL(k_bsr_spmv, dim3(nbs), dim3(64 * spmv_waves(a.S)), 0, s, a, 0);
   hipLaunchKernelGGL(k_quadratic_form, dim3(1), dim3(256), 0, s, a, nbs, out);
 }
 void launch_cg2_iteration(hipStream_t s, const BsrCgArgs &a, int parity) {
   const int nbs = cg2_blocks_spmv(a.S), nbv = cg2_blocks_vec(a.S);
-  if (nbs > 0) hipLaunchKernelGGL(k_bsr_spmv, dim3(nbs), dim3(64 * SPMV_WAVES), 0, s, a, parity);
+  if (nbs > 0) hipLaunchKernelGGL(k_bsr_spmv, dim3(nbs), dim3(64 * spmv_waves(a.S)), 0, s, a, parity);
   hipLaunchKernelGGL(k_cg2_update1, dim3(nbv), dim3(256), 0, s, a, parity, nbs);
   hipLaunchKernelGGL(k_cg2_update2, dim3(nbv), dim3(256), 0, s, a, parity, nbv);
 }
