@@ -76,10 +76,15 @@ k_point_elim(LinArgs a) {
     double B[CAM1 ? NCP : 1][3];  // all camera columns; the free ones are picked at the end
 #pragma unroll
     for (int k = 0; k < (CAM1 ? NCP : 1); ++k) B[k][0] = B[k][1] = B[k][2] = 0.0;
+    // the next observation's record is requested before this one is evaluated: its latency hides behind the arithmetic
+    // (the station record still follows its index: one dependent load per observation instead of two)
+    ObsIn o_next = load_obs(a.obs, e0 < e1 ? e0 : 0);
     for (int e = e0; e < e1; ++e) {
-      const ObsIn o = load_obs(a.obs, e);
+      const ObsIn o = o_next;
+      o_next = load_obs(a.obs, e + 1 < e1 ? e + 1 : e);
       const double *st = a.sta + (int64_t)BA_STA_STRIDE * o.sta;
-      const int c = __double2loint(st[20]);
+      // one camera: its record has one address for all lanes (scalar loads, no wait for the station record first)
+      const int c = CAM1 ? 0 : __double2loint(st[20]);
       const CamIn cm = load_cam(a.cam, c);
       double r0, r1, Js[12], Jp[6], dc0[NCP], dc1[NCP];
       eval_obs<true, GEN, EMP>(o, st, X, Y, Z, cm, r0, r1, Js, Jp, dc0, dc1, a.model);
@@ -225,7 +230,7 @@ k_obs_rows(LinArgs a) {
     const ObsIn o = load_obs(a.obs, e);
     const int jj = a.obs_pt[e];
     const double *st = a.sta + (int64_t)BA_STA_STRIDE * o.sta;
-    const int c = __double2loint(st[20]);
+    const int c = CAM1 ? 0 : __double2loint(st[20]);  // one camera: scalar loads of its record
     const CamIn cm = load_cam(a.cam, c);
     const double X = a.xyz[3 * (int64_t)jj], Y = a.xyz[3 * (int64_t)jj + 1], Z = a.xyz[3 * (int64_t)jj + 2];
     const double s0 = a.scale_pt[3 * (int64_t)jj], s1 = a.scale_pt[3 * (int64_t)jj + 1], s2 = a.scale_pt[3 * (int64_t)jj + 2];
