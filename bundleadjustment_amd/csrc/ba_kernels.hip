@@ -222,17 +222,54 @@ k_obs_rows(LinArgs a) {
   // (sixteen accumulators per lane across the tile loop would cost the second wave per SIMD)
   if (CAM1) lds_cam[w][lane] = 0.0;  // LIN_NPART == 64
   const int64_t n_tiles = (a.N + 63) / 64;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+  // The observation record and point index of the NEXT tile are requested at the top of a tile: a wave's loads and
+  // stores complete in order, so a load issued after a tile's stores also waits for those to drain.
+  const int64_t tile_step = (int64_t)gridDim.x * 4;
+  ObsIn o_next{};
+  int jj_next = 0;
+  {
+    const int64_t t0 = (int64_t)blockIdx.x * 4 + w;
+    if (t0 < n_tiles) {
+      const int64_t en = (t0 * 64 + lane < a.N) ? t0 * 64 + lane : t0 * 64;
+      o_next = load_obs(a.obs, en);
+      jj_next = a.obs_pt[en];
+    }
+  }
+  // ... and the records those lead to (station, point) right before a tile's first store, for the same reason
+  // (what the projection needs: rotation, position, sin/cos kappa, the point; the scales are read when they are used)
+  double st_next[14], xyz_next[3];
+  auto gather_next = [&]() {
+    const double2 *sp = reinterpret_cast<const double2 *>(a.sta + (int64_t)BA_STA_STRIDE * o_next.sta);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const double2 v = sp[k];
+      st_next[2 * k] = v.x;
+      st_next[2 * k + 1] = v.y;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) xyz_next[k] = a.xyz[3 * (int64_t)jj_next + k];
+  };
+  gather_next();
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < n_tiles; tile += tile_step) {
     const int64_t e0 = tile * 64;
     const int nvalid = (int)((a.N - e0 < 64) ? (a.N - e0) : 64);
     const bool on = lane < nvalid;
-    const int64_t e = on ? e0 + lane : e0;  // idle lanes of the last tile redo its first observation and store nothing
-    const ObsIn o = load_obs(a.obs, e);
-    const int jj = a.obs_pt[e];
-    const double *st = a.sta + (int64_t)BA_STA_STRIDE * o.sta;
-    const int c = CAM1 ? 0 : __double2loint(st[20]);  // one camera: scalar loads of its record
+    // idle lanes of the last tile redo its first observation and store nothing
+    const ObsIn o = o_next;
+    const int jj = jj_next;
+    if (tile + tile_step < n_tiles) {
+      const int64_t en0 = (tile + tile_step) * 64;
+      const int64_t en = (en0 + lane < a.N) ? en0 + lane : en0;
+      o_next = load_obs(a.obs, en);
+      jj_next = a.obs_pt[en];
+    }
+    double st[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) st[k] = st_next[k];
+    const double *st_rec = a.sta + (int64_t)BA_STA_STRIDE * o.sta;
+    const int c = CAM1 ? 0 : __double2loint(st_rec[20]);  // one camera: scalar loads of its record
     const CamIn cm = load_cam(a.cam, c);
-    const double X = a.xyz[3 * (int64_t)jj], Y = a.xyz[3 * (int64_t)jj + 1], Z = a.xyz[3 * (int64_t)jj + 2];
+    const double X = xyz_next[0], Y = xyz_next[1], Z = xyz_next[2];
     const double s0 = a.scale_pt[3 * (int64_t)jj], s1 = a.scale_pt[3 * (int64_t)jj + 1], s2 = a.scale_pt[3 * (int64_t)jj + 2];
     double r0, r1, Js[12], Jp[6], dc0[NCP], dc1[NCP];
     eval_obs<true, GEN, EMP>(o, st, X, Y, Z, cm, r0, r1, Js, Jp, dc0, dc1, a.model);
@@ -295,13 +332,14 @@ k_obs_rows(LinArgs a) {
       double rec[16];
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        const double cs = sc * st[14 + k];
+        const double cs = sc * st_rec[14 + k];
         Js[k] *= cs;
         Js[6 + k] *= cs;
         rec[k] = Js[k];
         rec[6 + k] = Js[6 + k];
       }
       rec[12] = r0; rec[13] = r1; rec[14] = h0; rec[15] = h1;
+      if (tile + tile_step < n_tiles) gather_next();  // before this tile's first store
       tile_store<16>(buf, rec, a.rec + (int64_t)BA_REC_STRIDE * e0, lane, nvalid);
     }
     {
