@@ -78,7 +78,8 @@ k_point_elim(LinArgs a) {
     for (int k = 0; k < (CAM1 ? NCP : 1); ++k) B[k][0] = B[k][1] = B[k][2] = 0.0;
     // the next observation's record is requested before this one is evaluated: its latency hides behind the arithmetic
     // (the station record still follows its index: one dependent load per observation instead of two)
-    ObsIn o_next = load_obs(a.obs, e0 < e1 ? e0 : 0);
+    ObsIn o_next{};
+    if (e0 < e1) o_next = load_obs(a.obs, e0);
     for (int e = e0; e < e1; ++e) {
       const ObsIn o = o_next;
       o_next = load_obs(a.obs, e + 1 < e1 ? e + 1 : e);
@@ -249,7 +250,7 @@ k_obs_rows(LinArgs a) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) xyz_next[k] = a.xyz[3 * (int64_t)jj_next + k];
   };
-  gather_next();
+  if ((int64_t)blockIdx.x * 4 + w < n_tiles) gather_next();
   for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < n_tiles; tile += tile_step) {
     const int64_t e0 = tile * 64;
     const int nvalid = (int)((a.N - e0 < 64) ? (a.N - e0) : 64);
