@@ -614,15 +614,45 @@ k_backsub_y(PointArgs a) {
     const int eb = a.pt_start[jj0], ee = a.pt_start[jend];
     const int e0 = has_pt ? a.pt_start[jj] : ee, e1 = has_pt ? a.pt_start[jj + 1] : ee;
     double t0 = 0, t1 = 0, t2 = 0;
+    // the point's elimination record up front: its loads travel with those of the observations (the camera columns in a
+    // loop over their run-time number would be one dependent load after the other)
+    double el9[9], elz[LIN_NCB][3];
+    {
+      const double *el = a.elim + (int64_t)ELIM_STRIDE * (has_pt ? jj : jj0);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) el9[k] = el[k];
+      const double2 *z = reinterpret_cast<const double2 *>(el + 16);
+#pragma unroll
+      for (int k = 0; k < 3 * LIN_NCB / 2; ++k) {
+        const double2 v = (2 * k < 3 * a.ncam) ? z[k] : make_double2(0.0, 0.0);
+        (&elz[0][0])[2 * k] = v.x;
+        (&elz[0][0])[2 * k + 1] = v.y;
+      }
+    }
+    // a chunk of 64 observations per pass; the station indices and Y rows of the next chunk are requested before this
+    // one is worked on
+    int sta_n = 0;
+    double2 yn[9];
+    auto request = [&](int base) {
+      const int e = base + lane;
+      if (e < ee) {
+        sta_n = a.obs_sta[e];
+        const double2 *py = reinterpret_cast<const double2 *>(a.Y + (int64_t)BA_Y_STRIDE * e);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) yn[k] = py[k];
+      }
+    };
+    request(eb);
     for (int base = eb; base < ee; base += 64) {
       const int e = base + lane;
       double c0 = 0, c1 = 0, c2 = 0;
-      if (e < ee) {
-        const int sta = a.obs_sta[e];
-        const double2 *pv = reinterpret_cast<const double2 *>(a.vec + 6 * (int64_t)sta);
-        const double2 *py = reinterpret_cast<const double2 *>(a.Y + (int64_t)BA_Y_STRIDE * e);
-        const double2 v0 = pv[0], v1 = pv[1], v2 = pv[2];
-        const double2 y0 = py[0], y1 = py[1], y2 = py[2], y3 = py[3], y4 = py[4], y5 = py[5], y6 = py[6], y7 = py[7], y8 = py[8];
+      const int sta = sta_n;
+      const double2 y0 = yn[0], y1 = yn[1], y2 = yn[2], y3 = yn[3], y4 = yn[4], y5 = yn[5], y6 = yn[6], y7 = yn[7], y8 = yn[8];
+      const bool mine = e < ee;
+      const double2 *pv = reinterpret_cast<const double2 *>(a.vec + 6 * (int64_t)(mine ? sta : 0));
+      const double2 v0 = pv[0], v1 = pv[1], v2 = pv[2];
+      if (base + 64 < ee) request(base + 64);
+      if (mine) {
         // Y row-major 6 x 3: row r at 3 r
         c0 = y0.x * v0.x + y1.y * v0.y + y3.x * v1.x + y4.y * v1.y + y6.x * v2.x + y7.y * v2.y;
         c1 = y0.y * v0.x + y2.x * v0.y + y3.y * v1.x + y5.x * v1.y + y6.y * v2.x + y8.x * v2.y;
@@ -645,17 +675,18 @@ k_backsub_y(PointArgs a) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     if (has_pt) {
-      const double *el = a.elim + (int64_t)ELIM_STRIDE * jj;
-      const double u0 = el[0], u1 = el[1], u2 = el[2];
-      const double l00 = el[3], l10 = el[4], l20 = el[5], l11 = el[6], l21 = el[7], l22 = el[8];
+      const double u0 = el9[0], u1 = el9[1], u2 = el9[2];
+      const double l00 = el9[3], l10 = el9[4], l20 = el9[5], l11 = el9[6], l21 = el9[7], l22 = el9[8];
       double y0 = u0 - l00 * t0, y1 = u1 - (l10 * t0 + l11 * t1), y2 = u2 - (l20 * t0 + l21 * t1 + l22 * t2);
       const double *yc = a.vec + 6 * (int64_t)a.S;
-      for (int k = 0; k < a.ncam; ++k) {
-        const double c = yc[k];
-        y0 -= el[16 + 3 * k] * c;
-        y1 -= el[17 + 3 * k] * c;
-        y2 -= el[18 + 3 * k] * c;
-      }
+#pragma unroll
+      for (int k = 0; k < LIN_NCB; ++k)
+        if (k < a.ncam) {  // the record holds LIN_NCB camera columns at most
+          const double c = yc[k];
+          y0 -= elz[k][0] * c;
+          y1 -= elz[k][1] * c;
+          y2 -= elz[k][2] * c;
+        }
       double *yo = a.y_pt + 3 * (int64_t)jj;
       yo[0] = y0; yo[1] = y1; yo[2] = y2;
       const double *g = a.g_pt + 3 * (int64_t)jj, *dg = a.diag_pt + 3 * (int64_t)jj;
