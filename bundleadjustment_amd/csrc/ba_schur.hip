@@ -56,8 +56,11 @@ k_schur_blocks(int nu, const int *__restrict__ cstart, const int2 *__restrict__ 
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) acc[i][j] = 0.0;
+  // the pair after this one is requested before this one's records: one dependent load per step instead of two
+  int2 pr_next = (q0 + g < q1) ? pairs[q0 + g] : make_int2(0, 0);
   for (int q = q0 + g; q < q1; q += 16) {
-    const int2 pr = pairs[q];
+    const int2 pr = pr_next;
+    if (q + 16 < q1) pr_next = pairs[q + 16];
     double av[3][3], bv[3][3];
     load_half(Y + (int64_t)BA_Y_STRIDE * pr.x, qa, av);
     load_half(Y + (int64_t)BA_Y_STRIDE * pr.y, qb, bv);
