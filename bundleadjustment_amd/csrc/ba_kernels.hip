@@ -738,8 +738,11 @@ k_station_pass(StationArgs a) {
   for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
   int nc = 0;
   if (SMODE == SMODE_GATHER_CAM || SMODE == SMODE_CAMNORM || SMODE == SMODE_CAM2) nc = a.cam[a.sta_cam[sta]].nc;
+  // the index of a thread's next observation is requested before the records of this one
+  int e_next = (b0 + (int)threadIdx.x < b1) ? a.sta_list[b0 + threadIdx.x] : 0;
   for (int q = b0 + threadIdx.x; q < b1; q += blockDim.x) {
-    const int e = a.sta_list[q];
+    const int e = e_next;
+    if (q + (int)blockDim.x < b1) e_next = a.sta_list[q + blockDim.x];
     const double2 *rec = reinterpret_cast<const double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
     if (SMODE == SMODE_GATHER || SMODE == SMODE_GATHER_CAM) {
       const double2 v = rec[a.voff];

@@ -149,8 +149,11 @@ k_border_station(StationArgs a, const double *__restrict__ Jt) {
   double acc[NBORDER];
 #pragma unroll
   for (int k = 0; k < NBORDER; ++k) acc[k] = 0.0;
+  // the index of a thread's next observation is requested before the records of this one
+  int e_next = (b0 + (int)threadIdx.x < b1) ? a.sta_list[b0 + threadIdx.x] : 0;
   for (int q = b0 + threadIdx.x; q < b1; q += blockDim.x) {
-    const int e = a.sta_list[q];
+    const int e = e_next;
+    if (q + (int)blockDim.x < b1) e_next = a.sta_list[q + blockDim.x];
     const double2 *rec = reinterpret_cast<const double2 *>(a.rec + (int64_t)BA_REC_STRIDE * e);
     double r0[6], r1[6];
     {
