@@ -1354,6 +1354,7 @@ int cost_local(ba_problem *p, const double *eop, const double *xyz, const CamRec
   ca.N = p->N; ca.obs = p->d_obs; ca.sta = sta_buf; ca.xyz = xyz; ca.obs_pt = p->d_obs_pt; ca.cam = cam; ca.huber_a = p->huber_a; ca.model = p->model;
   ca.emp = p->emp || (cam != p->d_cam && p->emp_c);  // candidates made on the device share the resident set's terms
   ca.apply_loss = apply_loss; ca.res_out = res_out; ca.partial = p->d_partial;
+  ca.one_cam = p->C == 1;
   const int b1 = cost_blocks(p->N), b2 = cost_blocks(3 * (int64_t)p->P);
   launch_cost_obs(s, ca, b1);
   launch_cost_prior(s, p->P, xyz, p->d_pt_prior, p->d_pt_isig, p->d_pt_file, res_out ? res_out + 2 * (size_t)p->N : nullptr,

@@ -82,6 +82,7 @@ struct CostArgs {
   int apply_loss;
   int model;
   int emp;  // as in LinArgs
+  int one_cam;  // every station uses camera 0: its record is read at one address for all lanes
   double *res_out;  // file order, may be null
   double *partial;
 };

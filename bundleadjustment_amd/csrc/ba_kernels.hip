@@ -953,16 +953,28 @@ __global__ void k_invert_blocks(int S, const double *__restrict__ src, const int
 // ------------------------------------------------------------------------------------------
 // cost at a candidate point (residuals only), src/main.cpp:1322-1388 + Huber
 // ------------------------------------------------------------------------------------------
-template <bool GEN, bool EMP>
+template <bool GEN, bool EMP, bool ONECAM>
 __global__ void __launch_bounds__(256)
 k_cost_obs(CostArgs a) {
   __shared__ double lds[8];
   double cost = 0.0;
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < a.N; e += (int64_t)gridDim.x * blockDim.x) {
-    const ObsIn o = load_obs(a.obs, e);
+  // the record and point index of a thread's next observation are requested before this one is evaluated
+  const int64_t first = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+  ObsIn o_next{};
+  int jj_next = 0;
+  if (first < a.N) {
+    o_next = load_obs(a.obs, first);
+    jj_next = a.obs_pt[first];
+  }
+  for (int64_t e = first; e < a.N; e += step) {
+    const ObsIn o = o_next;
+    const int jj = jj_next;
+    if (e + step < a.N) {
+      o_next = load_obs(a.obs, e + step);
+      jj_next = a.obs_pt[e + step];
+    }
     const double *st = a.sta + (int64_t)BA_STA_STRIDE * o.sta;
-    const CamIn cm = load_cam(a.cam, __double2loint(st[20]));
-    const int jj = a.obs_pt[e];
+    const CamIn cm = load_cam(a.cam, ONECAM ? 0 : __double2loint(st[20]));
     const double *x = a.xyz + 3 * (int64_t)jj;
     double r0, r1;
     eval_obs<false, GEN, EMP>(o, st, x[0], x[1], x[2], cm, r0, r1, nullptr, nullptr, nullptr, nullptr, a.model);
@@ -1618,9 +1630,10 @@ int cost_blocks(int64_t n) {
   return b < 1 ? 1 : (b > 4096 ? 4096 : b);
 }
 void launch_cost_obs(hipStream_t s, const CostArgs &a, int blocks) {
-  void (*k)(CostArgs) = a.model ? (a.emp ? k_cost_obs<true, true> : k_cost_obs<true, false>)
-                                : (a.emp ? k_cost_obs<false, true> : k_cost_obs<false, false>);
-  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, s, a);
+  static void (*const tab[2][2][2])(CostArgs) = {
+      {{k_cost_obs<false, false, false>, k_cost_obs<false, false, true>}, {k_cost_obs<false, true, false>, k_cost_obs<false, true, true>}},
+      {{k_cost_obs<true, false, false>, k_cost_obs<true, false, true>}, {k_cost_obs<true, true, false>, k_cost_obs<true, true, true>}}};
+  hipLaunchKernelGGL(tab[a.model ? 1 : 0][a.emp ? 1 : 0][a.one_cam ? 1 : 0], dim3(blocks), dim3(256), 0, s, a);
 }
 void launch_cost_prior(hipStream_t s, int P, const double *xyz, const double *prior, const double *isig, const int *pt_file,
                        double *res_out, double *partial, int blocks) {
