@@ -60,14 +60,77 @@ __global__ void k_station_prep(int S, const double *__restrict__ eop, const doub
 #define LIN_NPART (2 * LIN_NCB + 48)  // per-workgroup partials of k_obs_rows: Jc^T r | Jc^T rhat | upper triangle of Jc^T Jt (36 of 48)
 #define ELIM_STRIDE 40  // per point: u = V^-1 g (3) | L, V^-1 = L L^T (6) | pad (7) | Z = V^-1 B^T (LIN_NCB x 3)
 
+// 64 records of R doubles, one per lane, to contiguous global memory through a wave-private LDS
+// buffer of 64 * (R + 1) doubles: each store instruction then covers 512 contiguous bytes.
+// Only the first nvalid records are written.
+template <int R>
+__device__ __forceinline__ void tile_store(double *buf, const double (&v)[R], double *__restrict__ g, int lane, int nvalid) {
+#pragma unroll
+  for (int k = 0; k < R; ++k) buf[lane * (R + 1) + k] = v[k];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (R % 2 == 0) {
+    // two doubles per lane and store: a pair never straddles records when R is even, and g is 16-byte aligned
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) {
+      const int q = 2 * (i * 64 + lane);
+      const double *src = buf + (q / R) * (R + 1) + q % R;
+      typedef double nt2 __attribute__((ext_vector_type(2)));
+      const nt2 x = {src[0], src[1]};
+      if (q < nvalid * R) __builtin_nontemporal_store(x, reinterpret_cast<nt2 *>(g + q));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int q = i * 64 + lane;
+      const double x = buf[(q / R) * (R + 1) + q % R];
+      if (q < nvalid * R) __builtin_nontemporal_store(x, g + q);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The same for a piece of R doubles at `offset` of records of `stride` doubles (runs of R contiguous doubles per record)
+template <int R>
+__device__ __forceinline__ void tile_store_piece(double *buf, const double (&v)[R], double *__restrict__ g, int stride, int offset, int lane,
+                                                 int nvalid) {
+  static_assert(R % 2 == 0, "pairs of doubles");
+#pragma unroll
+  for (int k = 0; k < R; ++k) buf[lane * (R + 1) + k] = v[k];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int i = 0; i < R / 2; ++i) {
+    const int q = 2 * (i * 64 + lane), rec = q / R, k = q % R;
+    const double *src = buf + rec * (R + 1) + k;
+    if (rec < nvalid) *reinterpret_cast<double2 *>(g + (int64_t)stride * rec + offset + k) = make_double2(src[0], src[1]);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <bool CAM1, bool GEN, bool EMP>
 __global__ void __launch_bounds__(256)
 k_point_elim(LinArgs a) {
   constexpr int NCP = EMP ? BA_NCAMPAR : BA_NCAMPAR_BROWN;  // camera columns that can be in use
   __shared__ double lds[8];
+  __shared__ double tbuf[4][64 * 21];  // per wave: the per-point records leave through it as contiguous runs
   const int jj = blockIdx.x * blockDim.x + threadIdx.x;
   double cost = 0.0;
   int bad = 0;
+  // what the point leaves behind: V^-1 (6), gradient (3), column norms (3), LM diagonal (3), the elimination record
+  double o_vi[6], o_g[3], o_cn[3], o_dg[3], o_el[ELIM_STRIDE];
+#pragma unroll
+  for (int k = 0; k < ELIM_STRIDE; ++k) o_el[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) o_vi[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) o_g[k] = o_cn[k] = o_dg[k] = 0.0;
   if (jj < a.P) {
     const int e0 = a.pt_start[jj], e1 = a.pt_start[jj + 1];
     const double X = a.xyz[3 * (int64_t)jj], Y = a.xyz[3 * (int64_t)jj + 1], Z = a.xyz[3 * (int64_t)jj + 2];
@@ -123,29 +186,26 @@ k_point_elim(LinArgs a) {
     const double j0 = is[0] * s0, j1 = is[1] * s1, j2 = is[2] * s2;
     V[0] += j0 * j0; V[3] += j1 * j1; V[5] += j2 * j2;
     g[0] += j0 * rp0; g[1] += j1 * rp1; g[2] += j2 * rp2;
-    double *cn = a.colnorm_pt + 3 * (int64_t)jj;
-    cn[0] = V[0]; cn[1] = V[3]; cn[2] = V[5];
+    o_cn[0] = V[0]; o_cn[1] = V[3]; o_cn[2] = V[5];
     // Levenberg-Marquardt diagonal [Ceres 1.13 LevenbergMarquardtStrategy::ComputeStep]
-    double *dg = a.diag_pt + 3 * (int64_t)jj;
     double d0, d1, d2;
     if (a.reuse_diag) {
+      const double *dg = a.diag_pt + 3 * (int64_t)jj;
       d0 = dg[0]; d1 = dg[1]; d2 = dg[2];
     } else {
       d0 = fmin(fmax(V[0], a.lm_min), a.lm_max);
       d1 = fmin(fmax(V[3], a.lm_min), a.lm_max);
       d2 = fmin(fmax(V[5], a.lm_min), a.lm_max);
-      dg[0] = d0; dg[1] = d1; dg[2] = d2;
+      o_dg[0] = d0; o_dg[1] = d1; o_dg[2] = d2;
     }
     const double l0 = sqrt(d0 / a.radius), l1 = sqrt(d1 / a.radius), l2 = sqrt(d2 / a.radius);
     V[0] += l0 * l0; V[3] += l1 * l1; V[5] += l2 * l2;
     double Vi[6];
     if (!inv_sym3(V, Vi)) bad = 1;
-    double *vo = a.Vinv + 6 * (int64_t)jj;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) vo[k] = Vi[k];
-    double *go = a.g_pt + 3 * (int64_t)jj;
-    go[0] = g[0]; go[1] = g[1]; go[2] = g[2];
-    double *el = a.elim + (int64_t)ELIM_STRIDE * jj;
+    for (int k = 0; k < 6; ++k) o_vi[k] = Vi[k];
+    o_g[0] = g[0]; o_g[1] = g[1]; o_g[2] = g[2];
+    double (&el)[ELIM_STRIDE] = o_el;
     sym3_mul(Vi, g[0], g[1], g[2], el[0], el[1], el[2]);
     // Vinv = L L^T (lower Cholesky), for the whitened coupling blocks Y = Js^T Jp L
     const double l00 = sqrt(Vi[0]), l10 = Vi[1] / l00, l20 = Vi[2] / l00;
@@ -161,51 +221,42 @@ k_point_elim(LinArgs a) {
           const double cs = cr.scale[pos];
           double z0, z1, z2;
           sym3_mul(Vi, cs * B[p][0], cs * B[p][1], cs * B[p][2], z0, z1, z2);
-          if (pos < LIN_NCB) {
-            el[16 + 3 * pos] = z0;
-            el[17 + 3 * pos] = z1;
-            el[18 + 3 * pos] = z2;
-          }
+          // (run-time position, compile-time index: the record stays in registers)
+#pragma unroll
+          for (int q = 0; q < LIN_NCB; ++q)
+            if (q == pos) {
+              el[16 + 3 * q] = z0;
+              el[17 + 3 * q] = z1;
+              el[18 + 3 * q] = z2;
+            }
           ++pos;
         }
+    }
+  }
+  {
+    // the records of the wave's 64 points, as contiguous runs (a lane storing its own record piece by piece makes 64
+    // separate 8-byte writes of every store instruction)
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t jj0 = (int64_t)blockIdx.x * blockDim.x + 64 * w;
+    const int nvalid = (int)(a.P - jj0 < 64 ? (a.P - jj0 > 0 ? a.P - jj0 : 0) : 64);
+    double *buf = tbuf[w];
+    if (nvalid > 0) {  // uniform over the wave
+      tile_store<6>(buf, o_vi, a.Vinv + 6 * jj0, lane, nvalid);
+      tile_store<3>(buf, o_g, a.g_pt + 3 * jj0, lane, nvalid);
+      tile_store<3>(buf, o_cn, a.colnorm_pt + 3 * jj0, lane, nvalid);
+      if (!a.reuse_diag) tile_store<3>(buf, o_dg, a.diag_pt + 3 * jj0, lane, nvalid);
+      double half[ELIM_STRIDE / 2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int k = 0; k < ELIM_STRIDE / 2; ++k) half[k] = o_el[h * (ELIM_STRIDE / 2) + k];
+        tile_store_piece<ELIM_STRIDE / 2>(buf, half, a.elim + (int64_t)ELIM_STRIDE * jj0, ELIM_STRIDE, h * (ELIM_STRIDE / 2), lane, nvalid);
+      }
     }
   }
   const double t = block_sum(cost, lds);
   if (threadIdx.x == 0) a.cost_partial[blockIdx.x] = t;
   if (bad) atomicOr(a.flags, 1);
-}
-
-// 64 records of R doubles, one per lane, to contiguous global memory through a wave-private LDS
-// buffer of 64 * (R + 1) doubles: each store instruction then covers 512 contiguous bytes.
-// Only the first nvalid records are written.
-template <int R>
-__device__ __forceinline__ void tile_store(double *buf, const double (&v)[R], double *__restrict__ g, int lane, int nvalid) {
-#pragma unroll
-  for (int k = 0; k < R; ++k) buf[lane * (R + 1) + k] = v[k];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  if (R % 2 == 0) {
-    // two doubles per lane and store: a pair never straddles records when R is even, and g is 16-byte aligned
-#pragma unroll
-    for (int i = 0; i < R / 2; ++i) {
-      const int q = 2 * (i * 64 + lane);
-      const double *src = buf + (q / R) * (R + 1) + q % R;
-      typedef double nt2 __attribute__((ext_vector_type(2)));
-      const nt2 x = {src[0], src[1]};
-      if (q < nvalid * R) __builtin_nontemporal_store(x, reinterpret_cast<nt2 *>(g + q));
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-      const int q = i * 64 + lane;
-      const double x = buf[(q / R) * (R + 1) + q % R];
-      if (q < nvalid * R) __builtin_nontemporal_store(x, g + q);
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 #define ROWS_LDS(CAM1) (64 * ((CAM1) ? 25 : 2 * BA_NCAMPAR + 1))
