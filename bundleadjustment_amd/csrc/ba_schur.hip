@@ -44,6 +44,7 @@ k_schur_blocks(int nu, const int *__restrict__ cstart, const int2 *__restrict__ 
   // Workgroups are dealt round-robin over the eight XCDs, each with an L2 of its own.  The blocks are ordered by row,
   // and the blocks of one row read the same station's records: give every XCD one contiguous eighth of the list, so
   // that a record fetched for one block of a row is still in that L2 for the next.
+  __shared__ double lds_y[4][32 * 18];
   const int nwg = gridDim.x, per = (nwg + 7) >> 3;
   const int wg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   const int u = wg * 4 + (threadIdx.x >> 6);
@@ -56,18 +57,59 @@ k_schur_blocks(int nu, const int *__restrict__ cstart, const int2 *__restrict__ 
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) acc[i][j] = 0.0;
-  // the pair after this one is requested before this one's records: one dependent load per step instead of two
-  int2 pr_next = (q0 + g < q1) ? pairs[q0 + g] : make_int2(0, 0);
-  for (int q = q0 + g; q < q1; q += 16) {
-    const int2 pr = pr_next;
-    if (q + 16 < q1) pr_next = pairs[q + 16];
+  // Sixteen pairs per step.  Their 32 records (144 B each) are fetched by the whole wave, nine lanes per record and
+  // 16 bytes per lane -- seven records per load instruction, two cache lines each -- and handed to the lanes that
+  // multiply them through a wave-private LDS buffer.  (A lane fetching its own half record takes five instructions of
+  // which every one touches the lines of all sixteen pairs again: the kernel was bound by the address unit, not by bytes.)
+  double *sy = lds_y[threadIdx.x >> 6];
+  const int slot_rec = lane / 9, piece = lane - 9 * slot_rec;  // lane 63 idles
+  // pair indices two steps ahead, records one step ahead: nothing in a step waits for a load issued in it
+  auto pairs_of = [&](int q) { return (lane < 16 && q + lane < q1) ? pairs[q + lane] : make_int2(-1, -1); };
+  int2 pr_next = pairs_of(q0), pr_next2 = pairs_of(q0 + 16);
+  double2 fetched[5];
+  auto fetch = [&](int2 pr) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int s = 7 * k + slot_rec;  // record slot: 0..15 the pairs' first records, 16..31 their second
+      const int ia = __shfl(pr.x, s & 15, 64), ib = __shfl(pr.y, s & 15, 64);
+      const int rec = s < 16 ? ia : ib;
+      const bool on = lane < 63 && s < 32 && rec >= 0;
+      fetched[k] = on ? *reinterpret_cast<const double2 *>(Y + (int64_t)BA_Y_STRIDE * rec + 2 * piece) : make_double2(0.0, 0.0);
+    }
+  };
+  fetch(pr_next);
+  for (int q = q0; q < q1; q += 16) {
+    // hand over this step's records, request the next step's
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int s = 7 * k + slot_rec;
+      if (lane < 63 && s < 32) *reinterpret_cast<double2 *>(sy + 18 * s + 2 * piece) = fetched[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (q + 16 < q1) {
+      pr_next = pr_next2;
+      fetch(pr_next);
+      pr_next2 = pairs_of(q + 32);
+    }
+    // records of pairs beyond the block's last are zeros: they add nothing
     double av[3][3], bv[3][3];
-    load_half(Y + (int64_t)BA_Y_STRIDE * pr.x, qa, av);
-    load_half(Y + (int64_t)BA_Y_STRIDE * pr.y, qb, bv);
+    const double *pa = sy + 18 * g + 9 * qa, *pb = sy + 18 * (16 + g) + 9 * qb;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        av[i][j] = pa[3 * i + j];
+        bv[i][j] = pb[3 * i + j];
+      }
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc[i][j] += av[i][0] * bv[j][0] + av[i][1] * bv[j][1] + av[i][2] * bv[j][2];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i)
