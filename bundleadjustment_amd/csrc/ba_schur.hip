@@ -122,17 +122,28 @@ k_schur_blocks(int nu, const int *__restrict__ cstart, const int2 *__restrict__ 
       v += __shfl_xor(v, 32, 64);
       acc[i][j] = v;
     }
-  if (g != 0) return;
+  // the block and its mirror image leave as two runs of 288 contiguous bytes (16 bytes per lane) instead of 72
+  // scattered 8-byte writes: assembled in the wave's LDS buffer by the four lanes that hold the quadrants
   const int2 d = dst[u];
+  if (g == 0) {
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int r = 3 * qa + i, c = 3 * qb + j;
-      const double v = -acc[i][j];
-      val[36 * (int64_t)d.x + 6 * r + c] = v;
-      if (d.y >= 0) val[36 * (int64_t)d.y + 6 * c + r] = v;  // the mirrored block (hi, lo)
-    }
+      for (int j = 0; j < 3; ++j) {
+        const int r = 3 * qa + i, c = 3 * qb + j;
+        sy[6 * r + c] = -acc[i][j];
+        sy[36 + 6 * c + r] = -acc[i][j];  // the mirrored block (hi, lo)
+      }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane < 36) {
+    const int which = lane / 18, piece = lane - 18 * which;
+    const int blk = which ? d.y : d.x;
+    if (blk >= 0)
+      *reinterpret_cast<double2 *>(val + 36 * (int64_t)blk + 2 * piece) = *reinterpret_cast<const double2 *>(sy + 36 * which + 2 * piece);
+  }
 }
 
 // diagonal blocks: val[row i, first block] += Sdiag[i]
