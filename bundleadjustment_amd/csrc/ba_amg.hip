@@ -48,7 +48,7 @@ __global__ void k_amg_block_norms(int n, const double *__restrict__ val, double 
 __global__ void __launch_bounds__(256)
 k_amg_build_P(int nP, const int *__restrict__ P_row, const int *__restrict__ P_own, const int *__restrict__ Pa_ptr,
               const int *__restrict__ Pa_idx, const double *__restrict__ A_val, const double *__restrict__ Dinv, double omega,
-              double *__restrict__ P_val) {
+              double *__restrict__ P_val, const int *__restrict__ P_pos, double *__restrict__ Pc_val) {
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (t >= nP) return;
   const int e = lane < 36 ? lane : 0, r = e / 6, c = e % 6;
@@ -74,7 +74,10 @@ k_amg_build_P(int nP, const int *__restrict__ P_row, const int *__restrict__ P_o
 #pragma unroll
   for (int m = 0; m < 6; ++m) acc += D[6 * r + m] * __shfl(sum, 6 * m + c, 64);
   const double own = (P_own[t] && r == c) ? 1.0 : 0.0;
-  if (lane < 36) P_val[36 * (int64_t)t + lane] = own - omega * acc;
+  if (lane < 36) {
+    P_val[36 * (int64_t)t + lane] = own - omega * acc;
+    Pc_val[36 * (int64_t)P_pos[t] + lane] = own - omega * acc;  // the same block where its column's blocks lie side by side
+  }
 }
 
 // out[o] = sum_k op(X[la[k]]) Y[lb[k]], k in [ptr[o], ptr[o+1]) ; op = transpose when TRANS.
@@ -197,7 +200,8 @@ struct AmgTransfer {  // between a fine level and the next coarser one
   int nb, nc;
   const int *P_rowptr, *P_col;
   const double *P_val;
-  const int *Pt_ptr, *Pt_blk, *Pt_row;  // blocks of P by column
+  const double *Pc_val;  // the blocks once more, ordered by column: a restriction reads a column as one contiguous stream
+  const int *Pt_ptr, *Pt_blk, *Pt_row;  // blocks of P by column (Pt_blk: index in P_val of the block at that position of Pc_val)
   // the same lists padded to a fixed width, so that a lane finds its entry without reading a pointer array first
   // (one dependent load fewer per kernel): the first AMG_PT_ELL blocks of column c as (block, row) at Pt_ell[c * AMG_PT_ELL + k],
   // the columns of the first AMG_P_ELL blocks of row i at P_col_ell[i * AMG_P_ELL + k]; -1 = no entry.  Longer lists
@@ -281,7 +285,7 @@ __device__ __forceinline__ void restrict_finish(const AmgTransfer &t, RestrictId
         const int e = g + 8 * (4 * h + u);
         const int blk = __shfl(my_blk, e, 64), row = __shfl(my_row, e, 64);
         const bool on = blk >= 0 && rl;
-        const double2 *P = reinterpret_cast<const double2 *>(t.P_val + 36 * (int64_t)(on ? blk : 0) + 6 * (rl ? r : 0));
+        const double2 *P = reinterpret_cast<const double2 *>(t.Pc_val + 36 * (int64_t)(on ? blk : 0) + 6 * (rl ? r : 0));
 #pragma unroll
         for (int m = 0; m < 3; ++m) pv[u][m] = on ? P[m] : make_double2(0.0, 0.0);
         vv[u] = on ? v[6 * (int64_t)row + r] : 0.0;
@@ -302,7 +306,7 @@ __device__ __forceinline__ void restrict_finish(const AmgTransfer &t, RestrictId
     kb += 64;
     if (kb >= k1) break;  // uniform over the wave
     const int n = min(64, k1 - kb);
-    my_blk = lane < n ? t.Pt_blk[kb + lane] : -1;
+    my_blk = lane < n ? kb + lane : -1;  // position in the column-ordered copy
     my_row = lane < n ? t.Pt_row[kb + lane] : 0;
   }
   double w[16];
@@ -742,6 +746,8 @@ struct Level {  // transfer from level l to level l + 1 and everything the numer
   int *Pt_ptr = nullptr, *Pt_blk = nullptr, *Pt_row = nullptr, *P_col_ell = nullptr;
   int2 *Pt_ell = nullptr;
   int *Ac_rowptr = nullptr, *Ac_col = nullptr, *Ac_diag = nullptr, *used_c = nullptr;
+  double *Pc_val = nullptr;
+  int *P_pos = nullptr;
   double *P_val = nullptr, *AP_val = nullptr, *Ac_val = nullptr, *Dinv_c = nullptr, *rc = nullptr, *y = nullptr;
 };
 
@@ -844,7 +850,7 @@ struct Symbolic {
   std::vector<int> P_rowptr, P_col, P_row, P_own, Pa_ptr, Pa_idx;
   std::vector<int> AP_rowptr, AP_col, AP_ptr, AP_la, AP_lb;
   std::vector<int> Ac_ptr, Ac_la, Ac_lb, Ac_diag;
-  std::vector<int> Pt_ptr, Pt_blk, Pt_row, used_c, P_col_ell;
+  std::vector<int> Pt_ptr, Pt_blk, Pt_row, used_c, P_col_ell, P_pos;
   std::vector<int2> Pt_ell;
   Pattern Ac;
 };
@@ -927,18 +933,20 @@ void symbolic(const Pattern &A, const std::vector<int> &agg, int nc, const std::
   for (int t = 0; t < nP; ++t) sy.Pt_ptr[sy.P_col[t] + 1] += 1;
   for (int c = 0; c < nc; ++c) sy.Pt_ptr[c + 1] += sy.Pt_ptr[c];
   sy.Pt_blk.resize(nP);
+  sy.P_pos.resize(nP);
   sy.Pt_row.resize(nP);
   std::vector<int> fill(sy.Pt_ptr.begin(), sy.Pt_ptr.end() - 1);
   for (int t = 0; t < nP; ++t) {
     const int k = fill[sy.P_col[t]]++;
     sy.Pt_blk[k] = t;
+    sy.P_pos[t] = k;
     sy.Pt_row[k] = sy.P_row[t];
   }
   // the padded copies the kernels of the iteration start from
   sy.Pt_ell.assign((size_t)nc * AMG_PT_ELL, make_int2(-1, 0));
   for (int c = 0; c < nc; ++c)
     for (int k = sy.Pt_ptr[c]; k < sy.Pt_ptr[c + 1] && k - sy.Pt_ptr[c] < AMG_PT_ELL; ++k)
-      sy.Pt_ell[(size_t)c * AMG_PT_ELL + (k - sy.Pt_ptr[c])] = make_int2(sy.Pt_blk[k], sy.Pt_row[k]);
+      sy.Pt_ell[(size_t)c * AMG_PT_ELL + (k - sy.Pt_ptr[c])] = make_int2(k, sy.Pt_row[k]);  // (position in Pc_val, fine row)
   sy.P_col_ell.assign((size_t)nb * AMG_P_ELL, -1);
   for (int i = 0; i < nb; ++i)
     for (int k = sy.P_rowptr[i]; k < sy.P_rowptr[i + 1] && k - sy.P_rowptr[i] < AMG_P_ELL; ++k)
@@ -950,7 +958,7 @@ void symbolic(const Pattern &A, const std::vector<int> &agg, int nc, const std::
 
 void numeric_level(hipStream_t s, const Level &L, unsigned *flags) {
   hipLaunchKernelGGL(k_amg_build_P, dim3(nblk(L.nP, 4)), dim3(256), 0, s, L.nP, L.P_row, L.P_own, L.Pa_ptr, L.Pa_idx, L.A_val,
-                     L.Dinv, L.omega, L.P_val);
+                     L.Dinv, L.omega, L.P_val, L.P_pos, L.Pc_val);
   hipLaunchKernelGGL(k_amg_products<0>, dim3(nblk(L.nAP, 8)), dim3(256), 0, s, L.nAP, L.AP_ptr, L.AP_la, L.AP_lb, L.A_val,
                      L.P_val, L.AP_val);
   hipLaunchKernelGGL(k_amg_products<1>, dim3(nblk(L.nAc, 8)), dim3(256), 0, s, L.nAc, L.Ac_ptr, L.Ac_la, L.Ac_lb, L.P_val,
@@ -1023,7 +1031,8 @@ int amg_build(Amg *a, hipStream_t s, int nb0, const std::vector<int> &rowptr, co
               a->upload(&L.Pt_ptr, sy.Pt_ptr) && a->upload(&L.Pt_blk, sy.Pt_blk) && a->upload(&L.Pt_row, sy.Pt_row) &&
               a->upload(&L.Pt_ell, sy.Pt_ell) && a->upload(&L.P_col_ell, sy.P_col_ell) &&
               a->upload(&L.Ac_rowptr, sy.Ac.rowptr) && a->upload(&L.Ac_col, sy.Ac.col) && a->upload(&L.Ac_diag, sy.Ac_diag) &&
-              a->upload(&L.used_c, sy.used_c) && a->dalloc(&L.P_val, 36 * (size_t)L.nP) &&
+              a->upload(&L.used_c, sy.used_c) && a->upload(&L.P_pos, sy.P_pos) && a->dalloc(&L.P_val, 36 * (size_t)L.nP) &&
+              a->dalloc(&L.Pc_val, 36 * (size_t)L.nP) &&
               a->dalloc(&L.AP_val, 36 * (size_t)L.nAP) && a->dalloc(&L.Ac_val, 36 * (size_t)L.nAc) &&
               a->dalloc(&L.Dinv_c, 36 * (size_t)nc) && a->dalloc(&L.rc, 6 * (size_t)nc) && a->dalloc(&L.y, 6 * (size_t)nc);
     if (!ok) return -1;
@@ -1077,7 +1086,7 @@ static AmgApplyArgs apply_args(const Amg *a) {
   for (int l = 0; l < aa.n_transfers; ++l) {
     const Level &L = a->levels[l];
     AmgTransfer &t = aa.t[l];
-    t.nb = L.nb; t.nc = L.nc; t.P_rowptr = L.P_rowptr; t.P_col = L.P_col; t.P_val = L.P_val; t.Pt_ptr = L.Pt_ptr;
+    t.nb = L.nb; t.nc = L.nc; t.P_rowptr = L.P_rowptr; t.P_col = L.P_col; t.P_val = L.P_val; t.Pc_val = L.Pc_val; t.Pt_ptr = L.Pt_ptr;
     t.Pt_blk = L.Pt_blk; t.Pt_row = L.Pt_row; t.Dinv_c = L.Dinv_c; t.rc = L.rc; t.y = L.y;
     t.Pt_ell = L.Pt_ell; t.P_col_ell = L.P_col_ell;
   }
