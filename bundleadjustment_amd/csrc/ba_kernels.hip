@@ -1270,12 +1270,16 @@ k_xnorm(CandArgs a) {
 
 // camera prior rows: column norms, gradient, rhs, LM diagonal.  One thread; a few values.
 __global__ void k_camera_finish(CamFinishArgs a) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  for (int c = 0; c < a.C; ++c) {
+  // a thread per camera and parameter (a single thread walking them is a chain of dependent memory accesses: 0.17 ms for
+  // four cameras of twelve free parameters)
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.C * BA_NCAMPAR) return;
+  {
+    const int c = t / BA_NCAMPAR, p = t - c * BA_NCAMPAR;
     const CamRec &r = a.cam[c];
-    int pos = 0;
-    for (int p = 0; p < BA_NCAMPAR; ++p) {
-      if (!(r.mask & (1u << p))) continue;
+    {
+      if (!(r.mask & (1u << p))) return;
+      const int pos = __popc(r.mask & ((1u << p) - 1u));  // free parameters before this one
       const int col = r.off + pos;
       double jc = 0.0, rc = 0.0;
       if (p < 3) {
@@ -1297,7 +1301,6 @@ __global__ void k_camera_finish(CamFinishArgs a) {
       a.camdiag[col] = jc * jc + l * l;
       a.g_cam[col] += jc * rc;  // g_cam / b_cam hold the image-row sums on entry
       a.b_cam[col] += jc * rc;
-      ++pos;
     }
   }
 }
@@ -1747,7 +1750,7 @@ void launch_xnorm(hipStream_t s, const CandArgs &a, int blocks) {
   hipLaunchKernelGGL(k_xnorm, dim3(blocks), dim3(256), 0, s, a);
 }
 void launch_camera_finish(hipStream_t s, const CamFinishArgs &a) {
-  hipLaunchKernelGGL(k_camera_finish, dim3(1), dim3(1), 0, s, a);
+  if (a.C > 0) hipLaunchKernelGGL(k_camera_finish, dim3(nblk((int64_t)a.C * BA_NCAMPAR, 64)), dim3(64), 0, s, a);
 }
 void launch_camera_mcc(hipStream_t s, int C, const CamRec *cam, const double *y_cam, double *out, int slot) {
   hipLaunchKernelGGL(k_camera_mcc, dim3(1), dim3(1), 0, s, C, cam, y_cam, out, slot);
