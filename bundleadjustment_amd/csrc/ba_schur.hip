@@ -311,9 +311,19 @@ k_border_general(GenBorderArgs a) {
     double as[6] = {0, 0, 0, 0, 0, 0}, ac[BA_NCAMPAR];
 #pragma unroll
     for (int r = 0; r < BA_NCAMPAR; ++r) ac[r] = 0.0;
-    if (on)
+    if (on) {
+      // observation index two steps ahead, its point index one step ahead: a step waits for its records only, not for
+      // the two index loads that lead to them
+      auto obs_at = [&](int q) { return q < b1 ? a.sta_list[q] : -1; };
+      int e_cur = obs_at(b0 + sub), e_n1 = obs_at(b0 + sub + nsub), e_n2 = obs_at(b0 + sub + 2 * nsub);
+      int jj_cur = e_cur >= 0 ? a.obs_pt[e_cur] : 0, jj_n1 = e_n1 >= 0 ? a.obs_pt[e_n1] : 0;
       for (int q = b0 + sub; q < b1; q += nsub) {
-        const int e = a.sta_list[q], jj = a.obs_pt[e];
+        const int e = e_cur, jj = jj_cur;
+        e_cur = e_n1;
+        jj_cur = jj_n1;
+        e_n1 = e_n2;
+        jj_n1 = e_n1 >= 0 ? a.obs_pt[e_n1] : 0;
+        e_n2 = obs_at(q + 3 * nsub);
         const double *rec = a.rec + (int64_t)BA_REC_STRIDE * e, *jp = a.Jp + 6 * (int64_t)e;
         const double *jc = a.Jc + 2 * (int64_t)a.ncmax * e, *z = a.Zc + ((int64_t)jj * a.ncam + k) * 3;
         double t0 = -(jp[0] * z[0] + jp[1] * z[1] + jp[2] * z[2]), t1 = -(jp[3] * z[0] + jp[4] * z[1] + jp[5] * z[2]);
@@ -327,6 +337,7 @@ k_border_general(GenBorderArgs a) {
         for (int r = 0; r < BA_NCAMPAR; ++r)
           if (r < nc) ac[r] += jc[r] * t0 + jc[a.ncmax + r] * t1;
       }
+    }
     // fold the nsub partial sums of each column through LDS, 7 values at a time
     for (int pass = 0; pass < 4; ++pass) {
       __syncthreads();
