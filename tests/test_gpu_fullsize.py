@@ -142,3 +142,26 @@ def test_cfg3_full_size_variances():
         P.solve_resident(opt)
         ve2, vx2, _, _ = P.covariance()
     assert np.array_equal(ve, ve2) and np.array_equal(vx, vx2)
+
+
+@pytest.mark.timeout(600)
+def test_cfg4_full_size_variances(big):
+    # 10 000 stations: reduced system of order 60 007, two dense matrices of 28.8 GB each, factored and inverted on the
+    # matrix cores (a few seconds).  Properties as for the 5M-observation network, plus one independent route: the camera
+    # parameters' variances from one PCG solve per camera column (ba_covariance_cameras) against the dense inverse.
+    net = big
+    with solver.Problem(net) as P:
+        opt = solver.default_options()
+        opt.max_num_iterations = 3
+        P.set_parameters()
+        P.solve_resident(opt)
+        ve, vx, vi, va = P.covariance()
+        wi, wa = P.covariance_cameras()
+    assert ve.shape == (net.n_sta, 6) and vx.shape == (net.n_pts, 3)
+    assert np.all(np.isfinite(ve)) and np.all(ve > 0.0)
+    assert np.all(np.isfinite(vx)) and np.all(vx > 0.0)
+    assert np.all(vx <= net.pt_sigma ** 2 * (1.0 + 1e-9))
+    free = [2, 3, 5, 6]  # k1 k2 p1 p2
+    assert np.all(vi > 0.0) and np.all(va[0, free] > 0.0) and np.all(np.delete(va[0], free) == 0.0)
+    np.testing.assert_allclose(wi, vi, rtol=1e-6)
+    np.testing.assert_allclose(wa, va, rtol=1e-6)
