@@ -87,7 +87,6 @@ struct GemmArgs {
   double *T;        // inverse: work row of tiles, CB x ld
   int n, ld, k0, kw;  // current panel: first column, width
   int ib;             // inverse: current block row
-  int part;           // trailing update: 0 all tiles, 1 the first block column only, 2 all but the first block column
 };
 
 // tile (ti, tj), tj <= ti, of a lower triangle from a linear index
@@ -124,16 +123,7 @@ k_gemm_nt(GemmArgs g) {
     cmax = g.kw;
   } else if (MODE == GEMM_SYRK) {
     int ti, tj;
-    if (g.part == 1) {
-      ti = blockIdx.x;
-      tj = 0;
-    } else {
-      tri_tile(blockIdx.x, ti, tj);
-      if (g.part == 2) {
-        ++ti;
-        ++tj;
-      }
-    }
+    tri_tile(blockIdx.x, ti, tj);
     const int t0 = g.k0 + g.kw;
     r0 = t0 + CB * ti;
     c0 = t0 + CB * tj;
@@ -504,80 +494,104 @@ k_chol_diag(double *__restrict__ A, int n, int ld, int k0, double *__restrict__ 
 // ------------------------------------------------------------------------------------------------------------------
 // triangular solves with the factor and the inverted diagonal blocks, one launch per panel
 // ------------------------------------------------------------------------------------------------------------------
+// Both kernels are chains of memory round trips, not of bytes: a workgroup is 2 * CB threads, two per row (column), each
+// taking half of the summation index with all its loads requested at once; the halves meet in LDS.  The inverted
+// diagonal blocks W hold zeros above the diagonal, so the products with them need no masks.
+//
 // forward step k: workgroup i (block row k + 1 + i) subtracts L[i, k] x_k from its part of b; the workgroup of block row
 // k + 1 then finishes x_{k+1} = W_{k+1} b_{k+1}.  first != 0: only x_0 = W_0 b_0.
-__global__ void __launch_bounds__(CB)
+__global__ void __launch_bounds__(2 * CB)
 k_chol_forward(const double *__restrict__ L, int n, int ld, const double *__restrict__ W, double *__restrict__ b, int k, int first) {
-  __shared__ double xs[CB];
-  const int t = threadIdx.x;
+  __shared__ double xs[CB], hs[CB];
+  const int t = threadIdx.x & (CB - 1), h = threadIdx.x / CB;
   const int ib = first ? 0 : k + 1 + blockIdx.x;
   const int row = CB * ib + t;
-  double v = row < n ? b[row] : 0.0;
+  double v = (row < n && h == 0) ? b[row] : 0.0;
   if (!first) {
     const int k0 = CB * k;
-    xs[t] = b[k0 + t];  // block k is complete (k0 + t < n as block k is not the last one)
+    if (h == 0) xs[t] = b[k0 + t];  // block k is complete (k0 + t < n as block k is not the last one)
+    const double2 *lr = reinterpret_cast<const double2 *>(L + (int64_t)min(row, n - 1) * ld + k0 + (CB / 2) * h);
+    double2 l[CB / 4];
+#pragma unroll
+    for (int c = 0; c < CB / 4; ++c) l[c] = lr[c];
     __syncthreads();
-    if (row < n) {
-      const double2 *lr = reinterpret_cast<const double2 *>(L + (int64_t)row * ld + k0);
-      double s = 0.0;
-#pragma unroll 8
-      for (int c = 0; c < CB / 2; ++c) {
-        const double2 l = lr[c];
-        s += l.x * xs[2 * c] + l.y * xs[2 * c + 1];
-      }
-      v -= s;
-    }
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < CB / 4; ++c) s += l[c].x * xs[(CB / 2) * h + 2 * c] + l[c].y * xs[(CB / 2) * h + 2 * c + 1];
+    if (h == 1) hs[t] = s;
+    __syncthreads();
+    if (h == 0) v = row < n ? v - (s + hs[t]) : 0.0;
     if (blockIdx.x != 0) {
-      if (row < n) b[row] = v;
+      if (row < n && h == 0) b[row] = v;
       return;
     }
     __syncthreads();
   }
   // x = W_ib v (lower triangular, CB x CB)
-  xs[t] = v;
+  const double2 *wr = reinterpret_cast<const double2 *>(W + (int64_t)ib * CB * CB + (int64_t)t * CB + (CB / 2) * h);
+  double2 wv[CB / 4];
+#pragma unroll
+  for (int c = 0; c < CB / 4; ++c) wv[c] = wr[c];
+  if (h == 0) xs[t] = v;
   __syncthreads();
-  const double *wr = W + (int64_t)ib * CB * CB + (int64_t)t * CB;
   double s = 0.0;
-  for (int c = 0; c <= t; ++c) s += wr[c] * xs[c];
-  if (row < n) b[row] = s;
+#pragma unroll
+  for (int c = 0; c < CB / 4; ++c) s += wv[c].x * xs[(CB / 2) * h + 2 * c] + wv[c].y * xs[(CB / 2) * h + 2 * c + 1];
+  if (h == 1) hs[t] = s;
+  __syncthreads();
+  if (h == 0 && row < n) b[row] = s + hs[t];
 }
 
 // backward step i (from the last block row up): workgroup k < i subtracts L[i, k]^T x_i from its part of b; the workgroup
 // of block i - 1 then finishes x_{i-1} = W_{i-1}^T b_{i-1}.  first != 0: only x of the last block.
-__global__ void __launch_bounds__(CB)
+__global__ void __launch_bounds__(2 * CB)
 k_chol_backward(const double *__restrict__ L, int n, int ld, const double *__restrict__ W, double *__restrict__ b, int i, int first) {
-  __shared__ double xs[CB];
-  const int t = threadIdx.x;
+  __shared__ double xs[CB], hs[CB];
+  const int t = threadIdx.x & (CB - 1), h = threadIdx.x / CB;
   const int kb = first ? i : (int)blockIdx.x;
   const int col = CB * kb + t;
-  double v = col < n ? b[col] : 0.0;
+  double v = (col < n && h == 0) ? b[col] : 0.0;
   if (!first) {
     const int i0 = CB * i, iw = min(CB, n - i0);
-    xs[t] = t < iw ? b[i0 + t] : 0.0;
-    __syncthreads();
-    // consecutive threads, consecutive columns; eight rows requested at a time (rows beyond the block: a valid row, times 0)
-    double s = 0.0;
+    if (h == 0) xs[t] = t < iw ? b[i0 + t] : 0.0;
+    // consecutive threads, consecutive columns; rows beyond the block: a valid row, times 0
     const double *lc = L + (int64_t)i0 * ld + col;
-    for (int r0 = 0; r0 < iw; r0 += 8) {
-      double l[8];
+    double s = 0.0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) l[u] = lc[(int64_t)min(r0 + u, iw - 1) * ld];
+    for (int r0 = 0; r0 < CB / 2; r0 += 32) {
+      double l[32];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s += l[u] * xs[r0 + u];
+      for (int u = 0; u < 32; ++u) l[u] = lc[(int64_t)min((CB / 2) * h + r0 + u, iw - 1) * ld];
+      if (r0 == 0) __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 32; ++u) s += l[u] * xs[(CB / 2) * h + r0 + u];
     }
-    v -= s;
+    if (h == 1) hs[t] = s;
+    __syncthreads();
+    if (h == 0) v -= s + hs[t];
     if (kb != i - 1) {
-      b[col] = v;
+      if (h == 0) b[col] = v;
       return;
     }
     __syncthreads();
   }
-  xs[t] = v;
-  __syncthreads();
-  const double *wk = W + (int64_t)kb * CB * CB;
+  const double *wk = W + (int64_t)kb * CB * CB + t;
   double s = 0.0;
-  for (int r = t; r < CB; ++r) s += wk[(int64_t)r * CB + t] * xs[r];  // W^T
-  if (col < n) b[col] = s;
+#pragma unroll
+  for (int r0 = 0; r0 < CB / 2; r0 += 32) {
+    double w[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) w[u] = wk[(int64_t)((CB / 2) * h + r0 + u) * CB];  // W^T
+    if (r0 == 0) {
+      if (h == 0) xs[t] = v;
+      __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 32; ++u) s += w[u] * xs[(CB / 2) * h + r0 + u];
+  }
+  if (h == 1) hs[t] = s;
+  __syncthreads();
+  if (h == 0 && col < n) b[col] = s + hs[t];
 }
 
 // U[k-block diagonal] = W_k^T (upper triangular), the rest of U zero
@@ -604,23 +618,8 @@ void launch_cholesky_blocked(hipStream_t s, double *A, int n, int ld, double *W,
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  // Look-ahead: the diagonal block of panel k + 1 (one workgroup, a chain of 128 pivots) only needs the first block
-  // column of the trailing update of panel k, so the rest of that update runs on a side stream beside it.
-  static thread_local hipStream_t side = nullptr;
-  static thread_local hipEvent_t ev_panel = nullptr, ev_rest = nullptr;
-  const int nb = (n + CB - 1) / CB;
-  bool ahead = nb >= 6;
-  if (ahead && !side) {
-    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_panel, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ev_rest, hipEventDisableTiming) != hipSuccess) {
-      side = nullptr;
-      (void)hipGetLastError();
-    }
-  }
-  if (!side) ahead = false;
   GemmArgs g{};
   g.A = A; g.n = n; g.ld = ld;
-  bool rest_pending = false;
   for (int k0 = 0, kb = 0; k0 < n; k0 += CB, ++kb) {
     const int kw = (n - k0 < CB) ? n - k0 : CB;
     double *Wk = W + (size_t)kb * CB * CB;
@@ -629,35 +628,20 @@ void launch_cholesky_blocked(hipStream_t s, double *A, int n, int ld, double *W,
     if (rem <= 0) break;
     g.W = Wk; g.k0 = k0; g.kw = kw;
     const int T = (rem + CB - 1) / CB;
-    g.part = 0;
     hipLaunchKernelGGL(k_gemm_nt<GEMM_TRSM>, dim3(T), dim3(256), 0, s, g);
-    if (!ahead || T < 2) {
-      if (rest_pending) {
-        (void)hipStreamWaitEvent(s, ev_rest, 0);
-        rest_pending = false;
-      }
-      hipLaunchKernelGGL(k_gemm_nt<GEMM_SYRK>, dim3(T * (T + 1) / 2), dim3(256), 0, s, g);
-      continue;
-    }
-    (void)hipEventRecord(ev_panel, s);  // the panel is final: the side stream may read it
-    if (rest_pending) (void)hipStreamWaitEvent(s, ev_rest, 0);  // the first block column also takes the previous panel's update
-    g.part = 1;
-    hipLaunchKernelGGL(k_gemm_nt<GEMM_SYRK>, dim3(T), dim3(256), 0, s, g);
-    (void)hipStreamWaitEvent(side, ev_panel, 0);
-    g.part = 2;
-    hipLaunchKernelGGL(k_gemm_nt<GEMM_SYRK>, dim3((T - 1) * T / 2), dim3(256), 0, side, g);
-    (void)hipEventRecord(ev_rest, side);
-    rest_pending = true;
+    // One launch for the whole trailing update.  Running its first block column ahead of the rest (so that the next
+    // diagonal block could start early, the rest on a second stream) gained nothing at order 8190 and cost 0.1 ms of
+    // event hand-overs at order 1248.
+    hipLaunchKernelGGL(k_gemm_nt<GEMM_SYRK>, dim3(T * (T + 1) / 2), dim3(256), 0, s, g);
   }
-  if (rest_pending) (void)hipStreamWaitEvent(s, ev_rest, 0);
 }
 
 void launch_chol_solve_blocked(hipStream_t s, const double *L, int n, int ld, const double *W, double *b) {
   const int nb = (n + CB - 1) / CB;
-  hipLaunchKernelGGL(k_chol_forward, dim3(1), dim3(CB), 0, s, L, n, ld, W, b, 0, 1);
-  for (int k = 0; k + 1 < nb; ++k) hipLaunchKernelGGL(k_chol_forward, dim3(nb - 1 - k), dim3(CB), 0, s, L, n, ld, W, b, k, 0);
-  hipLaunchKernelGGL(k_chol_backward, dim3(1), dim3(CB), 0, s, L, n, ld, W, b, nb - 1, 1);
-  for (int i = nb - 1; i >= 1; --i) hipLaunchKernelGGL(k_chol_backward, dim3(i), dim3(CB), 0, s, L, n, ld, W, b, i, 0);
+  hipLaunchKernelGGL(k_chol_forward, dim3(1), dim3(2 * CB), 0, s, L, n, ld, W, b, 0, 1);
+  for (int k = 0; k + 1 < nb; ++k) hipLaunchKernelGGL(k_chol_forward, dim3(nb - 1 - k), dim3(2 * CB), 0, s, L, n, ld, W, b, k, 0);
+  hipLaunchKernelGGL(k_chol_backward, dim3(1), dim3(2 * CB), 0, s, L, n, ld, W, b, nb - 1, 1);
+  for (int i = nb - 1; i >= 1; --i) hipLaunchKernelGGL(k_chol_backward, dim3(i), dim3(2 * CB), 0, s, L, n, ld, W, b, i, 0);
 }
 
 // A: the factor on entry, (L L^T)^-1 as a full symmetric matrix on return.  U: n x ld work matrix, T: CB x ld work.
