@@ -107,6 +107,17 @@ def test_full_size_properties(name):
         assert sm["num_effective_parameters_reduced"] == 6 * S + 3 * Pn + free
         eop, xyz, iop, ap = P.get_parameters()
         assert np.sqrt(np.mean((xyz - t["xyz"]) ** 2)) < np.sqrt(np.mean((net.xyz - t["xyz"]) ** 2))
+        if name == "cfg5":
+            # variances at this size: the dense inverse of the reduced system (order 300 007, two matrices of 720 GB) is
+            # refused with a message; the camera parameters' variances come from one PCG solve per camera column
+            with pytest.raises(solver.BaError) as e:
+                P.covariance()
+            assert e.value.code == capi.ERR_UNSUPPORTED
+            vi, va = P.covariance_cameras()
+            k = [2, 3, 5, 6]  # k1 k2 p1 p2
+            assert np.all(np.isfinite(vi)) and np.all(vi > 0.0) and np.all(va[0, k] > 0.0) and np.all(np.delete(va[0], k) == 0.0)
+            # five times the observations of the 10M network, same geometry: the camera is known better, not worse
+            assert np.all(np.sqrt(vi) < 1e-1)
         if name == "cfg3":
             assert np.array_equal(iop, net.iop) and np.array_equal(ap, net.ap)  # constant blocks stay
             nr, nc, rws, cols = P.sparsity()
