@@ -357,6 +357,15 @@ def main():
     if per_rank is not None:
         out["per_rank"] = per_rank
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the CPU legs take a minute or two and print nothing: a line on stderr every 30 s shows a watcher that the run is alive
+        import threading
+        cpu_done = threading.Event()
+
+        def heartbeat():
+            t_cpu = time.perf_counter()
+            while not cpu_done.wait(30.0):
+                print(f"bench.py: CPU baseline running ({time.perf_counter() - t_cpu:.0f} s)", file=sys.stderr, flush=True)
+        threading.Thread(target=heartbeat, daemon=True).start()
         n_cpu, it_s, obs_s, cg = cpu_baseline(args.config, args.cpu_scale * args.scale, args.pcg_rtol)
         out["cpu_baseline"] = {
             "value": it_s * n_cpu / full.n_obs, "unit": "iter/s", "cores": 1, "kind": "port",
@@ -379,6 +388,7 @@ def main():
         except (RuntimeError, OSError, MemoryError) as e:
             out["cpu_baseline_all_cores"] = out.get("cpu_baseline_all_cores") or {"value": None, "error": str(e)}
             out["cpu_baseline_all_cores_full_size"] = {"value": None, "error": str(e)}
+        cpu_done.set()
     if rank == 0:
         print(json.dumps(out), flush=True)
     P.close()
