@@ -1149,14 +1149,20 @@ int amg_build(Amg *a, hipStream_t s, int nb0, const std::vector<int> &rowptr, co
     used = sy.used_c;
     dA_rowptr = L.Ac_rowptr; dA_col = L.Ac_col; dA_val = L.Ac_val; dDinv = L.Dinv_c;
   }
-  // Three levels: both coarse levels are reached from the finest one (F = P0 P1), which takes the two launches between
-  // the levels out of every PCG iteration.  BA_AMG_FLAT=0 keeps the level-by-level application.
+  // BA_AMG_FLAT=1, three levels: both coarse levels are reached from the finest one (F = P0 P1), which takes the two
+  // launches between the levels out of every PCG iteration -- three launches instead of five.  Same iterates to rounding,
+  // but slower as it stands, hence off by default: at 10 000 stations (levels of 10 000 / 1268 / 176 blocks) F has 107 337
+  // blocks where P1 has 9488, and a column of F has 610 of them for the one wave that restricts it -- 60 us per iteration
+  // against 43 (second kernel 29 instead of 9 us, last kernel 16 instead of 9).
   {
     const char *e = std::getenv("BA_AMG_FLAT");
-    if (a->levels.size() == 2 && !(e && std::atoi(e) == 0)) {
+    if (a->levels.size() == 2 && e && std::atoi(e) == 1) {
       if (!build_flat(a, hP_rowptr[0], hP_col[0], hP_rowptr[1], hP_col[1])) return -1;
       a->flat = true;
       numeric_flat(s, a);
+      if (std::getenv("BA_AMG_VERBOSE"))
+        fprintf(stderr, "amg: levels %d / %d / %d blocks, P0 %d, P1 %d, F %d blocks\n", a->levels[0].nb, a->levels[0].nc, a->levels[1].nc,
+                a->levels[0].nP, a->levels[1].nP, a->nF);
     }
   }
   a->n_part = 0;

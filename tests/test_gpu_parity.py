@@ -167,6 +167,20 @@ def test_multilevel_preconditioner_same_answer_fewer_iterations():
     assert g_ml[4]["total_linear_iterations"] < 0.6 * g_bj[4]["total_linear_iterations"]
 
 
+def test_flattened_hierarchy_gives_the_same_iterates(monkeypatch):
+    # BA_AMG_FLAT=1: the third level is reached straight from the finest one (F = P0 P1, three launches per PCG iteration
+    # instead of five); the same preconditioner up to rounding, so the same answer in the same number of iterations
+    net = host.synth_config("cfg4", scale=0.03).net
+    opt = options(capi.SOLVER_PCG_SCHUR, preconditioner=0)
+    g = gpu_solve(net, opt)
+    monkeypatch.setenv("BA_AMG_FLAT", "1")
+    f = gpu_solve(net, opt)
+    monkeypatch.delenv("BA_AMG_FLAT")
+    o = po.solve(net, opt, po.SCHUR_DENSE)
+    assert_solve_parity(f, o)
+    assert abs(f[4]["total_linear_iterations"] - g[4]["total_linear_iterations"]) <= 2 * g[4]["num_iterations"]
+
+
 def test_multilevel_preconditioner_several_cameras():
     # more than one camera: the camera border comes from the general (probing) path
     net = host.synth(n_cam=3, n_sta=90, n_pts=6000, rays_per_point=6, ap_free_mask=host.AP_K1K2P1P2, seed=5).net
