@@ -18,6 +18,8 @@
 // (P_l, A_l P_l, A_{l+1}, D_{l+1}^-1) is recomputed on the device after every linearisation.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -881,6 +883,8 @@ struct Symbolic {
 
 void symbolic(const Pattern &A, const std::vector<int> &agg, int nc, const std::vector<int> &used, Symbolic &sy) {
   const int nb = A.nb;
+  auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tt0 = now();
   // ---- P: one block per (row, aggregate seen in the row)
   sy.P_rowptr.assign(nb + 1, 0);
   sy.Pa_ptr.assign(1, 0);
@@ -902,56 +906,125 @@ void symbolic(const Pattern &A, const std::vector<int> &agg, int nc, const std::
     sy.P_rowptr[i + 1] = (int)sy.P_col.size();
   }
   const int nP = (int)sy.P_col.size();
-  // ---- A P: row i = union of the rows of P over the neighbours of i
+  const double tt1 = now();
+  // ---- A P: row i = union of the rows of P over the neighbours of i; per block (i, c) the products (b, t) in the order
+  //      they are met (b, then t, ascending).  Two passes per row with a marker per coarse column -- count, then place --
+  //      instead of sorting the row's triples.
   sy.AP_rowptr.assign(nb + 1, 0);
   sy.AP_ptr.assign(1, 0);
-  std::vector<std::pair<int, std::pair<int, int>>> tri;
-  for (int i = 0; i < nb; ++i) {
-    tri.clear();
-    for (int b = A.rowptr[i]; b < A.rowptr[i + 1]; ++b) {
-      const int j = A.col[b];
-      for (int t = sy.P_rowptr[j]; t < sy.P_rowptr[j + 1]; ++t) tri.push_back({sy.P_col[t], {b, t}});
-    }
-    std::sort(tri.begin(), tri.end());
-    for (size_t k = 0; k < tri.size(); ++k) {
-      if (k == 0 || tri[k].first != tri[k - 1].first) {
-        if (k) sy.AP_ptr.push_back((int)sy.AP_la.size());
-        sy.AP_col.push_back(tri[k].first);
+  {
+    std::vector<int> slot(nc, -1), cols, cnt, order, pos;
+    for (int i = 0; i < nb; ++i) {
+      cols.clear();
+      cnt.clear();
+      for (int b = A.rowptr[i]; b < A.rowptr[i + 1]; ++b) {
+        const int j = A.col[b];
+        for (int t = sy.P_rowptr[j]; t < sy.P_rowptr[j + 1]; ++t) {
+          const int c = sy.P_col[t];
+          if (slot[c] < 0) {
+            slot[c] = (int)cols.size();
+            cols.push_back(c);
+            cnt.push_back(0);
+          }
+          cnt[slot[c]] += 1;
+        }
       }
-      sy.AP_la.push_back(tri[k].second.first);
-      sy.AP_lb.push_back(tri[k].second.second);
+      const int m = (int)cols.size();
+      order.resize(m);
+      for (int k = 0; k < m; ++k) order[k] = k;
+      std::sort(order.begin(), order.end(), [&](int x, int y) { return cols[x] < cols[y]; });
+      pos.resize(m);
+      int64_t base = (int64_t)sy.AP_la.size();
+      for (int k = 0; k < m; ++k) {
+        const int q = order[k];
+        pos[q] = (int)base;
+        base += cnt[q];
+        sy.AP_col.push_back(cols[q]);
+        sy.AP_ptr.push_back((int)base);
+      }
+      sy.AP_la.resize((size_t)base);
+      sy.AP_lb.resize((size_t)base);
+      for (int b = A.rowptr[i]; b < A.rowptr[i + 1]; ++b) {
+        const int j = A.col[b];
+        for (int t = sy.P_rowptr[j]; t < sy.P_rowptr[j + 1]; ++t) {
+          const int q = slot[sy.P_col[t]];
+          sy.AP_la[pos[q]] = b;
+          sy.AP_lb[pos[q]] = t;
+          pos[q] += 1;
+        }
+      }
+      for (int k = 0; k < m; ++k) slot[cols[k]] = -1;
+      sy.AP_rowptr[i + 1] = (int)sy.AP_col.size();
     }
-    if (!tri.empty()) sy.AP_ptr.push_back((int)sy.AP_la.size());
-    sy.AP_rowptr[i + 1] = (int)sy.AP_col.size();
   }
-  // ---- A_c = P^T (A P)
+  const double tt2 = now();
+  // ---- A_c = P^T (A P): the products (t, u) of block (c, d) = (P_col[t], AP_col[u]) over the fine rows, ordered by c,
+  //      then d, then as generated: a counting sort by c, then count-and-place by d inside each coarse row (sorting the
+  //      whole list and the rows' triples was 50 of the 65 ms this function took at 10 000 stations).
   struct Ent {
-    int64_t key;
-    int t, u;
+    int d, t, u;
   };
-  std::vector<Ent> ent;
+  std::vector<int64_t> start(nc + 1, 0);
   for (int i = 0; i < nb; ++i)
-    for (int t = sy.P_rowptr[i]; t < sy.P_rowptr[i + 1]; ++t)
-      for (int u = sy.AP_rowptr[i]; u < sy.AP_rowptr[i + 1]; ++u)
-        ent.push_back({(int64_t)sy.P_col[t] * nc + sy.AP_col[u], t, u});
-  std::stable_sort(ent.begin(), ent.end(), [](const Ent &a, const Ent &b) { return a.key < b.key; });
+    for (int t = sy.P_rowptr[i]; t < sy.P_rowptr[i + 1]; ++t) start[sy.P_col[t] + 1] += sy.AP_rowptr[i + 1] - sy.AP_rowptr[i];
+  for (int c = 0; c < nc; ++c) start[c + 1] += start[c];
+  std::vector<Ent> ent((size_t)start[nc]);
+  {
+    std::vector<int64_t> pos(start.begin(), start.end() - 1);
+    for (int i = 0; i < nb; ++i)
+      for (int t = sy.P_rowptr[i]; t < sy.P_rowptr[i + 1]; ++t) {
+        int64_t &q = pos[sy.P_col[t]];
+        for (int u = sy.AP_rowptr[i]; u < sy.AP_rowptr[i + 1]; ++u) ent[(size_t)q++] = {sy.AP_col[u], t, u};
+      }
+  }
   sy.Ac.nb = nc;
   sy.Ac.rowptr.assign(nc + 1, 0);
   sy.Ac_ptr.assign(1, 0);
   sy.Ac_diag.assign(nc, 0);
-  for (size_t k = 0; k < ent.size(); ++k) {
-    if (k == 0 || ent[k].key != ent[k - 1].key) {
-      if (k) sy.Ac_ptr.push_back((int)sy.Ac_la.size());
-      const int c = (int)(ent[k].key / nc), d = (int)(ent[k].key % nc);
-      if (c == d) sy.Ac_diag[c] = (int)sy.Ac.col.size();
-      sy.Ac.col.push_back(d);
-      sy.Ac.rowptr[c + 1] += 1;
+  {
+    // inside a coarse row: count per column d, then place (the entries of a column keep their order)
+    std::vector<int> slot(nc, -1), cols, cnt, order, pos;
+    for (int c = 0; c < nc; ++c) {
+      cols.clear();
+      cnt.clear();
+      for (int64_t k = start[c]; k < start[c + 1]; ++k) {
+        const int d = ent[(size_t)k].d;
+        if (slot[d] < 0) {
+          slot[d] = (int)cols.size();
+          cols.push_back(d);
+          cnt.push_back(0);
+        }
+        cnt[slot[d]] += 1;
+      }
+      const int m = (int)cols.size();
+      order.resize(m);
+      for (int k = 0; k < m; ++k) order[k] = k;
+      std::sort(order.begin(), order.end(), [&](int x, int y) { return cols[x] < cols[y]; });
+      pos.resize(m);
+      int64_t base = (int64_t)sy.Ac_la.size();
+      for (int k = 0; k < m; ++k) {
+        const int q = order[k];
+        if (base > 0) sy.Ac_ptr.push_back((int)base);
+        pos[q] = (int)base;
+        base += cnt[q];
+        if (cols[q] == c) sy.Ac_diag[c] = (int)sy.Ac.col.size();
+        sy.Ac.col.push_back(cols[q]);
+        sy.Ac.rowptr[c + 1] += 1;
+      }
+      sy.Ac_la.resize((size_t)base);
+      sy.Ac_lb.resize((size_t)base);
+      for (int64_t k = start[c]; k < start[c + 1]; ++k) {
+        const int q = slot[ent[(size_t)k].d];
+        sy.Ac_la[pos[q]] = ent[(size_t)k].t;
+        sy.Ac_lb[pos[q]] = ent[(size_t)k].u;
+        pos[q] += 1;
+      }
+      for (int k = 0; k < m; ++k) slot[cols[k]] = -1;
     }
-    sy.Ac_la.push_back(ent[k].t);
-    sy.Ac_lb.push_back(ent[k].u);
   }
   if (!ent.empty()) sy.Ac_ptr.push_back((int)sy.Ac_la.size());
   for (int c = 0; c < nc; ++c) sy.Ac.rowptr[c + 1] += sy.Ac.rowptr[c];
+  const double tt3 = now();
   // ---- P by column (restriction), coarse "has observations" flags
   sy.Pt_ptr.assign(nc + 1, 0);
   for (int t = 0; t < nP; ++t) sy.Pt_ptr[sy.P_col[t] + 1] += 1;
@@ -978,6 +1051,9 @@ void symbolic(const Pattern &A, const std::vector<int> &agg, int nc, const std::
   sy.used_c.assign(nc, 0);
   for (int i = 0; i < nb; ++i)
     if (used[i]) sy.used_c[agg[i]] = 1;
+  if (std::getenv("BA_AMG_VERBOSE"))
+    fprintf(stderr, "amg: lists of P %.1f ms, of A P %.1f (%zu products), of P^T A P %.1f (%zu products), by column %.1f\n", tt1 - tt0, tt2 - tt1,
+            sy.AP_la.size(), tt3 - tt2, sy.Ac_la.size(), now() - tt3);
 }
 
 void numeric_level(hipStream_t s, const Level &L, unsigned *flags) {
@@ -1087,7 +1163,10 @@ int amg_build(Amg *a, hipStream_t s, int nb0, const std::vector<int> &rowptr, co
   int max_levels = AMG_MAX_LEVELS;
   if (const char *e = std::getenv("BA_AMG_LEVELS")) max_levels = std::min(std::max(std::atoi(e), 1), (int)AMG_MAX_LEVELS);
   std::vector<std::vector<int>> hP_rowptr, hP_col;
+  const bool verbose = std::getenv("BA_AMG_VERBOSE") != nullptr;
+  auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (int l = 0; l < max_levels - 1 && A.nb >= 2 * AMG_MIN_BLOCKS; ++l) {
+    const double t_start = now();
     const int nA = (int)A.col.size();
     std::vector<double> fro(nA);
     if ((size_t)nA > tmp_cap) {
@@ -1102,10 +1181,13 @@ int amg_build(Amg *a, hipStream_t s, int nb0, const std::vector<int> &rowptr, co
     }
     std::vector<int> agg;
     int nc = 0;
+    const double t_norms = now();
     aggregate(A, fro, theta, agg, nc);
+    const double t_agg = now();
     if (nc < AMG_MIN_BLOCKS || (l >= 2 && nc < AMG_DEEP_BLOCKS) || (int64_t)nc * 10 > (int64_t)A.nb * 9) break;  // no useful coarsening left
     Symbolic sy;
     symbolic(A, agg, nc, used, sy);
+    const double t_sym = now();
     Level L;
     L.nb = A.nb; L.nc = nc; L.nA = nA; L.nP = (int)sy.P_col.size(); L.nAP = (int)sy.AP_col.size(); L.nAc = (int)sy.Ac.col.size();
     L.A_rowptr = dA_rowptr; L.A_col = dA_col; L.A_val = dA_val; L.Dinv = dDinv;
@@ -1121,6 +1203,7 @@ int amg_build(Amg *a, hipStream_t s, int nb0, const std::vector<int> &rowptr, co
               a->dalloc(&L.AP_val, 36 * (size_t)L.nAP) && a->dalloc(&L.Ac_val, 36 * (size_t)L.nAc) &&
               a->dalloc(&L.Dinv_c, 36 * (size_t)nc) && a->dalloc(&L.rc, 6 * (size_t)nc) && a->dalloc(&L.y, 6 * (size_t)nc);
     if (!ok) return -1;
+    const double t_up = now();
     // damping factor from the spectral radius of Dinv A (power iteration, fixed start vector)
     {
       const int n = 6 * A.nb, steps = 20;
@@ -1142,6 +1225,9 @@ int amg_build(Amg *a, hipStream_t s, int nb0, const std::vector<int> &rowptr, co
       L.omega = 4.0 / (3.0 * rho);
     }
     numeric_level(s, L, a->d_flags);
+    if (verbose)
+      fprintf(stderr, "amg: level %d (%d -> %d blocks): block norms %.1f ms, aggregation %.1f, lists %.1f, uploads %.1f, damping factor %.1f\n", l,
+              A.nb, nc, t_norms - t_start, t_agg - t_norms, t_sym - t_agg, t_up - t_sym, now() - t_up);
     a->levels.push_back(L);
     hP_rowptr.push_back(sy.P_rowptr);
     hP_col.push_back(sy.P_col);
