@@ -3,7 +3,8 @@
     python -m bundleadjustment_amd.build [--force]
 
 libba_host.so : g++   bundleadjustment_amd/host/ba_host.cpp
-libba_gpu.so  : hipcc --offload-arch=gfx950 bundleadjustment_amd/csrc/*.hip  (cross-compiles without a GPU)
+libba_gpu.so  : hipcc --offload-arch=gfx950 bundleadjustment_amd/csrc/*.hip  (cross-compiles without a GPU; one object per
+                source under bundleadjustment_amd/build/, so a change recompiles one file)
 ba_main       : g++   bundleadjustment_amd/host/ba_main.cpp, linked against both
 """
 import glob
@@ -41,12 +42,26 @@ def build_host(force=False):
 
 
 def build_gpu(force=False):
+    """One object per source under build/ (recompiled when the source or a header is newer), in parallel, then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     src = sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")))
-    deps = src + glob.glob(os.path.join(PKG, "csrc", "*.h")) + glob.glob(os.path.join(INC, "*.h"))
-    if force or _stale(GPU_SO, deps):
-        hipcc = os.path.join(ROCM, "bin", "hipcc")
-        _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", 
-              "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-I", INC, "-I", os.path.join(PKG, "csrc")] + src +
+    hdr = glob.glob(os.path.join(PKG, "csrc", "*.h")) + glob.glob(os.path.join(INC, "*.h"))
+    hipcc = os.path.join(ROCM, "bin", "hipcc")
+    objdir = os.path.join(PKG, "build")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value",
+             "-I", INC, "-I", os.path.join(PKG, "csrc")]
+    objs, todo = [], []
+    for f in src:
+        o = os.path.join(objdir, os.path.basename(f)[:-4] + ".o")
+        objs.append(o)
+        if force or _stale(o, [f] + hdr):
+            todo.append([hipcc] + flags + ["-c", f, "-o", o])
+    if todo:
+        with ThreadPoolExecutor(max_workers=min(8, len(todo))) as ex:
+            list(ex.map(_run, todo))
+    if todo or force or _stale(GPU_SO, objs):
+        _run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs +
              ["-L", os.path.join(ROCM, "lib"), "-lrccl", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-o", GPU_SO])
     return GPU_SO
 

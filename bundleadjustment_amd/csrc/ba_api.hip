@@ -163,6 +163,12 @@ struct ba_problem {
   // state
   bool have_params = false;
   bool rows_lean = false;  // the last linearisation did not write the rows Jp and Jc (the back substitution works from Y)
+  // per-station sums formed inside the observation kernel (ba_keyed.hip): plan of this network, null when it has none
+  bool fused_ok = false;
+  bool rows_fused = false;  // the last linearisation took that route: the station sums and the camera border are done
+  ba::KeyedPlanDev kp{};
+  int kp_ncolp = 0;
+  int *d_kp_sta_rec0 = nullptr, *d_kp_sta_recs = nullptr;
   double lin_radius = 1.0; // trust-region radius that linearisation carried
   double *d_zero = nullptr, *d_ytSy = nullptr;
   // second stream: the numbers of the multilevel preconditioner are set up beside the camera border, both
@@ -659,10 +665,46 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
     p->general_border = true;
   }
   BA_TRY(alloc_reduced_sums(p));
+  int campart_rows = obs_rows_blocks(N);
+  if (p->explicit_ok && N > 0 && (single_camera_path || p->ncam == 0) && !std::getenv("BA_NO_FUSED_SUMS")) {
+    // The station sums and the camera border can come out of the observation kernel when no tile of 64 observations
+    // sees more stations than a wave's table has rows, and the partial records stay a small part of the traffic.
+    std::vector<int> sta_host;
+    const int *sta_of_obs = e_sta.data();
+    if (on_device) {
+      sta_host.resize((size_t)N);
+      HIP_OK(hipMemcpy(sta_host.data(), p->d_obs_sta, (size_t)N * sizeof(int), hipMemcpyDeviceToHost));
+      sta_of_obs = sta_host.data();
+    }
+    int tps = 16;
+    if (const char *e = std::getenv("BA_KEYED_TILES")) tps = std::max(1, std::atoi(e));
+    KeyedPlanHost kh;
+    const int ncolp = keyed_ncolp(single_camera_path);
+    if (build_keyed_plan(N, S, sta_of_obs, tps, setup_threads(), kh) && (double)kh.n_rec * ncolp * 8.0 <= 48.0 * (double)N + 1e6) {
+      uint8_t *d_spos = nullptr, *d_slot = nullptr;
+      uint32_t *d_um = nullptr;
+      int *d_op0 = nullptr;
+      int2 *d_ops = nullptr;
+      BA_TRY(p->upload(&d_spos, kh.spos));
+      BA_TRY(p->upload(&d_slot, kh.slot));
+      BA_TRY(p->upload(&d_um, kh.umask));
+      BA_TRY(p->upload(&d_op0, kh.seg_op0));
+      BA_TRY(p->upload(&d_ops, kh.ops));
+      BA_TRY(p->upload(&p->d_kp_sta_rec0, kh.sta_rec0));
+      BA_TRY(p->upload(&p->d_kp_sta_recs, kh.sta_recs));
+      p->kp.spos = d_spos; p->kp.slot = d_slot; p->kp.umask = d_um; p->kp.seg_op0 = d_op0; p->kp.ops = d_ops;
+      p->kp.tiles_per_seg = kh.tiles_per_seg; p->kp.n_seg = kh.n_seg;
+      BA_TRY(p->dalloc(&p->kp.part, (size_t)kh.n_rec * ncolp));
+      p->kp_ncolp = ncolp;
+      p->fused_ok = true;
+      campart_rows = std::max(campart_rows, keyed_blocks(kh.n_seg));
+    }
+    trace.mark("plan of the station sums");
+  }
   if (single_camera_path) {
     // single camera with few free parameters: the linearisation kernel also produces the camera border's inputs
     BA_TRY(p->dalloc(&p->d_Jt, 2 * (size_t)border_ncb() * N));
-    BA_TRY(p->dalloc(&p->d_campart, (size_t)obs_rows_blocks(N) * lin_npart()));
+    BA_TRY(p->dalloc(&p->d_campart, (size_t)campart_rows * lin_npart()));
   }
   p->n_partial = 4 * std::max(std::max(linearize_blocks(P), cost_blocks(N)), cost_blocks(6 * (int64_t)S + 3 * (int64_t)P)) + 16;
   BA_TRY(p->dalloc(&p->d_partial, (size_t)p->n_partial));
@@ -771,6 +813,9 @@ int linearize(ba_problem *p, const LmState &st) {
   // reads Jp or Jc: the back substitution and the model cost change work from Y and the elimination records.
   la.lean = (st.reduced == 2 && !st.full_rows && !st.need_norms && (p->d_Jt != nullptr || p->ncam == 0) && p->ncam <= cg2_max_cam()) ? 1 : 0;
   p->rows_lean = la.lean != 0;
+  la.fused = (la.lean && p->fused_ok) ? 1 : 0;
+  la.kp = p->kp;
+  p->rows_fused = la.fused != 0;
   p->lin_radius = st.radius;
   launch_linearize(s, la);
   if (st.reduced == 2) {
@@ -785,13 +830,19 @@ int linearize(ba_problem *p, const LmState &st) {
   }
   launch_sum_partials(s, p->d_partial, linearize_blocks(p->P), p->d_scal, SC_COST);
   // this rank's share of the station blocks and of the camera rows of the gradient and the reduced right-hand side
-  StationArgs sa = station_args(p, 6, 39);
-  launch_station_pass(s, sa, SMODE_SETUP);
-  launch_station_fold(s, p->S, p->d_sta_chunk0, p->d_part, 39, 39, p->d_F);
+  if (la.fused) {
+    // the observation kernel left them in partial records: station sums into F, the camera border into Ssc
+    launch_keyed_fold(s, p->S, p->kp_ncolp, p->ncam, p->d_kp_sta_rec0, p->d_kp_sta_recs, p->kp.part, p->d_F, p->d_Ssc);
+  } else {
+    StationArgs sa = station_args(p, 6, 39);
+    launch_station_pass(s, sa, SMODE_SETUP);
+    launch_station_fold(s, p->S, p->d_sta_chunk0, p->d_part, 39, 39, p->d_F);
+  }
+  const int rows_blocks = la.fused ? keyed_blocks(p->kp.n_seg) : obs_rows_blocks(p->N);
   double *g_cam = p->d_g + 6 * (size_t)p->S, *b_cam = p->d_b + 6 * (size_t)p->S;
   if (p->ncam > 0) {
     if (p->d_Jt) {
-      launch_camera_rows_fold(s, p->d_campart, obs_rows_blocks(p->N), p->ncam, g_cam, b_cam);
+      launch_camera_rows_fold(s, p->d_campart, rows_blocks, p->ncam, g_cam, b_cam);
     } else {
       // camera rows of the gradient and of the reduced right-hand side: one station sweep over the camera columns for both
       StationArgs sc2 = station_args(p, 6, 2 * BA_NCAMPAR);
@@ -954,10 +1005,12 @@ int build_reduced(ba_problem *p, bool explicit_blocks) {
   if (p->ncam == 0) return 0;
   if (p->d_Jt) {
     // one camera, few free parameters: the border comes out of one point sweep and one station sweep
-    StationArgs sa = station_args(p, 6, border_nacc());
-    launch_border_station(s, sa, p->d_Jt);
-    launch_border_fold(s, p->S, p->ncam, p->n_chunks, p->d_sta_chunk0, p->d_part, border_nacc(), p->d_Ssc);
-    launch_camera_corner_fold(s, p->d_campart, obs_rows_blocks(p->N), p->d_corner);  // the sums come out of k_obs_rows
+    if (!p->rows_fused) {
+      StationArgs sa = station_args(p, 6, border_nacc());
+      launch_border_station(s, sa, p->d_Jt);
+      launch_border_fold(s, p->S, p->ncam, p->n_chunks, p->d_sta_chunk0, p->d_part, border_nacc(), p->d_Ssc);
+    }
+    launch_camera_corner_fold(s, p->d_campart, p->rows_fused ? keyed_blocks(p->kp.n_seg) : obs_rows_blocks(p->N), p->d_corner);  // the sums come out of k_obs_rows
     BA_TRY(sum_border());
     launch_border_corner(s, p->ncam, p->d_corner, p->d_diagfull + ns, p->d_Scc);
   } else if (p->d_Zc) {
@@ -2087,6 +2140,8 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
   la.cam_partial = p->d_campart;
   // timed as a solve runs it: without the rows that nothing reads
   la.lean = (p->explicit_ok && (p->d_Jt != nullptr || p->ncam == 0) && p->ncam <= cg2_max_cam()) ? 1 : 0;
+  la.fused = (la.lean && p->fused_ok) ? 1 : 0;
+  la.kp = p->kp;
   BsrCgArgs ba{};
   ba.S = p->S; ba.ncam = p->ncam; ba.rowptr = p->d_bsr_rowptr; ba.col = p->d_bsr_col; ba.val = p->d_bsr_val; ba.Ssc = p->d_Ssc;
   ba.Scc = p->d_Scc; ba.Lcc = p->d_Sccinv; ba.Minv = p->d_Minv; ba.b = p->d_b; ba.x = p->d_x; ba.r = p->d_r; ba.z = p->d_z; ba.p = p->d_p;
@@ -2205,6 +2260,32 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
           fprintf(stderr, "  %-18s mark %d  n=%4zu  %7.2f %7.2f %7.2f\n", kk == 1 ? (part ? "update1 (restrict)" : "update1 (vectors)") : names[kk], m,
                   v.size(), v.front(), v[v.size() / 2], v.back());
         }
+    *seconds_per_launch = 0.0;
+    return p->check_kernels();
+  }
+  if (which == 12) {
+    // the observation kernel that also forms the station sums, with clock counters around the phases of a tile
+    if (!la.fused) return fail(BA_ERR_INVALID, "ba_time_kernel: this network has no plan for the station sums");
+    const int nw = 4 * keyed_blocks(p->kp.n_seg);
+    unsigned long long *d_tr = nullptr;
+    HIP_OK(hipMalloc((void **)&d_tr, (size_t)nw * KS_TRACE_SLOTS * sizeof(unsigned long long)));
+    HIP_OK(hipMemsetAsync(d_tr, 0, (size_t)nw * KS_TRACE_SLOTS * sizeof(unsigned long long), s));
+    LinArgs lt = la;
+    lt.kp.trace = d_tr;
+    launch_linearize(s, lt, 2);
+    HIP_OK(hipStreamSynchronize(s));
+    std::vector<unsigned long long> tr((size_t)nw * KS_TRACE_SLOTS);
+    HIP_OK(hipMemcpy(tr.data(), d_tr, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    (void)hipFree(d_tr);
+    static const char *names[KS_TRACE_SLOTS] = {"load + evaluate", "camera columns", "elimination, requests", "Y: compute + store", "camera rows + sums, final write-out", "products, staging writes", "row reads", "adds, table"};
+    double tot = 0.0;
+    std::vector<double> sum(KS_TRACE_SLOTS, 0.0);
+    for (int wv = 0; wv < nw; ++wv)
+      for (int k = 0; k < KS_TRACE_SLOTS; ++k) sum[k] += (double)tr[(size_t)wv * KS_TRACE_SLOTS + k];
+    for (double v : sum) tot += v;
+    fprintf(stderr, "k_obs_rows with station sums: clocks per wave and tile (%d waves, %d tiles each)\n", nw, p->kp.tiles_per_seg);
+    for (int k = 0; k < KS_TRACE_SLOTS; ++k)
+      fprintf(stderr, "  %-20s %9.0f  %5.1f %%\n", names[k], sum[k] / nw / p->kp.tiles_per_seg, 100.0 * sum[k] / std::max(tot, 1.0));
     *seconds_per_launch = 0.0;
     return p->check_kernels();
   }

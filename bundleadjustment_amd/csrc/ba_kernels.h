@@ -16,6 +16,22 @@ enum { MODE_APPLY = 0, MODE_BACKSUB = 1 };
 enum { SMODE_GATHER = 0, SMODE_GATHER_CAM = 1, SMODE_SETUP = 2, SMODE_CAMNORM = 3, SMODE_CAM2 = 4 };
 enum { BA_CHUNK = 1024 };  // observations of one station handled by one workgroup
 
+// Per-station sums formed inside the observation kernel (ba_keyed.hip): the plan, as the kernel sees it
+#define BA_KS_NSLOT 24   // rows of a wave's LDS table: stations a segment can work on at once
+#define BA_KS_NCB 8      // camera border columns per station row (the single-camera path's limit)
+struct KeyedPlanDev {
+  const uint8_t *spos, *slot;  // per observation: row in its tile's station-sorted order; per sorted row: table slot
+  const uint32_t *umask;       // per tile: bit i set when row i or row 32 + i is the last of a run of one station
+  const int *seg_op0;          // per segment: its first entry in ops
+  const int2 *ops;             // x = (tile inside the segment << 8) | slot to write out before that tile, y = record
+  int tiles_per_seg, n_seg;
+  double *part;                // partial records, ncolp doubles each
+  // null, or KS_TRACE_SLOTS counters per wave of the grid: shader clocks spent in the phases of a tile, summed over the
+  // wave's tiles (ba_time_kernel, which = 12)
+  unsigned long long *trace;
+};
+enum { KS_TRACE_SLOTS = 8 };
+
 struct LinArgs {
   int P, ncmax;
   int64_t N;
@@ -32,6 +48,8 @@ struct LinArgs {
   int model;  // projection, 0..7 (ba_inputs.model)
   int emp;    // 0: no camera has an empirical term AP[7..15] that is free or non-zero (kernels then skip them)
   int lean;   // 1: the rows Jp and Jc are not written (nothing reads them: the back substitution works from Y)
+  int fused;  // 1: the observation kernel also forms the per-station sums (kp); it then writes Y only
+  KeyedPlanDev kp;
 };
 
 struct PointArgs {
@@ -106,6 +124,20 @@ struct CgArgs {
 
 void launch_station_prep(hipStream_t s, int S, const double *eop, const double *scale_sta, const int *sta_cam, double *sta);
 int linearize_blocks(int P);
+struct KeyedPlanHost {
+  std::vector<uint8_t> spos, slot;
+  std::vector<uint32_t> umask;
+  std::vector<int> seg_op0, sta_rec0, sta_recs;
+  std::vector<int2> ops;
+  int tiles_per_seg = 0, n_seg = 0, n_rec = 0;
+};
+// false: some tile of 64 observations sees more than keyed_nslot() stations (the caller keeps the station sweeps)
+bool build_keyed_plan(int64_t N, int S, const int *e_sta, int tiles_per_seg, int threads, KeyedPlanHost &out);
+int keyed_nslot();
+int keyed_ncolp(bool cam1);          // doubles per partial record
+int keyed_blocks(int n_seg);         // workgroups of the observation kernel when it forms the sums
+void launch_keyed_fold(hipStream_t s, int S, int ncolp, int ncam, const int *sta_rec0, const int *sta_recs, const double *part,
+                       double *F, double *Ssc);
 void launch_linearize(hipStream_t s, const LinArgs &a, int part = 3);
 int lin_ncb();
 int elim_stride();

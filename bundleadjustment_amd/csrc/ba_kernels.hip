@@ -260,36 +260,114 @@ k_point_elim(LinArgs a) {
 }
 
 #define ROWS_LDS(CAM1) (64 * ((CAM1) ? 25 : 2 * BA_NCAMPAR + 1))
+#define KS_STRIDE 34  // doubles per row of the staging buffer of the per-station sums: 32 columns, rows 16-byte aligned
+#define WAVE_SYNC()                                        \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
 // Two waves per SIMD where the register budget of that allows it without spilling (one register short otherwise): the
 // collinearity projection without the empirical terms.  The other variants keep one wave with the full register file.
-template <bool CAM1, bool GEN, bool EMP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((GEN || EMP) ? 1 : 2)))
+//
+// SUMS: the kernel also forms everything a station sums over its observations -- the diagonal block sum Js^T M Js, the
+// column norms, gradient and reduced right-hand side, and the camera border sum Js^T Jt -- and then writes the
+// coupling blocks Y only (no row of the Jacobian leaves the chip).  A wave owns a segment of consecutive tiles.  Per
+// tile every lane forms the products of its observation (39 + 6 x 8 columns), 32 columns at a time, and puts them
+// into the wave's staging buffer at the row its observation has in the tile's station-sorted order (prepared once per
+// problem, ba_keyed.hip).  Then the lanes change roles: lane (h, c) owns column c and rows 32 h .. 32 h + 31, adds the
+// rows up in a register and, where a run of one station ends, adds the sum to that station's row of the wave's LDS
+// table (ds_add_f64 -- the table is private to the wave and LDS operations of a wave execute in order, so the order
+// of every sum is fixed).  Rows leave the table for partial records in global memory when the plan says so; a second
+// tiny kernel adds the records of a station in ascending order.
+template <bool CAM1, bool GEN, bool EMP, bool SUMS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((GEN || EMP || SUMS) ? 1 : 2)))
 k_obs_rows(LinArgs a) {
   constexpr int NCP = EMP ? BA_NCAMPAR : BA_NCAMPAR_BROWN;
-  __shared__ double lds[4][ROWS_LDS(CAM1)];
+  constexpr int NCOLP = CAM1 ? 96 : 64;  // columns of a table row: 39 station sums (+ 48 border sums), padded to 32s
+  constexpr int BUF = SUMS ? 64 * KS_STRIDE : ROWS_LDS(CAM1);
+  __shared__ __attribute__((aligned(16))) double lds[4][BUF];
   __shared__ double lds_cam[4][LIN_NPART];
+  __shared__ __attribute__((aligned(16))) double lds_tab[SUMS ? 4 : 1][SUMS ? BA_KS_NSLOT * NCOLP : 2];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   double *buf = lds[w];
+  double *tab = lds_tab[SUMS ? w : 0];
   // sums of Jc^T r and Jc^T rhat over this wave's tiles: reduced across the wave tile by tile and kept in LDS
   // (sixteen accumulators per lane across the tile loop would cost the second wave per SIMD)
   if (CAM1) lds_cam[w][lane] = 0.0;  // LIN_NPART == 64
+  // SUMS, one camera: which camera column each of the LIN_NCB free parameters is and its scale (zero: no such parameter),
+  // once per workgroup; a tile then picks its columns with it instead of walking the camera's mask
+  __shared__ int lds_selp[SUMS && CAM1 ? LIN_NCB : 1];
+  __shared__ double lds_sels[SUMS && CAM1 ? LIN_NCB : 1];
+  if (SUMS && CAM1) {
+    if (threadIdx.x < LIN_NCB) {
+      const CamRec &cr = a.cam[0];
+      int pos = 0, pk = 0;
+      double sk = 0.0;
+      for (int p = 0; p < NCP; ++p)
+        if (cr.mask & (1u << p)) {
+          if (pos == (int)threadIdx.x) { pk = p; sk = cr.scale[pos]; }
+          ++pos;
+        }
+      lds_selp[threadIdx.x] = pk;
+      lds_sels[threadIdx.x] = sk;
+    }
+    __syncthreads();
+  }
   const int64_t n_tiles = (a.N + 63) / 64;
+  // SUMS: one segment of consecutive tiles per wave; otherwise the tiles are dealt round-robin over all waves
+  int64_t tile_begin, tile_end, tile_step;
+  int op = 0, op_end = 0;
+  if (SUMS) {
+    const int seg = blockIdx.x * 4 + w;
+    tile_begin = (int64_t)seg * a.kp.tiles_per_seg;
+    tile_end = tile_begin + a.kp.tiles_per_seg;
+    if (tile_end > n_tiles) tile_end = n_tiles;
+    if (seg >= a.kp.n_seg) tile_end = tile_begin;
+    tile_step = 1;
+    if (seg < a.kp.n_seg) {
+      op = a.kp.seg_op0[seg];
+      op_end = a.kp.seg_op0[seg + 1];
+    }
+    for (int k = lane; k < BA_KS_NSLOT * NCOLP; k += 64) tab[k] = 0.0;
+  } else {
+    tile_begin = (int64_t)blockIdx.x * 4 + w;
+    tile_end = n_tiles;
+    tile_step = (int64_t)gridDim.x * 4;
+  }
+  // table rows that the plan sends to their partial records before tile `trel` of the segment; the entry that is next
+  // in the list is held in registers, so that a tile with nothing to write out waits for no load
+  int2 op_cur = make_int2(0x7FFFFFFF, 0);
+  if (SUMS && op < op_end) op_cur = a.kp.ops[op];
+  auto write_out = [&](int trel) {
+    while (op < op_end && (op_cur.x >> 8) <= trel) {
+      double *row = tab + (op_cur.x & 255) * NCOLP;
+      if (lane < NCOLP / 2) {
+        const double2 v = *reinterpret_cast<const double2 *>(row + 2 * lane);
+        *reinterpret_cast<double2 *>(a.kp.part + (int64_t)op_cur.y * NCOLP + 2 * lane) = v;
+        *reinterpret_cast<double2 *>(row + 2 * lane) = make_double2(0.0, 0.0);
+      }
+      ++op;
+      if (op < op_end) op_cur = a.kp.ops[op];
+    }
+  };
   // The observation record and point index of the NEXT tile are requested at the top of a tile: a wave's loads and
   // stores complete in order, so a load issued after a tile's stores also waits for those to drain.
-  const int64_t tile_step = (int64_t)gridDim.x * 4;
   ObsIn o_next{};
   int jj_next = 0;
-  {
-    const int64_t t0 = (int64_t)blockIdx.x * 4 + w;
-    if (t0 < n_tiles) {
-      const int64_t en = (t0 * 64 + lane < a.N) ? t0 * 64 + lane : t0 * 64;
-      o_next = load_obs(a.obs, en);
-      jj_next = a.obs_pt[en];
-    }
+  if (tile_begin < tile_end) {
+    const int64_t t0 = tile_begin;
+    const int64_t en = (t0 * 64 + lane < a.N) ? t0 * 64 + lane : t0 * 64;
+    o_next = load_obs(a.obs, en);
+    jj_next = a.obs_pt[en];
   }
   // ... and the records those lead to (station, point) right before a tile's first store, for the same reason
   // (what the projection needs: rotation, position, sin/cos kappa, the point; the scales are read when they are used)
   double st_next[14], xyz_next[3];
+  // SUMS (one wave per SIMD, the whole register file): everything else the tile reads per observation as well -- the
+  // station's column scales, the point's scales, V^-1 and its elimination record -- so that a tile waits for no load
+  // that it issued itself
+  double ssc_next[SUMS ? 6 : 1], spt_next[SUMS ? 3 : 1], vi_next[SUMS ? 6 : 1], el_next[SUMS ? 10 : 1];
   auto gather_next = [&]() {
     const double2 *sp = reinterpret_cast<const double2 *>(a.sta + (int64_t)BA_STA_STRIDE * o_next.sta);
 #pragma unroll
@@ -300,20 +378,68 @@ k_obs_rows(LinArgs a) {
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) xyz_next[k] = a.xyz[3 * (int64_t)jj_next + k];
+    if (SUMS) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double2 v = sp[7 + k];
+        ssc_next[2 * k] = v.x;
+        ssc_next[2 * k + 1] = v.y;
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) spt_next[k] = a.scale_pt[3 * (int64_t)jj_next + k];
+      const double2 *vp = reinterpret_cast<const double2 *>(a.Vinv + 6 * (int64_t)jj_next);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double2 v = vp[k];
+        vi_next[2 * k] = v.x;
+        vi_next[2 * k + 1] = v.y;
+      }
+      const double2 *ep = reinterpret_cast<const double2 *>(a.elim + (int64_t)ELIM_STRIDE * jj_next);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const double2 v = ep[k];
+        el_next[2 * k] = v.x;
+        el_next[2 * k + 1] = v.y;
+      }
+    }
   };
-  if ((int64_t)blockIdx.x * 4 + w < n_tiles) gather_next();
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < n_tiles; tile += tile_step) {
+  if (tile_begin < tile_end) gather_next();
+  double cam_acc[(SUMS && CAM1) ? 2 * LIN_NCB + LIN_NCORNER : 1];  // per-lane sums of the camera rows and the corner (SUMS)
+#pragma unroll
+  for (int k = 0; k < ((SUMS && CAM1) ? 2 * LIN_NCB + LIN_NCORNER : 1); ++k) cam_acc[k] = 0.0;
+  unsigned long long tr_acc[KS_TRACE_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_last = 0;
+  const bool tracing = SUMS && a.kp.trace != nullptr;
+  auto stamp = [&](int k) {
+    if (SUMS && tracing) {
+      const unsigned long long now = clock64();
+      tr_acc[k] += now - tr_last;
+      tr_last = now;
+    }
+  };
+  for (int64_t tile = tile_begin; tile < tile_end; tile += tile_step) {
+    if (SUMS && tracing) tr_last = clock64();
     const int64_t e0 = tile * 64;
     const int nvalid = (int)((a.N - e0 < 64) ? (a.N - e0) : 64);
     const bool on = lane < nvalid;
     // idle lanes of the last tile redo its first observation and store nothing
     const ObsIn o = o_next;
     const int jj = jj_next;
-    if (tile + tile_step < n_tiles) {
+    if (tile + tile_step < tile_end) {
       const int64_t en0 = (tile + tile_step) * 64;
       const int64_t en = (en0 + lane < a.N) ? en0 + lane : en0;
       o_next = load_obs(a.obs, en);
       jj_next = a.obs_pt[en];
+    }
+    // SUMS: this tile's part of the plan -- the lane's row in the sorted order, the slots of the rows of its half
+    int my_row = 0;
+    uint32_t um = 0;
+    uint4 sw0 = make_uint4(0, 0, 0, 0), sw1 = make_uint4(0, 0, 0, 0);
+    if (SUMS) {
+      my_row = a.kp.spos[e0 + lane];
+      um = a.kp.umask[tile];
+      const uint4 *sp = reinterpret_cast<const uint4 *>(a.kp.slot + e0 + 32 * (lane >> 5));
+      sw0 = sp[0];
+      sw1 = sp[1];
     }
     double st[14];
 #pragma unroll
@@ -322,16 +448,53 @@ k_obs_rows(LinArgs a) {
     const int c = CAM1 ? 0 : __double2loint(st_rec[20]);  // one camera: scalar loads of its record
     const CamIn cm = load_cam(a.cam, c);
     const double X = xyz_next[0], Y = xyz_next[1], Z = xyz_next[2];
-    const double s0 = a.scale_pt[3 * (int64_t)jj], s1 = a.scale_pt[3 * (int64_t)jj + 1], s2 = a.scale_pt[3 * (int64_t)jj + 2];
+    double ssc[6], Vi[6], el9[9], elz[3 * LIN_NCB];
+    double s0, s1, s2;
+    if (SUMS) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { ssc[k] = ssc_next[k]; Vi[k] = vi_next[k]; }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) el9[k] = el_next[k];
+      if (CAM1) {
+        // the camera part of the elimination record is used last in the tile: requested here, for this tile
+        const double2 *zp = reinterpret_cast<const double2 *>(a.elim + (int64_t)ELIM_STRIDE * jj + 16);
+#pragma unroll
+        for (int k = 0; k < 3 * LIN_NCB / 2; ++k) {
+          const double2 v = zp[k];
+          elz[2 * k] = v.x;
+          elz[2 * k + 1] = v.y;
+        }
+      }
+      s0 = spt_next[0]; s1 = spt_next[1]; s2 = spt_next[2];
+    } else {
+      s0 = a.scale_pt[3 * (int64_t)jj]; s1 = a.scale_pt[3 * (int64_t)jj + 1]; s2 = a.scale_pt[3 * (int64_t)jj + 2];
+    }
     double r0, r1, Js[12], Jp[6], dc0[NCP], dc1[NCP];
     eval_obs<true, GEN, EMP>(o, st, X, Y, Z, cm, r0, r1, Js, Jp, dc0, dc1, a.model);
     double sc;
     (void)huber_rho(a.huber_a, r0 * r0 + r1 * r1, sc);
     r0 *= sc;
     r1 *= sc;
+    stamp(0);
     // free camera columns, compacted: into LDS at a run-time position, out as whole lines
     double c0[CAM1 ? LIN_NCB : 1], c1[CAM1 ? LIN_NCB : 1];
-    if (a.ncmax > 0) {
+    if (SUMS && CAM1) {
+      // all camera columns into the lane's own row of the wave's buffer, the free ones back out by their index
+      double *mine = buf + lane * (2 * NCP + 1);
+#pragma unroll
+      for (int p = 0; p < NCP; ++p) {
+        mine[p] = dc0[p];
+        mine[NCP + p] = dc1[p];
+      }
+#pragma unroll
+      for (int k = 0; k < LIN_NCB; ++k) {
+        const int pk = lds_selp[k];
+        const double cs = sc * lds_sels[k];
+        c0[k] = mine[pk] * cs;
+        c1[k] = mine[NCP + pk] * cs;
+      }
+      WAVE_SYNC();
+    } else if (a.ncmax > 0) {
       const CamRec &cr = a.cam[c];
       const int R = 2 * a.ncmax;
       double *mine = buf + lane * (R + 1);
@@ -349,9 +512,7 @@ k_obs_rows(LinArgs a) {
           ++pos;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      WAVE_SYNC();
       if (!a.lean) {
         double *gj = a.Jc + (int64_t)R * e0;
         // q / R by a multiplication: exact for q < 64 * 38 with this constant (R is not known at compile time, and a
@@ -369,43 +530,54 @@ k_obs_rows(LinArgs a) {
           c1[k] = (k < a.ncmax) ? mine[a.ncmax + k] : 0.0;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      WAVE_SYNC();
     }
+    stamp(1);
     // point data of the elimination
-    const double *vi = a.Vinv + 6 * (int64_t)jj, *el = a.elim + (int64_t)ELIM_STRIDE * jj;
-    const double Vi[6] = {vi[0], vi[1], vi[2], vi[3], vi[4], vi[5]};
-    const double u0 = el[0], u1 = el[1], u2 = el[2];
+    // (two waves per SIMD: the elimination record is read where it is used, it would not fit the registers)
+    const double *el = a.elim + (int64_t)ELIM_STRIDE * jj;
+    if (!SUMS) {
+      const double *vi = a.Vinv + 6 * (int64_t)jj;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Vi[k] = vi[k];
+    }
+    const double u0 = SUMS ? el9[0] : el[0], u1 = SUMS ? el9[1] : el[1], u2 = SUMS ? el9[2] : el[2];
     const double p0 = Jp[0] * (sc * s0), p1 = Jp[1] * (sc * s1), p2 = Jp[2] * (sc * s2);
     const double p3 = Jp[3] * (sc * s0), p4 = Jp[4] * (sc * s1), p5 = Jp[5] * (sc * s2);
     const double h0 = r0 - (p0 * u0 + p1 * u1 + p2 * u2), h1 = r1 - (p3 * u0 + p4 * u1 + p5 * u2);
-    {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double cs = sc * (SUMS ? ssc[k] : st_rec[14 + k]);
+      Js[k] *= cs;
+      Js[6 + k] *= cs;
+    }
+    if (!SUMS) {
       double rec[16];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const double cs = sc * st_rec[14 + k];
-        Js[k] *= cs;
-        Js[6 + k] *= cs;
-        rec[k] = Js[k];
-        rec[6 + k] = Js[6 + k];
-      }
+      for (int k = 0; k < 12; ++k) rec[k] = Js[k];
       rec[12] = r0; rec[13] = r1; rec[14] = h0; rec[15] = h1;
-      if (tile + tile_step < n_tiles) gather_next();  // before this tile's first store
+      if (tile + tile_step < tile_end) gather_next();  // before this tile's first store
       tile_store<16>(buf, rec, a.rec + (int64_t)BA_REC_STRIDE * e0, lane, nvalid);
+    } else {
+      if (tile + tile_step < tile_end) gather_next();
     }
+    double mo[3];
     {
       const double jp[6] = {p0, p1, p2, p3, p4, p5};
-      if (!a.lean) tile_store<6>(buf, jp, a.Jp + 6 * e0, lane, nvalid);
+      if (!SUMS && !a.lean) tile_store<6>(buf, jp, a.Jp + 6 * e0, lane, nvalid);
       double t0, t1, t2, w0, w1, w2;
       sym3_mul(Vi, p0, p1, p2, t0, t1, t2);
       sym3_mul(Vi, p3, p4, p5, w0, w1, w2);
-      const double mo[3] = {1.0 - (p0 * t0 + p1 * t1 + p2 * t2), -(p0 * w0 + p1 * w1 + p2 * w2), 1.0 - (p3 * w0 + p4 * w1 + p5 * w2)};
-      tile_store<3>(buf, mo, a.Mo + 3 * e0, lane, nvalid);
+      mo[0] = 1.0 - (p0 * t0 + p1 * t1 + p2 * t2);
+      mo[1] = -(p0 * w0 + p1 * w1 + p2 * w2);
+      mo[2] = 1.0 - (p3 * w0 + p4 * w1 + p5 * w2);
+      if (!SUMS) tile_store<3>(buf, mo, a.Mo + 3 * e0, lane, nvalid);
     }
+    stamp(2);
     if (a.Y) {
       // G = Jp L (2x3);  Y[r][m] = Js0[r] G0[m] + Js1[r] G1[m], row-major 6 x 3
-      const double l00 = el[3], l10 = el[4], l20 = el[5], l11 = el[6], l21 = el[7], l22 = el[8];
+      const double l00 = SUMS ? el9[3] : el[3], l10 = SUMS ? el9[4] : el[4], l20 = SUMS ? el9[5] : el[5];
+      const double l11 = SUMS ? el9[6] : el[6], l21 = SUMS ? el9[7] : el[7], l22 = SUMS ? el9[8] : el[8];
       const double g00 = p0 * l00 + p1 * l10 + p2 * l20, g01 = p1 * l11 + p2 * l21, g02 = p2 * l22;
       const double g10 = p3 * l00 + p4 * l10 + p5 * l20, g11 = p4 * l11 + p5 * l21, g12 = p5 * l22;
       double y[BA_Y_STRIDE];
@@ -417,18 +589,21 @@ k_obs_rows(LinArgs a) {
       }
       tile_store<BA_Y_STRIDE>(buf, y, a.Y + (int64_t)BA_Y_STRIDE * e0, lane, nvalid);
     }
+    stamp(3);
+    double jt[2 * LIN_NCB];  // projected camera rows (single-camera path)
     if (CAM1) {
       {
-        double jt[2 * LIN_NCB];
 #pragma unroll
         for (int k = 0; k < LIN_NCB; ++k) {
-          const double z0 = el[16 + 3 * k], z1 = el[17 + 3 * k], z2 = el[18 + 3 * k];
-          const bool free_k = k < a.ncmax;
+          const double z0 = SUMS ? elz[3 * k] : el[16 + 3 * k], z1 = SUMS ? elz[3 * k + 1] : el[17 + 3 * k], z2 = SUMS ? elz[3 * k + 2] : el[18 + 3 * k];
+          const bool free_k = SUMS || k < a.ncmax;  // SUMS: columns beyond the free ones are zeros, and so is their Z
           jt[k] = free_k ? c0[k] - (p0 * z0 + p1 * z1 + p2 * z2) : 0.0;
           jt[LIN_NCB + k] = free_k ? c1[k] - (p3 * z0 + p4 * z1 + p5 * z2) : 0.0;
         }
-        tile_store<2 * LIN_NCB>(buf, jt, a.Jt + 2 * (int64_t)LIN_NCB * e0, lane, nvalid);
+        if (!SUMS) tile_store<2 * LIN_NCB>(buf, jt, a.Jt + 2 * (int64_t)LIN_NCB * e0, lane, nvalid);
         // corner of the camera border: upper triangle of Jc^T Jt, 36 sums in three reductions of 16
+        // (SUMS: one wave per SIMD has the registers to keep the 52 sums per lane over all tiles of its segment; they are
+        // reduced across the wave once, after the last tile)
         const int slot = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
 #pragma unroll
         for (int part = 0; part < 3; ++part) {
@@ -442,23 +617,109 @@ k_obs_rows(LinArgs a) {
                                        6, 7, 4, 5, 6, 7, 5, 6, 7, 6, 7, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             const int idx = 16 * part + q;
             cs[q] = (idx < LIN_NCORNER && on) ? c0[tri_k[idx]] * jt[tri_m[idx]] + c1[tri_k[idx]] * jt[LIN_NCB + tri_m[idx]] : 0.0;
+            if (SUMS && idx < LIN_NCORNER) cam_acc[2 * LIN_NCB + idx] += cs[q];
           }
-          const double tot = wave_sum16(cs, lane);
-          if ((lane & 3) == 0) lds_cam[w][2 * LIN_NCB + 16 * part + slot] += tot;
+          if (!SUMS) {
+            const double tot = wave_sum16(cs, lane);
+            if ((lane & 3) == 0) lds_cam[w][2 * LIN_NCB + 16 * part + slot] += tot;
+          }
         }
       }
       {
         double gsum[2 * LIN_NCB];
 #pragma unroll
         for (int k = 0; k < LIN_NCB; ++k) {
-          const bool use = on && k < a.ncmax;
+          const bool use = on && (SUMS || k < a.ncmax);
           gsum[k] = use ? c0[k] * r0 + c1[k] * r1 : 0.0;
           gsum[LIN_NCB + k] = use ? c0[k] * h0 + c1[k] * h1 : 0.0;
+          if (SUMS) {
+            cam_acc[k] += gsum[k];
+            cam_acc[LIN_NCB + k] += gsum[LIN_NCB + k];
+          }
         }
-        const double tot = wave_sum16(gsum, lane);
-        if ((lane & 3) == 0) lds_cam[w][((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1)] += tot;
+        if (!SUMS) {
+          const double tot = wave_sum16(gsum, lane);
+          if ((lane & 3) == 0) lds_cam[w][((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1)] += tot;
+        }
       }
     }
+    stamp(4);
+    if (SUMS) {
+      write_out((int)(tile - tile_begin));
+      // factors of the products; idle lanes of the last tile contribute zeros
+      double a0[6], a1[6], w0[6], w1[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        a0[k] = on ? Js[k] : 0.0;
+        a1[k] = on ? Js[6 + k] : 0.0;
+        w0[k] = mo[0] * a0[k] + mo[1] * a1[k];
+        w1[k] = mo[1] * a0[k] + mo[2] * a1[k];
+      }
+      auto product = [&](int col) -> double {  // col is a constant wherever this is called
+        constexpr int tp[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+        constexpr int tq[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
+        if (col < 21) return w0[tp[col]] * a0[tq[col]] + w1[tp[col]] * a1[tq[col]];   // sum Js^T M Js, upper triangle
+        if (col < 27) return a0[col - 21] * a0[col - 21] + a1[col - 21] * a1[col - 21];  // column norms
+        if (col < 33) return a0[col - 27] * r0 + a1[col - 27] * r1;                      // gradient
+        if (col < 39) return a0[col - 33] * h0 + a1[col - 33] * h1;                      // reduced right-hand side
+        if (CAM1 && col < 39 + 6 * LIN_NCB)                                              // camera border, 6 x 8
+          return a0[(col - 39) / LIN_NCB] * jt[(col - 39) % LIN_NCB] + a1[(col - 39) / LIN_NCB] * jt[LIN_NCB + (col - 39) % LIN_NCB];
+        return 0.0;
+      };
+      const int h = lane >> 5, cl = lane & 31;
+      double *row = buf + my_row * KS_STRIDE;
+      const double *colp = buf + (32 * h) * KS_STRIDE + cl;
+      const uint32_t sw[8] = {sw0.x, sw0.y, sw0.z, sw0.w, sw1.x, sw1.y, sw1.z, sw1.w};
+      const uint32_t umu = __builtin_amdgcn_readfirstlane(um);
+#pragma unroll
+      for (int pass = 0; pass < NCOLP / 32; ++pass) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          *reinterpret_cast<double2 *>(row + 2 * k) = make_double2(product(32 * pass + 2 * k), product(32 * pass + 2 * k + 1));
+        WAVE_SYNC();
+        stamp(5);
+        double acc = 0.0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {  // sixteen rows at a time keep the registers in bounds
+          double x[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) x[i] = colp[(16 * half + i) * KS_STRIDE];
+          if (tracing) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(6); }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            acc += x[i];
+            if (umu & (1u << (16 * half + i))) {  // uniform: a run ends here in one of the halves (the other half's run is cut in two)
+              const int ii = 16 * half + i;
+              const int sl = (int)((sw[ii >> 2] >> (8 * (ii & 3))) & 255u);
+              __hip_atomic_fetch_add(tab + sl * NCOLP + 32 * pass + cl, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+              acc = 0.0;
+            }
+          }
+        }
+        WAVE_SYNC();
+        stamp(7);
+      }
+      WAVE_SYNC();
+    }
+  }
+  if (SUMS && tracing) tr_last = clock64();
+  if (SUMS && CAM1) {
+    const int slot = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+#pragma unroll
+    for (int part = 0; part < 4; ++part) {  // 0: camera rows of gradient and right-hand side, 1..3: the corner
+      double v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = (16 * part + q < 2 * LIN_NCB + LIN_NCORNER) ? cam_acc[(16 * part + q < 2 * LIN_NCB + LIN_NCORNER) ? 16 * part + q : 0] : 0.0;
+      const double tot = wave_sum16(v, lane);
+      if ((lane & 3) == 0) lds_cam[w][16 * part + slot] = tot;
+    }
+  }
+  if (SUMS) write_out(0x7FFFFF);
+  stamp(4);
+  if (SUMS && tracing && lane == 0) {
+    unsigned long long *out = a.kp.trace + (int64_t)(blockIdx.x * 4 + w) * KS_TRACE_SLOTS;
+#pragma unroll
+    for (int k = 0; k < KS_TRACE_SLOTS; ++k) out[k] = tr_acc[k];
   }
   if (CAM1) {
     __syncthreads();
@@ -1612,13 +1873,18 @@ void launch_linearize(hipStream_t s, const LinArgs &a, int part) {
       {{k_point_elim<false, false, false>, k_point_elim<false, false, true>}, {k_point_elim<false, true, false>, k_point_elim<false, true, true>}},
       {{k_point_elim<true, false, false>, k_point_elim<true, false, true>}, {k_point_elim<true, true, false>, k_point_elim<true, true, true>}}};
   static void (*const rows_tab[2][2][2])(LinArgs) = {
-      {{k_obs_rows<false, false, false>, k_obs_rows<false, false, true>}, {k_obs_rows<false, true, false>, k_obs_rows<false, true, true>}},
-      {{k_obs_rows<true, false, false>, k_obs_rows<true, false, true>}, {k_obs_rows<true, true, false>, k_obs_rows<true, true, true>}}};
+      {{k_obs_rows<false, false, false, false>, k_obs_rows<false, false, true, false>}, {k_obs_rows<false, true, false, false>, k_obs_rows<false, true, true, false>}},
+      {{k_obs_rows<true, false, false, false>, k_obs_rows<true, false, true, false>}, {k_obs_rows<true, true, false, false>, k_obs_rows<true, true, true, false>}}};
+  static void (*const sums_tab[2][2][2])(LinArgs) = {
+      {{k_obs_rows<false, false, false, true>, k_obs_rows<false, false, true, true>}, {k_obs_rows<false, true, false, true>, k_obs_rows<false, true, true, true>}},
+      {{k_obs_rows<true, false, false, true>, k_obs_rows<true, false, true, true>}, {k_obs_rows<true, true, false, true>, k_obs_rows<true, true, true, true>}}};
   void (*elim)(LinArgs) = elim_tab[a.Jt ? 1 : 0][gen ? 1 : 0][a.emp ? 1 : 0];
-  void (*rows)(LinArgs) = rows_tab[a.Jt ? 1 : 0][gen ? 1 : 0][a.emp ? 1 : 0];
+  void (*rows)(LinArgs) = (a.fused ? sums_tab : rows_tab)[a.Jt ? 1 : 0][gen ? 1 : 0][a.emp ? 1 : 0];
   if (part & 1) hipLaunchKernelGGL(elim, gp, b, 0, s, a);
-  if (part & 2) hipLaunchKernelGGL(rows, go, b, 0, s, a);
+  if (part & 2) hipLaunchKernelGGL(rows, a.fused ? dim3(keyed_blocks(a.kp.n_seg)) : go, b, 0, s, a);
 }
+int keyed_ncolp(bool cam1) { return cam1 ? 96 : 64; }
+int keyed_blocks(int n_seg) { return n_seg < 1 ? 1 : (n_seg + 3) / 4; }
 int elim_stride() { return ELIM_STRIDE; }
 int lin_ncb() { return LIN_NCB; }
 // camera rows of the gradient (out_g) and of the reduced right-hand side (out_b) from the partials
