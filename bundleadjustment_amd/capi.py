@@ -26,6 +26,7 @@ class BaInputs(C.Structure):
         ("iop_prior", c_double_p), ("iop_sigma", c_double_p),
         ("ap_free_mask", C.POINTER(C.c_uint16)), ("iop_free_mask", C.POINTER(C.c_uint8)),
         ("huber_a", C.c_double), ("model", C.c_int32),
+        ("cam_in_use", C.POINTER(C.c_uint8)),
     ]
 
 
@@ -136,6 +137,7 @@ class Network:
     huber_a: float = 1.0
     model: int = 0
     truth: dict = field(default_factory=dict)
+    cam_in_use: np.ndarray = None  # a rank's share of a network only: [C] uint8, cameras that the whole network observes
 
     def __post_init__(self):
         for k in ("obs_pt", "obs_sta", "sta_cam"):
@@ -145,6 +147,8 @@ class Network:
             setattr(self, k, _f64(getattr(self, k)))
         self.ap_free_mask = np.ascontiguousarray(self.ap_free_mask, dtype=np.uint16)
         self.iop_free_mask = np.ascontiguousarray(self.iop_free_mask, dtype=np.uint8)
+        if self.cam_in_use is not None:
+            self.cam_in_use = np.ascontiguousarray(self.cam_in_use, dtype=np.uint8)
 
     @property
     def n_obs(self):
@@ -184,6 +188,7 @@ class Network:
         s.iop_free_mask = self.iop_free_mask.ctypes.data_as(C.POINTER(C.c_uint8))
         s.huber_a = float(self.huber_a)
         s.model = int(self.model)
+        s.cam_in_use = None if self.cam_in_use is None else self.cam_in_use.ctypes.data_as(C.POINTER(C.c_uint8))
         return s
 
     def params_copy(self):

@@ -146,6 +146,7 @@ struct ba_problem {
   // block-sparse PCG is formed by rows (-1 never, 0 when the model below says it pays, 1 always), its buffer
   // [q | partials], and the rows the last solve gave this rank (both 0: every rank formed the whole product)
   int shard_rank = 0, shard_world = 1, shard_mode = 0;
+  bool shard_layout_checked = false;  // the ranks have compared the layout of the buffer they sum (solve_pcg_explicit)
   double *d_qshard = nullptr;
   int last_row0 = 0, last_row_end = 0;
   bool cg_graph_failed = false;
@@ -208,17 +209,41 @@ struct ba_problem {
   int64_t n_reductions = 0;
   double reduction_bytes = 0.0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> reduction_events;
+  double reduction_seconds = 0.0;  // of event pairs already folded in (the list is kept short)
+  // elapsed time of the pairs recorded so far into reduction_seconds; the events are released
+  void fold_reduction_events() {
+    for (auto &e : reduction_events) {
+      float ms = 0.f;
+      if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) reduction_seconds += 1e-3 * ms;
+      (void)hipEventDestroy(e.first);
+      (void)hipEventDestroy(e.second);
+    }
+    reduction_events.clear();
+  }
   int allreduce(double *buf, int64_t n, int op) {
     if (!ar || n <= 0) return 0;
     n_reductions++;
     reduction_bytes += 8.0 * (double)n;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (time_reductions) {
+      if (reduction_events.size() >= 1024) fold_reduction_events();  // a long solve makes one reduction per inner iteration
       HIP_OK(hipEventCreate(&e0));
       HIP_OK(hipEventCreate(&e1));
       HIP_OK(hipEventRecord(e0, stream));
     }
-    if (ar(ar_user, buf, n, op, stream) != 0) return fail(BA_ERR_COMM, "allreduce callback failed");
+    if (ar(ar_user, buf, n, op, stream) != 0) {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      // a communicator of this library's own is torn down at once: the ranks that are inside the collective get an
+      // error from it instead of waiting for this one, and nothing is queued behind a reduction that did not happen
+      if (comm) {
+        (void)ncclCommAbort(comm);
+        comm = nullptr;
+        ar = nullptr;
+      }
+      return fail(BA_ERR_COMM, "reduction over the ranks failed (%lld doubles, %s): the ranks no longer hold the same sums, the solve ends here",
+                  (long long)n, op == 1 ? "max" : "sum");
+    }
     if (time_reductions) {
       HIP_OK(hipEventRecord(e1, stream));
       reduction_events.emplace_back(e0, e1);
@@ -341,6 +366,10 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
     sdeg[in->obs_sta[n]]++;
     min_sta[in->obs_pt[n]] = std::min(min_sta[in->obs_pt[n]], in->obs_sta[n]);
   }
+  // a share of a larger network: cameras that only other ranks observe keep their columns here too
+  if (in->cam_in_use)
+    for (int c = 0; c < C; ++c)
+      if (in->cam_in_use[c]) cam_used[c] = 1;
   // cameras: free-parameter lists (src/main.cpp:4479-4511 for the AP; an AP block that no
   // observation references is not part of the reduced program)
   p->cam_h.assign(C, CamRec());
@@ -647,7 +676,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
     BA_TRY(p->dalloc(&p->d_part_pq, npart));
     BA_TRY(p->dalloc(&p->d_part_qc, npart * std::max(p->ncam, 1)));
     BA_TRY(p->dalloc(&p->d_part_rz, npart));
-    BA_TRY(p->dalloc(&p->d_cg2scal, 16));
+    BA_TRY(p->dalloc(&p->d_cg2scal, 32));
   }
   trace.mark("pair lists upload");
   const bool single_camera_path = C == 1 && p->ncmax > 0 && p->ncmax <= border_ncb() && border_ncb() == lin_ncb();
@@ -1137,6 +1166,19 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
   const int64_t n_shard_buf = 6 * (int64_t)p->S + (int64_t)nbs * (1 + p->ncam);
   p->last_row0 = p->last_row_end = 0;
   if (shard_rows) {
+    if (!p->shard_layout_checked) {
+      // the buffer that the ranks sum is [q | one partial per workgroup of the product kernel]: its layout follows from
+      // the device the rank runs on, so the ranks make sure once that they all have the same one
+      double h[2] = {(double)nbs, -(double)nbs};
+      HIP_OK(hipMemcpyAsync(p->d_cg2scal + 24, h, sizeof h, hipMemcpyHostToDevice, s));
+      BA_TRY(p->allreduce(p->d_cg2scal + 24, 2, 1));
+      HIP_OK(hipMemcpyAsync(h, p->d_cg2scal + 24, sizeof h, hipMemcpyDeviceToHost, s));
+      HIP_OK(hipStreamSynchronize(s));
+      if (h[0] != (double)nbs || h[1] != -(double)nbs)
+        return fail(BA_ERR_COMM, "the ranks run on different devices (%d workgroups of the product kernel here, %d to %d over the ranks): "
+                    "the product cannot be split by rows (ba_shard_reduced_solve mode -1 keeps it whole)", nbs, (int)-h[1], (int)h[0]);
+      p->shard_layout_checked = true;
+    }
     if (!p->d_qshard) BA_TRY(p->dalloc(&p->d_qshard, (size_t)n_shard_buf));
     a.q = p->d_qshard;
     a.part_pq = a.q + 6 * (size_t)p->S;
@@ -1154,7 +1196,9 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
   }
   auto iteration = [&](int parity) -> int {
     if (shard_rows) {
-      HIP_OK(hipMemsetAsync(a.q, 0, 6 * (size_t)p->S * sizeof(double), s));
+      // the whole buffer: the partial sums too (an iteration that runs after convergence leaves them unwritten, and
+      // what the previous reduction left there must not be summed again)
+      HIP_OK(hipMemsetAsync(a.q, 0, (size_t)n_shard_buf * sizeof(double), s));
       launch_bsr_spmv(s, a, parity);
       BA_TRY(p->allreduce(a.q, n_shard_buf, 0));
       launch_amg_cg_iteration_after_product(s, a, p->amg, parity);
@@ -2393,8 +2437,9 @@ static int sync_shards(ba_problem *p) {
     BA_TRY(host_allreduce(p, c, 1));
     for (size_t k = 0; k < c.size(); ++k)
       if ((c[k] > 0.0) != (p->cam_used_h[k] != 0))
-        return fail(BA_ERR_UNSUPPORTED, "camera %zu is observed on another shard but not on this one: every rank must hold "
-                    "observations of every camera that is used", k);
+        return fail(BA_ERR_INVALID, "camera %zu is observed on another rank but this rank's problem does not carry its columns: "
+                    "create the problems of all ranks with ba_inputs.cam_in_use (the cameras that the whole network observes; "
+                    "ba_net_shard fills it)", k);
   }
   if (S == 0) return 0;
   std::vector<double> flag(1, p->explicit_ok ? 0.0 : 1.0);
@@ -2477,19 +2522,13 @@ int ba_reduction_timing(ba_problem *p, int32_t on) {
 int ba_reduction_stats(ba_problem *p, int64_t *count, double *bytes, double *seconds) {
   if (!p) return fail(BA_ERR_INVALID, "ba_reduction_stats: null problem");
   HIP_OK(hipStreamSynchronize(p->stream));
-  double t = 0.0;
-  for (auto &e : p->reduction_events) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) t += 1e-3 * ms;
-    (void)hipEventDestroy(e.first);
-    (void)hipEventDestroy(e.second);
-  }
-  p->reduction_events.clear();
+  p->fold_reduction_events();
   if (count) *count = p->n_reductions;
   if (bytes) *bytes = p->reduction_bytes;
-  if (seconds) *seconds = t;
+  if (seconds) *seconds = p->reduction_seconds;
   p->n_reductions = 0;
   p->reduction_bytes = 0.0;
+  p->reduction_seconds = 0.0;
   return 0;
 }
 
@@ -2546,8 +2585,13 @@ int ba_copy_to_device(double *device_dst, const void *host_src, int64_t count, v
 
 static int rccl_allreduce(void *user, double *buf, int64_t count, int32_t op, void *stream) {
   ba_problem *p = static_cast<ba_problem *>(user);
-  const ncclResult_t r = ncclAllReduce(buf, buf, (size_t)count, ncclDouble, op == 1 ? ncclMax : ncclSum, p->comm,
-                                       static_cast<hipStream_t>(stream));
+  if (!p->comm) return -1;
+  ncclResult_t r = ncclAllReduce(buf, buf, (size_t)count, ncclDouble, op == 1 ? ncclMax : ncclSum, p->comm,
+                                 static_cast<hipStream_t>(stream));
+  // an error that an earlier collective ran into shows here as well (a peer that is gone, a failed transfer)
+  ncclResult_t async_err = ncclSuccess;
+  if (r == ncclSuccess && ncclCommGetAsyncError(p->comm, &async_err) == ncclSuccess && async_err != ncclSuccess) r = async_err;
+  if (r != ncclSuccess) fprintf(stderr, "ba_gpu: ncclAllReduce: %s\n", ncclGetErrorString(r));
   return r == ncclSuccess ? 0 : -1;
 }
 

@@ -822,16 +822,20 @@ int cg2_blocks_spmv(int S) {
   if (nw < SPMV_WAVES) return nb;  // at most CG2_MAX_SPMV_BLOCKS by the choice of nw, all resident
   // as many workgroups as the device holds at once (one of sixteen waves per CU on MI355X: 256; more would wait for a
   // second round), at most the partials the fold takes
-  static int cap = 0;
-  if (!cap) {
-    int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+  // (looked up once per device: a process may hold problems on several)
+  static int caps[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!caps[dev]) {
+    int cus = 0, per_cu = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bsr_spmv, 64 * SPMV_WAVES, 0) == hipSuccess && cus > 0 && per_cu > 0)
-      cap = std::min((int)CG2_MAX_SPMV_BLOCKS, cus * per_cu);
+      caps[dev] = std::min((int)CG2_MAX_SPMV_BLOCKS, cus * per_cu);
     else
-      cap = 256;
+      caps[dev] = 256;
     (void)hipGetLastError();
   }
+  const int cap = caps[dev];
   if (nb <= cap) return nb;
   // the same number of rows for every wave: the kernel ends when the waves with the most rows do
   const int rows_per_wave = nblk(S, cap * SPMV_WAVES);

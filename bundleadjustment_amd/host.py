@@ -184,7 +184,8 @@ class HostNetwork:
             xyz=_arr(L.ba_net_xyz(self._h), 3 * P, np.float64).reshape(P, 3),
             iop=_arr(L.ba_net_iop(self._h), 3 * Cn, np.float64).reshape(Cn, 3),
             ap=_arr(L.ba_net_ap(self._h), 16 * Cn, np.float64).reshape(Cn, 16),
-            huber_a=inp.huber_a, model=inp.model, truth=truth)
+            huber_a=inp.huber_a, model=inp.model, truth=truth,
+            cam_in_use=_arr(inp.cam_in_use, Cn, np.uint8) if inp.cam_in_use else None)
 
     def ids(self, which):
         names = {"pho_target": 0, "pho_station": 1, "eop_station": 2, "eop_camera": 3, "xyz_target": 4, "iop_camera": 5}

@@ -57,6 +57,7 @@ struct ba_network {
   std::vector<double> iopPrior, iopStdDev;
   std::vector<uint16_t> apFree;
   std::vector<uint8_t> iopFree;
+  std::vector<uint8_t> camInUse;  // a shard only (ba_net_shard): cameras that the whole network observes
   // truth (synthetic only)
   std::vector<double> tEOP, tXYZ, tIOP, tAP;
   // variances of the parameters (empty until ba_net_set_variances; src/main.cpp:5251-5256 defaults otherwise)
@@ -528,6 +529,7 @@ int ba_net_inputs(ba_network *n, ba_inputs *in) {
   in->iop_free_mask = n->iopFree.data();
   in->huber_a = 1.0;  // src/main.cpp:3810
   in->model = n->model;
+  in->cam_in_use = n->camInUse.empty() ? nullptr : n->camInUse.data();
   return 0;
 }
 
@@ -575,6 +577,9 @@ int ba_net_shard(const ba_network *n, int32_t rank, int32_t world, ba_network **
   s->IOP = n->IOP; s->AP = n->AP;
   s->staSensor = n->staSensor; s->iopPrior = n->iopPrior; s->iopStdDev = n->iopStdDev;
   s->apFree = n->apFree; s->iopFree = n->iopFree;
+  // the cameras that the whole network observes: a rank without rows of one of them carries its columns all the same
+  s->camInUse.assign(n->iopCamera.size(), 0);
+  for (size_t i = 0; i < n->indexPose.size(); ++i) s->camInUse[n->staSensor[n->indexPose[i]]] = 1;
   s->tEOP = n->tEOP; s->tIOP = n->tIOP; s->tAP = n->tAP;
   s->vEOP = n->vEOP; s->vIOP = n->vIOP; s->vAP = n->vAP;
   auto cut = [&](const std::vector<double> &v, std::vector<double> &o, int per) {

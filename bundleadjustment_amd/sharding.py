@@ -30,6 +30,9 @@ def shard_network(net: Network, rank: int, world: int):
     b = point_ranges(net.obs_pt, net.n_pts, world)
     lo, hi = int(b[rank]), int(b[rank + 1])
     sel = np.nonzero((net.obs_pt >= lo) & (net.obs_pt < hi))[0]
+    # cameras that the whole network observes: a rank without rows of one of them still carries its columns
+    in_use = np.zeros(net.n_cam, dtype=np.uint8)
+    in_use[net.sta_cam[net.obs_sta]] = 1
     shard = Network(
         obs_pt=net.obs_pt[sel] - lo, obs_sta=net.obs_sta[sel], sta_cam=net.sta_cam,
         obs_x=net.obs_x[sel], obs_y=net.obs_y[sel], obs_sx=net.obs_sx[sel], obs_sy=net.obs_sy[sel],
@@ -37,5 +40,5 @@ def shard_network(net: Network, rank: int, world: int):
         pt_prior=net.pt_prior.reshape(-1, 3)[lo:hi], pt_sigma=net.pt_sigma.reshape(-1, 3)[lo:hi],
         iop_prior=net.iop_prior, iop_sigma=net.iop_sigma, ap_free_mask=net.ap_free_mask,
         iop_free_mask=net.iop_free_mask, eop=net.eop, xyz=net.xyz.reshape(-1, 3)[lo:hi], iop=net.iop, ap=net.ap,
-        huber_a=net.huber_a, model=net.model)
+        huber_a=net.huber_a, model=net.model, cam_in_use=in_use)
     return shard, slice(lo, hi)

@@ -56,9 +56,11 @@ enum ba_stop_reason {
 
 enum ba_linear_solver {
   BA_SOLVER_DENSE_SCHUR = 0, /* point elimination + dense fp64 Cholesky of the reduced system */
-  BA_SOLVER_PCG_SCHUR = 1,   /* point elimination + block-Jacobi PCG on the reduced system, held as 6x6
-                                blocks in block-sparse form (matrix-free when it is too dense for that, or when
-                                the cameras have more than 79 free parameters between them) */
+  BA_SOLVER_PCG_SCHUR = 1,   /* point elimination + PCG on the reduced system, held as 6x6 blocks in
+                                block-sparse form, with the multilevel (smoothed aggregation) preconditioner
+                                unless ba_options.preconditioner asks for block-Jacobi (matrix-free with
+                                block-Jacobi when the system is too dense for that form, or when the cameras
+                                have more than 79 free parameters between them) */
   BA_SOLVER_PCG_IMPLICIT = 2, /* same PCG, always matrix-free: S p = Jc^T (I - Jp V^-1 Jp^T) Jc p */
   BA_SOLVER_AUTO = 3          /* the default: DENSE_SCHUR while the reduced system has at most
                                  BA_AUTO_DENSE_ORDER unknowns (6 per station + the free camera
@@ -104,6 +106,12 @@ typedef struct {
                                  * 2 fisheye equidistant :1596/:2226, 3 equisolid angle :1680/:2312,
                                  * 4 fisheye orthographic :1765/:2398, 5 fisheye stereographic :1850/:2484,
                                  * 6 collinearity orthographic :1412, 7 omnidirectional :2700 */
+  const uint8_t *cam_in_use;    /* NULL, or [n_cam] for a problem that holds one rank's share of a network
+                                 * (ba_set_allreduce): non-zero for every camera that some observation of the WHOLE
+                                 * network refers to.  The AP block of a camera is part of the program when an image
+                                 * row refers to it (src/main.cpp:4242-4245); a rank whose share holds no such row
+                                 * still carries the block's columns (with zero sums of its own), so that the reduced
+                                 * systems of all ranks have one layout.  ba_net_shard fills it. */
 } ba_inputs;
 
 /*
@@ -377,6 +385,8 @@ int ba_use_rccl(ba_problem *p, int32_t n_ranks, int32_t rank, const void *unique
  * stations and BA_NOALLOC_MAX_CAMERAS cameras (BA_ERR_UNSUPPORTED beyond; points and observations are not limited).
  * All calls on one GPU share that array: calls on one stream are ordered and safe, calls that overlap in time on one
  * GPU (two streams, two host threads) race.
+ * The first call on a device looks the array's address up (hipGetSymbolAddress, which may load the library's code
+ * object): make one call on every device outside any graph capture before the first captured one.
  */
 #define BA_NOALLOC_MAX_STATIONS 65536
 #define BA_NOALLOC_MAX_CAMERAS 64

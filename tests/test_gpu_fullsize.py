@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from bundleadjustment_amd import capi, host, solver
+from util import RTOL, rel
 
 pytestmark = pytest.mark.gpu
 
@@ -176,3 +177,34 @@ def test_cfg4_full_size_variances(big):
     assert np.all(vi > 0.0) and np.all(va[0, free] > 0.0) and np.all(np.delete(va[0], free) == 0.0)
     np.testing.assert_allclose(wi, vi, rtol=1e-6)
     np.testing.assert_allclose(wa, va, rtol=1e-6)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name", ["cfg3", "cfg4"])
+def test_full_size_pcg_step_equals_dense_cholesky_step(name, big):
+    # One LM step of the whole network (cfg3: reduced system of order 10 800; cfg4: order 60 007, the benchmark's) taken
+    # twice on the GPU: with the PCG on the block-sparse system -- three-level hierarchy, structures built on the device,
+    # batches of iterations replayed as graphs -- and with the dense Cholesky factorisation on the matrix cores, which
+    # shares none of that.  Same candidate cost and same parameters after the step to 1e-9.
+    net = big if name == "cfg4" else host.synth_config("cfg3", outlier_fraction=0.0).net
+    out = {}
+    for ls in (capi.SOLVER_PCG_SCHUR, capi.SOLVER_DENSE_SCHUR):
+        with solver.Problem(net) as P:
+            opt = solver.default_options()
+            opt.linear_solver = ls
+            opt.max_num_iterations = 1
+            opt.pcg_rtol = 1e-12
+            opt.pcg_max_iters = 20000
+            opt.function_tolerance = opt.parameter_tolerance = opt.gradient_tolerance = 0.0
+            P.set_parameters()
+            sm, rows = P.solve_resident(opt)
+            assert sm["linear_solver_used"] == ls and len(rows) == 2 and rows[1]["step_is_successful"]
+            out[ls] = (rows, P.get_parameters())
+    (rp, pp), (rd, pd) = out[capi.SOLVER_PCG_SCHUR], out[capi.SOLVER_DENSE_SCHUR]
+    assert rp[0]["cost"] == rd[0]["cost"]
+    assert abs(rp[1]["cost"] - rd[1]["cost"]) <= RTOL * rd[1]["cost"], (rp[1]["cost"], rd[1]["cost"])
+    assert abs(rp[1]["step_norm"] - rd[1]["step_norm"]) <= 1e-9 * rd[1]["step_norm"]
+    for nm, a, b in zip(("eop", "xyz", "iop", "ap"), pp, pd):
+        assert rel(a, b) < RTOL, (nm, rel(a, b))
+    # and the step is a real one: the cost falls by an order of magnitude
+    assert rd[1]["cost"] < 0.12 * rd[0]["cost"]

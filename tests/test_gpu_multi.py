@@ -24,6 +24,22 @@ def _make_net(n_cam=1):
                       control_every=8).net
 
 
+def _make_net_lonely_camera():
+    """Two cameras; the stations of camera 1 (the odd ones) only see points of the first rank's share, so the second
+    rank holds no image row of that camera."""
+    import dataclasses
+    from bundleadjustment_amd import host, sharding
+    net = host.synth(n_cam=2, n_sta=60, n_pts=400, rays_per_point=6, seed=5, ap_free_mask=host.AP_K1K2P1P2, control_every=8).net
+    for _ in range(50):  # dropping rows moves the boundary between the shares: repeat until the second share has none
+        cut = int(sharding.point_ranges(net.obs_pt, net.n_pts, 2)[1])
+        keep = ~((net.obs_sta % 2 == 1) & (net.obs_pt >= cut))
+        if keep.all():
+            break
+        kw = {k: getattr(net, k)[keep] for k in ("obs_pt", "obs_sta", "obs_x", "obs_y", "obs_sx", "obs_sy", "obs_cx", "obs_cy")}
+        net = dataclasses.replace(net, **kw)
+    return net
+
+
 def _box(net):
     """A box on xp yp c whose upper bound on camera 0's xp is active at the solution."""
     lo = np.tile([-100.0, -100.0, 0.0], (net.n_cam, 1))
@@ -48,7 +64,7 @@ def _worker(rank, world, port, ls, n_cam, out, bounded=False, by_rows=False):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from bundleadjustment_amd import sharding, solver
-    net = _make_net(n_cam)
+    net = _make_net_lonely_camera() if n_cam == "lonely" else _make_net(n_cam)
     shard, sl = sharding.shard_network(net, rank, world)
 
     calls = []
@@ -111,6 +127,35 @@ def test_two_ranks_match_oracle(ls, n_cam, bounded):
         assert res[4]["reductions_in_solve"] <= 4 * len(res[5]) + 4, (res[4]["reductions_in_solve"], len(res[5]))
 
 
+@pytest.mark.parametrize("ls", [0, 1])
+def test_a_rank_without_rows_of_a_camera(ls):
+    """A camera that only one rank's share of the points sees: the other rank carries its columns with sums of zero
+    (ba_inputs.cam_in_use, filled by the sharding) and the two-rank solve matches the oracle's solve of the network."""
+    from oracle import py_oracle as po
+    from bundleadjustment_amd import sharding
+    from util import assert_solve_parity
+    net = _make_net_lonely_camera()
+    s1, _ = sharding.shard_network(net, 1, 2)
+    assert not np.any(s1.sta_cam[s1.obs_sta] == 1) and np.any(net.sta_cam[net.obs_sta] == 1)
+    assert list(s1.cam_in_use) == [1, 1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ls, "lonely", q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    o = po.solve(net, _options(ls, False), po.SCHUR_DENSE)
+    g = list(res)
+    for k in ("num_residuals_reduced", "num_parameters_reduced", "num_effective_parameters_reduced", "num_parameters",
+              "num_residuals"):
+        g[4][k] = o[4][k]
+    assert_solve_parity(tuple(g), o)
+
+
 @pytest.mark.parametrize("n_cam", [1, 3])
 def test_two_ranks_product_by_rows(n_cam):
     """The block-sparse PCG with its product q = S p formed by rows: each rank takes half of the blocks and one more sum
@@ -142,6 +187,63 @@ def test_two_ranks_product_by_rows(n_cam):
     n_lm = len(res[5])
     assert res[4]["reductions_in_solve"] >= n_pcg  # at least one per PCG iteration
     assert res[4]["reductions_in_solve"] <= 4 * n_lm + 4 + n_pcg + 32 * n_lm
+
+
+def _full_size_worker(rank, world, port, steps, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from bundleadjustment_amd import capi, host, solver
+    hn = host.synth_config("cfg4")
+    net = hn.shard(rank, world)[0].net if world > 1 else hn.net
+
+    def reduce_fn(buf, op):
+        dist.all_reduce(torch.from_numpy(buf), op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+
+    with solver.Problem(net) as P:
+        if world > 1:
+            P.set_allreduce_host_staged(reduce_fn)
+        opt = solver.default_options()
+        opt.linear_solver = capi.SOLVER_PCG_SCHUR
+        opt.max_num_iterations = steps
+        opt.pcg_max_iters = 20000
+        opt.function_tolerance = opt.parameter_tolerance = opt.gradient_tolerance = 0.0
+        P.set_parameters()
+        sm, rows = P.solve_resident(opt)
+    if rank == 0:
+        out.put((world, [r["cost"] for r in rows], [r["linear_iterations"] for r in rows]))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_on_the_10m_network_match_one_rank():
+    """The benchmark's network (10M observations) solved for three LM iterations by one rank and by two ranks (both on
+    the one GPU of the box, sums staged through the host): the same cost after every iteration to 1e-9."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    steps = 3
+    one = ctx.Process(target=_full_size_worker, args=(0, 1, 0, steps, q))
+    one.start()
+    r1 = q.get(timeout=600)
+    one.join(120)
+    assert one.exitcode == 0
+    port = _free_port()
+    procs = [ctx.Process(target=_full_size_worker, args=(r, 2, port, steps, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    r2 = q.get(timeout=800)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert r1[0] == 1 and r2[0] == 2 and len(r1[1]) == len(r2[1]) == steps + 1
+    for a, b in zip(r1[1], r2[1]):
+        assert abs(a - b) <= 1e-9 * abs(a), (r1[1], r2[1])
+    assert r1[1][-1] < 0.1 * r1[1][0]
 
 
 @pytest.mark.parametrize("pcg_rows", ["auto", "always"])
