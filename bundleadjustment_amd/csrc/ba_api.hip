@@ -167,6 +167,7 @@ struct ba_problem {
   // per-station sums formed inside the observation kernel (ba_keyed.hip): plan of this network, null when it has none
   bool fused_ok = false;
   bool rows_fused = false;  // the last linearisation took that route: the station sums and the camera border are done
+  ba::SchurWinDev sw{};  // off-diagonal blocks assembled window by window (n_win == 0: block by block)
   ba::KeyedPlanDev kp{};
   int kp_ncolp = 0;
   int *d_kp_sta_rec0 = nullptr, *d_kp_sta_recs = nullptr;
@@ -678,6 +679,18 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
     BA_TRY(p->dalloc(&p->d_part_rz, npart));
     BA_TRY(p->dalloc(&p->d_cg2scal, 32));
   }
+  if (p->explicit_ok && p->n_pairs > 0 && !std::getenv("BA_NO_SCHUR_WINDOWS")) {
+    std::vector<int> pts_host;
+    const int *pts = pt_start.data();
+    if (on_device) {
+      pts_host.resize((size_t)P + 1);
+      HIP_OK(hipMemcpy(pts_host.data(), p->d_pt_start, ((size_t)P + 1) * sizeof(int), hipMemcpyDeviceToHost));
+      pts = pts_host.data();
+    }
+    std::string err;
+    if (setup_schur_windows(p->stream, N, P, pts, p->d_pairs, p->n_pairs, ublk_cstart, p->sw, p->allocs, err) < 0)
+      return fail(BA_ERR_DEVICE, "set-up of the window lists: %s", err.c_str());
+  }
   trace.mark("pair lists upload");
   const bool single_camera_path = C == 1 && p->ncmax > 0 && p->ncmax <= border_ncb() && border_ncb() == lin_ncb();
   if (p->ncam > 0 && !single_camera_path && (double)P * p->ncam * 24.0 <= 16e9) {
@@ -853,7 +866,8 @@ int linearize(ba_problem *p, const LmState &st) {
     HIP_OK(hipEventRecord(p->ev_rows, s));
     HIP_OK(hipStreamWaitEvent(p->stream2, p->ev_rows, 0));
     HIP_OK(hipMemsetAsync(p->d_bsr_val, 0, 36 * (size_t)p->n_bsr * sizeof(double), p->stream2));
-    launch_schur_blocks(p->stream2, p->n_ublk, p->d_ublk_cstart, p->d_ublk_dst, p->d_pairs, p->d_Y, p->d_bsr_val);
+    if (p->sw.n_win > 0) launch_schur_windows(p->stream2, p->sw, p->d_Y, p->d_ublk_dst, p->d_bsr_val);
+    else launch_schur_blocks(p->stream2, p->n_ublk, p->d_ublk_cstart, p->d_ublk_dst, p->d_pairs, p->d_Y, p->d_bsr_val);
     HIP_OK(hipEventRecord(p->ev_schur, p->stream2));
     p->schur_queued = true;
   }
@@ -1022,7 +1036,8 @@ int build_reduced(ba_problem *p, bool explicit_blocks) {
       // numbers queued for the previous matrix and never waited for (the solve took another route) still read it
       if (p->amg_numbers_queued) HIP_OK(hipStreamWaitEvent(s, p->ev_amg, 0));
       HIP_OK(hipMemsetAsync(p->d_bsr_val, 0, 36 * (size_t)p->n_bsr * sizeof(double), s));
-      launch_schur_blocks(s, p->n_ublk, p->d_ublk_cstart, p->d_ublk_dst, p->d_pairs, p->d_Y, p->d_bsr_val);
+      if (p->sw.n_win > 0) launch_schur_windows(s, p->sw, p->d_Y, p->d_ublk_dst, p->d_bsr_val);
+      else launch_schur_blocks(s, p->n_ublk, p->d_ublk_cstart, p->d_ublk_dst, p->d_pairs, p->d_Y, p->d_bsr_val);
     }
     if (!border_first) {
       BA_TRY(p->allreduce(p->d_bsr_val, 36 * (int64_t)p->n_bsr, 0));
@@ -2225,7 +2240,10 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
       case 1: launch_point_pass(s, pa, MODE_APPLY, false); break;
       case 2: launch_station_pass(s, sa, SMODE_GATHER); break;
       case 3: launch_cost_obs(s, ca, cost_blocks(p->N)); break;
-      case 4: launch_schur_blocks(s, p->n_ublk, p->d_ublk_cstart, p->d_ublk_dst, p->d_pairs, p->d_Y, p->d_bsr_val); break;
+      case 4:
+        if (p->sw.n_win > 0) launch_schur_windows(s, p->sw, p->d_Y, p->d_ublk_dst, p->d_bsr_val);
+        else launch_schur_blocks(s, p->n_ublk, p->d_ublk_cstart, p->d_ublk_dst, p->d_pairs, p->d_Y, p->d_bsr_val);
+        break;
       case 5:  // two iterations, as the parity of the scalar slots alternates
         for (int par = 0; par < 2; ++par) {
           if (with_amg) launch_amg_cg_iteration(s, ba, p->amg, par);

@@ -220,6 +220,21 @@ struct BsrCgArgs {
   int rows_sharded, row0, row_end;
 };
 enum { PCG_TRACE_KERNELS = 5, PCG_TRACE_MAXWG = 2048, PCG_TRACE_SLOTS = 8 };
+// ba_schur_win.hip: the same blocks assembled window by window (every record read once)
+#define BA_SW_WCAP 448   // observations per window: their 144-byte records fill 63 KB of LDS (two workgroups share a CU)
+#define BA_SW_PCAP 2048  // pairs per window (their indices are staged in LDS too)
+struct SchurWinDev {
+  int n_win, n_seg, nu;
+  const int *win_obs0, *win_seg0, *win_pair0;  // per window: first observation, first (window, block) segment, first pair
+  const int *seg_q0;               // per segment: first pair
+  const unsigned *pairs16;         // pairs in (window, block) order: observation a | observation b << 16, relative to the window
+  const int *blk_seg0, *blk_segs;  // per block: its segments, ascending
+  double *part;                    // one partial block (36 doubles) per segment
+};
+int setup_schur_windows(hipStream_t s, int64_t N, int P, const int *pt_start, const int2 *d_pairs, int64_t n_pairs, const std::vector<int> &cstart,
+                        SchurWinDev &out, std::vector<void *> &owned, std::string &err);
+void launch_schur_windows(hipStream_t s, const SchurWinDev &a, const double *Y, const int2 *dst, double *val);
+int schur_windows_grid(const SchurWinDev &a);  // workgroups of the window kernel
 void launch_schur_blocks(hipStream_t s, int nu, const int *cstart, const int2 *dst, const int2 *pairs, const double *Y, double *val);
 void launch_bsr_add_diag(hipStream_t s, int S, const int *rowptr, const double *Sdiag, double *val);
 void launch_bsr_to_dense(hipStream_t s, int S, int ncam, const int *rowptr, const int *col, const double *val, const double *Ssc,
