@@ -2,7 +2,10 @@
 `scripts/pmc_workload.py cfg4 1.0 2`) into the files kept under profiles/: the kernel-statistics table, the per-kernel
 traffic table, and pmc_traffic.json, which bench.py reads for roofline.traffic.
 
-    python scripts/summarise_profiles.py r01e gpurun_out/prof_r01e gpurun_out/pmc_fetch gpurun_out/pmc_write
+    python scripts/summarise_profiles.py r03 gpurun_out/r03_prof gpurun_out/r03_pmc_fetch gpurun_out/r03_pmc_write gpurun_out/r03_pmc_calib
+
+The last directory holds the FETCH_SIZE pass of scripts/pmc_calib (read patterns of known size): the ratio counter / bytes it
+gives for every pattern is written into the table and decides the correction of FETCH_SIZE.
 """
 import collections
 import csv
@@ -14,6 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, d_stats, d_fetch, d_write = sys.argv[1:5]
+d_calib = sys.argv[5] if len(sys.argv) > 5 else None
 
 
 def one(pattern):
@@ -43,26 +47,54 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_fetch_write_cfg4.csv"), "w"
 
 
 def find(prefix):
-    hits = [r for r in rows if r[0].replace("void ", "").startswith("ba::" + prefix)]
+    hits = [r for r in rows if r[0].replace("void ", "").startswith("ba::" + prefix) or r[0].replace("void ", "").startswith("ba::(anonymous namespace)::" + prefix)]
     assert hits, prefix
     return max(hits, key=lambda r: r[1])  # the variant the benchmark network uses is the one dispatched most
 
 
+# calibration: counter value over the bytes each pattern reads (2 GiB each, see scripts/pmc_calib.hip)
+calibration = {}
+if d_calib:
+    shutil.copy(one(os.path.join(d_calib, "**", "*counter_collection.csv")), os.path.join(ROOT, "profiles", f"{tag}_pmc_calibration_fetch_size.csv"))
+    sizes = {"calib_stream16": 2 << 30, "calib_stream8": 2 << 30, "calib_stream4": 2 << 30, "calib_records<4>": 2 << 30, "calib_records<8>": 2 << 30,
+             "calib_records<9>": (2 << 30) // 144 * 144, "calib_gather<4>": 2 << 30, "calib_gather<8>": 2 << 30, "calib_records9": (2 << 30) // 144 * 144}
+    for k, (n, kb) in means(d_calib, "FETCH_SIZE").items():
+        for name, nbytes in sizes.items():
+            if k.replace("void ", "").startswith(name):
+                calibration[name] = round(kb * 1024.0 / nbytes, 4)
+# Every pattern of the calibration reads half of its bytes on the counter, except scattered 64-byte records, which read
+# their bytes (= half of the 128-byte lines they touch): FETCH_SIZE counts 128-byte requests at 64 bytes whatever the
+# width of the load.  Twice the counter is therefore the bytes of the lines requested, for every kernel.
+doubled = True if not calibration else all(abs(v - 0.5) < 0.02 for k, v in calibration.items() if k != "calib_gather<4>")
 kernels = {}
-for name, doubled in (("k_bsr_spmv", True), ("k_schur_blocks", False), ("k_point_elim", False), ("k_obs_rows", False)):
-    k, n, fkb, wkb = find(name)
-    kernels[name] = {"fetch_kb_raw": fkb, "write_kb": wkb, "fetch_doubled": doubled,
+for name in ("k_bsr_spmv", "k_schur_windows", "k_schur_win_fold", "k_schur_blocks", "k_point_elim", "k_obs_rows", "k_cost_obs", "k_backsub_y", "k_keyed_fold"):
+    try:
+        k, n, fkb, wkb = find(name)
+    except AssertionError:
+        continue
+    kernels[name] = {"fetch_kb_raw": fkb, "write_kb": wkb, "fetch_doubled": doubled, "dispatches": n,
                      "bytes_per_launch": int(round(((2.0 if doubled else 1.0) * fkb + wkb) * 1024))}
-kernels["linearisation (k_point_elim + k_obs_rows)"] = {
-    "fetch_kb_raw": kernels["k_point_elim"]["fetch_kb_raw"] + kernels["k_obs_rows"]["fetch_kb_raw"],
-    "write_kb": kernels["k_point_elim"]["write_kb"] + kernels["k_obs_rows"]["write_kb"], "fetch_doubled": False,
-    "bytes_per_launch": kernels["k_point_elim"]["bytes_per_launch"] + kernels["k_obs_rows"]["bytes_per_launch"],
-    "note": "k_point_elim + k_obs_rows"}
+
+
+def total(names, label):
+    have = [kernels[n] for n in names if n in kernels]
+    kernels[label] = {"fetch_kb_raw": sum(h["fetch_kb_raw"] for h in have), "write_kb": sum(h["write_kb"] for h in have), "fetch_doubled": doubled,
+                      "bytes_per_launch": sum(h["bytes_per_launch"] for h in have), "note": " + ".join(n for n in names if n in kernels)}
+
+
+total(("k_point_elim", "k_obs_rows"), "linearisation (k_point_elim + k_obs_rows)")
+total(("k_schur_windows", "k_schur_win_fold") if "k_schur_windows" in kernels else ("k_schur_blocks",), "k_schur_blocks")
+total(("k_point_elim", "k_obs_rows", "k_schur_windows", "k_schur_win_fold", "k_keyed_fold") if "k_schur_windows" in kernels else ("k_point_elim", "k_obs_rows", "k_schur_blocks"),
+      "Jacobian + Schur assembly (k_point_elim + k_obs_rows + k_schur_blocks)")
 out = {"config": "cfg4",
        "source": f"profiles/{tag}_pmc_fetch_write_cfg4.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, scripts/pmc_workload.py cfg4 1.0 2)",
-       "correction": "FETCH_SIZE doubled for kernels whose dominant reads are 16 B per lane (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE as reported; KB = 1024 B; Infinity-Cache hits are included in FETCH_SIZE",
+       "correction": "FETCH_SIZE doubled for every kernel: the calibration (scripts/pmc_calib, profiles/" + tag + "_pmc_calibration_fetch_size.csv) reads 0.50 of the bytes "
+                     "for contiguous reads of 4, 8 and 16 bytes per lane, for records of 64 / 128 / 144 bytes walked in order and for scattered 128-byte records, and 1.0 for "
+                     "scattered 64-byte records (half of the 128-byte lines they touch): the counter tallies 128-byte requests at 64 bytes whatever the load width; "
+                     "WRITE_SIZE as reported; KB = 1024 B; Infinity-Cache hits are included in FETCH_SIZE; 'k_schur_blocks' = the window kernel + its fold",
+       "calibration_counter_over_bytes": calibration,
        "kernels": kernels}
 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
     json.dump(out, f, indent=1)
 for k, v in kernels.items():
-    print("%-45s %8.1f MB per launch" % (k, v["bytes_per_launch"] / 1e6))
+    print("%-75s %8.1f MB per launch" % (k, v["bytes_per_launch"] / 1e6))
