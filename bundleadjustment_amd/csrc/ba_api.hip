@@ -138,6 +138,8 @@ struct ba_problem {
   double *d_Y = nullptr, *d_bsr_val = nullptr, *d_Sdiag = nullptr, *d_Jt = nullptr, *d_corner = nullptr, *d_campart = nullptr, *d_elim = nullptr;
   double *d_part_pq = nullptr, *d_part_qc = nullptr, *d_part_rz = nullptr, *d_cg2scal = nullptr;
   std::vector<int> ub_lo_h, ub_hi_h, bsr_rowptr_h, bsr_col_h;  // host copies of the block structure
+  int cov_route = 0, cov_max_cluster = 1536, cov_route_used = 0;  // ba_set_covariance_route / ba_covariance_stats
+  SelInvStats cov_stats{};
   std::vector<int> cam_used_h;
   hipGraphExec_t cg_graph = nullptr;  // one batch of PCG iterations, captured once
   hipGraphExec_t cg_graph_tail = nullptr;  // a short batch for the end of a solve
@@ -1992,21 +1994,48 @@ int ba_solve(ba_problem *p, const ba_options *opt, double *eop, double *xyz, dou
   return ba_get_parameters(p, eop, xyz, iop, ap);
 }
 
+int ba_set_covariance_route(ba_problem *p, int32_t route, int32_t max_cluster_stations) {
+  if (!p) return fail(BA_ERR_INVALID, "ba_set_covariance_route: null problem");
+  if (route < 0 || route > 2) return fail(BA_ERR_INVALID, "ba_set_covariance_route: route %d (0 automatic, 1 dense inverse, 2 dissection)", route);
+  if (max_cluster_stations < 0) return fail(BA_ERR_INVALID, "ba_set_covariance_route: negative cluster size");
+  p->cov_route = route;
+  p->cov_max_cluster = max_cluster_stations > 0 ? max_cluster_stations : 1536;
+  return 0;
+}
+
+int ba_covariance_stats(const ba_problem *p, int32_t *route_used, int32_t *clusters, int32_t *boundary_order, int32_t *largest_cluster_order) {
+  if (!p) return fail(BA_ERR_INVALID, "ba_covariance_stats: null problem");
+  if (route_used) *route_used = p->cov_route_used;
+  if (clusters) *clusters = p->cov_stats.clusters;
+  if (boundary_order) *boundary_order = p->cov_stats.boundary_order;
+  if (largest_cluster_order) *largest_cluster_order = p->cov_stats.largest_cluster_order;
+  return 0;
+}
+
 int ba_covariance(ba_problem *p, double *var_eop, double *var_xyz, double *var_iop, double *var_ap) {
   if (!p) return fail(BA_ERR_INVALID, "ba_covariance: null problem");
   if (!p->have_params) return fail(BA_ERR_INVALID, "ba_covariance: no parameters set");
   const int n = p->nr;
-  // the dense reduced matrix, a work matrix of the same size for the inverse, and the per-point work array must fit
+  // Route 1 needs the dense reduced matrix, a work matrix of the same size for the inverse and the per-point work array;
+  // when they do not fit, the blocks of the inverse that the variances need come from a dissection of the station graph.
+  bool selected = p->cov_route == 2, dense_fits = true;
   {
     const double ld = n >= chol_blocked_min_order() ? chol_blocked_ld(n) : n;
     const double need = 2.0 * n * ld * 8.0 + (double)p->P * p->ncam * 24.0 + 1e9;
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     const double have = (double)free_b + (p->d_Sdense ? (double)n * ld * 8.0 : 0.0);
-    if (need > have)
-      return fail(BA_ERR_UNSUPPORTED, "ba_covariance: reduced system of order %d: the dense inverse needs %.1f GB, %.1f GB are free "
-                  "(ba_covariance_cameras gives the camera parameters at any size)", n, need * 1e-9, have * 1e-9);
+    dense_fits = need <= have;
+    if (!dense_fits && p->cov_route == 1)
+      return fail(BA_ERR_UNSUPPORTED, "ba_covariance: reduced system of order %d: the dense inverse needs %.1f GB, %.1f GB are free", n,
+                  need * 1e-9, have * 1e-9);
+    // left to choose: the dissection when the dense inverse does not fit, and from order 16384 on, where it is the
+    // faster of the two (0.5 s against 5.7 s at order 60 007); the dense inverse is the fallback while it fits
+    if (p->cov_route == 0 && (!dense_fits || (n >= 16384 && p->explicit_ok && p->S > 0))) selected = true;
   }
+  if (selected && (!p->explicit_ok || p->S < 1))
+    return fail(BA_ERR_UNSUPPORTED, "ba_covariance: the dissection route needs the reduced system in blocks (a network with stations whose "
+                "camera blocks fit the block kernels); ba_covariance_cameras gives the camera parameters at any size");
   hipStream_t s = p->stream;
   ba_options opt;
   ba_default_options(&opt);
@@ -2017,15 +2046,6 @@ int ba_covariance(ba_problem *p, double *var_eop, double *var_xyz, double *var_i
   st.full_rows = true;  // the point variances are formed from the rows
   BA_TRY(linearize(p, st));
   std::vector<double> cs((size_t)std::max(n, 1), 0.0), vx(3 * (size_t)std::max(p->P, 1), 0.0);
-  if (n > 0) {
-    BA_TRY(build_dense(p, use_explicit));
-    launch_dense_fix_unused(s, p->S, p->dense_ld, p->d_sta_used, p->d_Sdense);
-    BA_TRY(factor_dense(p));
-    int info = 0;
-    HIP_OK(hipMemcpyAsync(&info, p->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_OK(hipStreamSynchronize(s));
-    if (info) return fail(BA_ERR_NUMERIC, "ba_covariance: the reduced normal matrix is rank deficient (column %d of %d)", info - 1, n);
-  }
   double *d_inv = nullptr, *d_tc = nullptr, *d_vx = nullptr, *d_cs = nullptr, *d_T = nullptr;
   auto cleanup = [&]() {
     if (d_inv) (void)hipFree(d_inv);
@@ -2034,29 +2054,73 @@ int ba_covariance(ba_problem *p, double *var_eop, double *var_xyz, double *var_i
     if (d_cs) (void)hipFree(d_cs);
     if (d_T) (void)hipFree(d_T);
   };
-  const size_t nn = (size_t)std::max(n, 1), ld = (size_t)std::max(p->dense_ld, 1);
-  if (hipMalloc((void **)&d_inv, nn * ld * sizeof(double)) != hipSuccess ||
-      hipMalloc((void **)&d_tc, std::max<size_t>((size_t)p->P * p->ncam * 3, 1) * sizeof(double)) != hipSuccess ||
-      hipMalloc((void **)&d_vx, vx.size() * sizeof(double)) != hipSuccess || hipMalloc((void **)&d_cs, nn * sizeof(double)) != hipSuccess ||
-      (p->dense_blocked && hipMalloc((void **)&d_T, 128 * ld * sizeof(double)) != hipSuccess)) {
-    cleanup();
-    return fail(BA_ERR_DEVICE, "ba_covariance: out of device memory");
-  }
-  const double *d_Sinv = d_inv;
-  if (n > 0 && p->dense_blocked) {
-    // the inverse replaces the factor in place; d_inv is the work matrix U = L^-T
-    launch_chol_inverse_blocked(s, p->d_Sdense, n, p->dense_ld, p->d_cholW, d_inv, d_T);
-    d_Sinv = p->d_Sdense;
-  } else {
-    launch_chol_inverse(s, p->d_Sdense, n, d_inv);
-  }
+  const size_t nn = (size_t)std::max(n, 1);
   CovArgs ca{};
-  ca.P = p->P; ca.S = p->S; ca.n = n; ca.ncmax = p->ncmax; ca.ld = p->dense_ld;
+  ca.P = p->P; ca.S = p->S; ca.n = n; ca.ncmax = p->ncmax;
   ca.pt_start = p->d_pt_start; ca.obs_sta = p->d_obs_sta; ca.sta_cam = p->d_sta_cam; ca.sta_used = p->d_sta_used; ca.pt_file = p->d_pt_file;
-  ca.rec = p->d_rec; ca.Jp = p->d_Jp; ca.Jc = p->d_Jc; ca.Vinv = p->d_Vinv; ca.Sinv = d_Sinv;
+  ca.rec = p->d_rec; ca.Jp = p->d_Jp; ca.Jc = p->d_Jc; ca.Vinv = p->d_Vinv;
   ca.scale_pt = p->d_scale_pt; ca.scale_sta = p->d_scale_sta; ca.scale_cam = p->d_scale_cam; ca.cam = p->d_cam;
-  ca.Tc = d_tc; ca.var_xyz = d_vx; ca.var_cs = d_cs;
-  launch_cov(s, ca);
+  p->cov_route_used = selected ? 2 : 1;
+  p->cov_stats = SelInvStats{};
+  if (selected) {
+    if (hipMalloc((void **)&d_tc, std::max<size_t>((size_t)p->P * p->ncam * 3, 1) * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&d_vx, vx.size() * sizeof(double)) != hipSuccess || hipMalloc((void **)&d_cs, nn * sizeof(double)) != hipSuccess) {
+      cleanup();
+      return fail(BA_ERR_DEVICE, "ba_covariance: out of device memory");
+    }
+    ca.Tc = d_tc; ca.var_xyz = d_vx; ca.var_cs = d_cs;
+    SelInvArgs sa{};
+    sa.stream = s; sa.S = p->S; sa.ncam = p->ncam;
+    sa.bsr_rowptr_h = p->bsr_rowptr_h.data(); sa.bsr_col_h = p->bsr_col_h.data(); sa.sta_used_h = p->sta_used_h.data();
+    sa.d_bsr_rowptr = p->d_bsr_rowptr; sa.d_bsr_col = p->d_bsr_col; sa.d_bsr_val = p->d_bsr_val; sa.d_Ssc = p->d_Ssc; sa.d_Scc = p->d_Scc;
+    sa.max_cluster = p->cov_max_cluster; sa.cov = ca; sa.d_info = p->d_info;
+    std::string why;
+    const int rc = covariance_selected(sa, why, &p->cov_stats);
+    if (rc == 1 && p->cov_route == 0 && dense_fits) {
+      selected = false;  // a station graph without separators: the dense inverse after all
+      p->cov_route_used = 1;
+    } else if (rc) {
+      (void)hipStreamSynchronize(s);
+      cleanup();
+      if (rc == 1) return fail(BA_ERR_UNSUPPORTED, "ba_covariance: reduced system of order %d, dissection route: %s "
+                               "(ba_covariance_cameras gives the camera parameters at any size)", n, why.c_str());
+      if (rc == 3) return fail(BA_ERR_NUMERIC, "ba_covariance: %s", why.c_str());
+      return fail(BA_ERR_DEVICE, "ba_covariance: %s", why.c_str());
+    }
+  }
+  if (!selected) {
+    if (d_tc) { (void)hipFree(d_tc); d_tc = nullptr; }
+    if (d_vx) { (void)hipFree(d_vx); d_vx = nullptr; }
+    if (d_cs) { (void)hipFree(d_cs); d_cs = nullptr; }
+    if (n > 0) {
+      BA_TRY(build_dense(p, use_explicit));
+      launch_dense_fix_unused(s, p->S, p->dense_ld, p->d_sta_used, p->d_Sdense);
+      BA_TRY(factor_dense(p));
+      int info = 0;
+      HIP_OK(hipMemcpyAsync(&info, p->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIP_OK(hipStreamSynchronize(s));
+      if (info) return fail(BA_ERR_NUMERIC, "ba_covariance: the reduced normal matrix is rank deficient (column %d of %d)", info - 1, n);
+    }
+    const size_t ld = (size_t)std::max(p->dense_ld, 1);
+    if (hipMalloc((void **)&d_inv, nn * ld * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&d_tc, std::max<size_t>((size_t)p->P * p->ncam * 3, 1) * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&d_vx, vx.size() * sizeof(double)) != hipSuccess || hipMalloc((void **)&d_cs, nn * sizeof(double)) != hipSuccess ||
+        (p->dense_blocked && hipMalloc((void **)&d_T, 128 * ld * sizeof(double)) != hipSuccess)) {
+      cleanup();
+      return fail(BA_ERR_DEVICE, "ba_covariance: out of device memory");
+    }
+    const double *d_Sinv = d_inv;
+    if (n > 0 && p->dense_blocked) {
+      // the inverse replaces the factor in place; d_inv is the work matrix U = L^-T
+      launch_chol_inverse_blocked(s, p->d_Sdense, n, p->dense_ld, p->d_cholW, d_inv, d_T);
+      d_Sinv = p->d_Sdense;
+    } else {
+      launch_chol_inverse(s, p->d_Sdense, n, d_inv);
+    }
+    ca.ld = p->dense_ld; ca.Sinv = d_Sinv;
+    ca.Tc = d_tc; ca.var_xyz = d_vx; ca.var_cs = d_cs;
+    launch_cov(s, ca);
+  }
   hipError_t e1 = hipMemcpyAsync(vx.data(), d_vx, vx.size() * sizeof(double), hipMemcpyDeviceToHost, s);
   hipError_t e2 = hipMemcpyAsync(cs.data(), d_cs, nn * sizeof(double), hipMemcpyDeviceToHost, s);
   hipError_t e3 = hipStreamSynchronize(s);

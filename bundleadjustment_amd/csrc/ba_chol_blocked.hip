@@ -660,4 +660,48 @@ void launch_chol_inverse_blocked(hipStream_t s, double *A, int n, int ld, const 
   hipLaunchKernelGGL(k_gemm_nt<GEMM_INV_S>, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, g);
 }
 
+// C = (accumulate ? C : 0) + alpha A B^T for any row-major operands with the summation index contiguous: A am x k,
+// B bm x k, C am x bm; one workgroup per 128 x 128 tile of C.  lda and ldb are even and the column after an odd k
+// holds zero.
+struct GemmNtArgs {
+  const double *A, *B;
+  double *C;
+  int lda, ldb, ldc, am, bm, k;
+  double alpha;
+  int accumulate;
+};
+
+__global__ void __launch_bounds__(256, 2)
+k_gemm_nt_general(GemmNtArgs g) {
+  __shared__ double sA[KC * LDT], sB[KC * LDT];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wr = w >> 1, wc = w & 1, lr = lane & 15, lk = lane >> 4;
+  d4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int r0 = CB * blockIdx.x, c0 = CB * blockIdx.y;
+  gemm_tile_nt(g.A, g.lda, r0, g.am, g.B, g.ldb, c0, g.bm, 0, g.k, sA, sB, acc);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int r = r0 + 64 * wr + 16 * a + lk + 4 * reg, cc = c0 + 64 * wc + 16 * c + lr;
+        if (r >= g.am || cc >= g.bm) continue;
+        double *dst = g.C + (int64_t)r * g.ldc + cc;
+        const double v = g.alpha * acc[a][c][reg];
+        *dst = g.accumulate ? *dst + v : v;
+      }
+}
+
+void launch_gemm_nt(hipStream_t s, const double *A, int lda, int am, const double *B, int ldb, int bm, int k, double alpha,
+                    bool accumulate, double *C, int ldc) {
+  if (am <= 0 || bm <= 0) return;
+  GemmNtArgs g{A, B, C, lda, ldb, ldc, am, bm, k, alpha, accumulate ? 1 : 0};
+  hipLaunchKernelGGL(k_gemm_nt_general, dim3((am + CB - 1) / CB, (bm + CB - 1) / CB), dim3(256), 0, s, g);
+}
+
 }  // namespace ba

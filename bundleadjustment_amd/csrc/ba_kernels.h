@@ -307,6 +307,10 @@ void launch_cholesky_blocked(hipStream_t s, double *A, int n, int ld, double *W,
 void launch_chol_solve_blocked(hipStream_t s, const double *L, int n, int ld, const double *W, double *b);
 // A: the factor on entry, (L L^T)^-1 as a full symmetric matrix on return; U: n x ld work matrix, T: 128 x ld
 void launch_chol_inverse_blocked(hipStream_t s, double *A, int n, int ld, const double *W, double *U, double *T);
+// C = (accumulate ? C : 0) + alpha A B^T on the matrix cores: A am x k, B bm x k, C am x bm, all row-major; lda and ldb
+// even, the column after an odd k holds zero, A and B 16-byte aligned
+void launch_gemm_nt(hipStream_t s, const double *A, int lda, int am, const double *B, int ldb, int bm, int k, double alpha,
+                    bool accumulate, double *C, int ldc);
 void launch_chol_solve(hipStream_t s, const double *L, int n, double *b);
 void launch_chol_inverse(hipStream_t s, const double *L, int n, double *B);  // B = (L L^T)^-1, n x n
 
@@ -320,8 +324,31 @@ struct CovArgs {
   double *Tc;       // work: [P x ncam x 3]
   double *var_xyz;  // [3P], file order
   double *var_cs;   // [n]: stations then camera columns
+  // Sinv as a local matrix: S local stations (sta_loc: station -> local index), then the camera columns; only the points
+  // with pt_home[jj] == home are computed.  Null pointers: Sinv is the whole inverse.
+  const int *sta_loc, *pt_home;
+  int home;
 };
 void launch_cov(hipStream_t s, const CovArgs &a);
+void launch_cov_points(hipStream_t s, const CovArgs &a);
+
+// ba_cov_select.hip: the same variances from one level of nested dissection of the station graph, for reduced systems
+// whose dense inverse does not fit.  Returns 0, 1 (not applicable: no separators / not enough memory), 2 (device
+// failure) or 3 (rank deficient); err says why.
+struct SelInvArgs {
+  hipStream_t stream;
+  int S, ncam;
+  const int *bsr_rowptr_h, *bsr_col_h, *sta_used_h;  // host copies of the block pattern
+  const int *d_bsr_rowptr, *d_bsr_col;
+  const double *d_bsr_val, *d_Ssc, *d_Scc;
+  int max_cluster;  // stations per cluster at most
+  CovArgs cov;      // the point kernel's arguments and the outputs var_xyz / var_cs; Sinv, ld, S, n are set per cluster
+  int *d_info;
+};
+struct SelInvStats {
+  int clusters, boundary_stations, boundary_order, largest_cluster_order;
+};
+int covariance_selected(const SelInvArgs &a, std::string &err, SelInvStats *stats);
 void launch_dense_fix_unused(hipStream_t s, int S, int ld, const int *sta_used, double *A);
 
 }  // namespace ba

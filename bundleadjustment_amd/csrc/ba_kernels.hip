@@ -1774,6 +1774,7 @@ __global__ void __launch_bounds__(64)
 k_cov_points(CovArgs a) {
   const int jj = blockIdx.x * blockDim.x + threadIdx.x;
   if (jj >= a.P) return;
+  if (a.pt_home && a.pt_home[jj] != a.home) return;  // another local matrix holds this point's blocks
   const int e0 = a.pt_start[jj], e1 = a.pt_start[jj + 1];
   const int ns = 6 * a.S, ncam = a.n - ns;
   const double *vi = a.Vinv + 6 * (int64_t)jj;
@@ -1792,15 +1793,15 @@ k_cov_points(CovArgs a) {
   for (int ea = e0; ea < e1; ++ea) {
     double Ta[6][3], Qa[2][3];
     station_part(ea, Ta, Qa);
-    const int ia = a.obs_sta[ea];
-    const int c = a.sta_cam[ia], nc = a.cam[c].nc, off = a.cam[c].off;
+    const int sa = a.obs_sta[ea], ia = a.sta_loc ? a.sta_loc[sa] : sa;
+    const int c = a.sta_cam[sa], nc = a.cam[c].nc, off = a.cam[c].off;
     const double *jc = a.Jc + 2 * (int64_t)a.ncmax * ea;
     for (int k = 0; k < nc; ++k)
       for (int m = 0; m < 3; ++m) Tc[3 * (off + k) + m] += jc[k] * Qa[0][m] + jc[a.ncmax + k] * Qa[1][m];
     for (int eb = e0; eb < e1; ++eb) {
       double Tb[6][3], Qb[2][3];
       station_part(eb, Tb, Qb);
-      const int ib = a.obs_sta[eb];
+      const int sb = a.obs_sta[eb], ib = a.sta_loc ? a.sta_loc[sb] : sb;
       for (int r = 0; r < 6; ++r) {
         const double *row = a.Sinv + (int64_t)(6 * ia + r) * a.ld + 6 * ib;
         double u[3] = {0, 0, 0};  // row r of Sinv[ia, ib] times T_b
@@ -1815,7 +1816,7 @@ k_cov_points(CovArgs a) {
   for (int ea = e0; ea < e1; ++ea) {
     double Ta[6][3], Qa[2][3];
     station_part(ea, Ta, Qa);
-    const int ia = a.obs_sta[ea];
+    const int sa = a.obs_sta[ea], ia = a.sta_loc ? a.sta_loc[sa] : sa;
     for (int r = 0; r < 6; ++r) {
       const double *row = a.Sinv + (int64_t)(6 * ia + r) * a.ld + ns;
       double u[3] = {0, 0, 0};
@@ -1853,6 +1854,9 @@ void launch_station_prep(hipStream_t s, int S, const double *eop, const double *
 }
 void launch_cov(hipStream_t s, const CovArgs &a) {
   if (a.n > 0) hipLaunchKernelGGL(k_cov_camside, dim3(nblk(a.n, 256)), dim3(256), 0, s, a);
+  if (a.P > 0) hipLaunchKernelGGL(k_cov_points, dim3(nblk(a.P, 64)), dim3(64), 0, s, a);
+}
+void launch_cov_points(hipStream_t s, const CovArgs &a) {
   if (a.P > 0) hipLaunchKernelGGL(k_cov_points, dim3(nblk(a.P, 64)), dim3(64), 0, s, a);
 }
 void launch_dense_fix_unused(hipStream_t s, int S, int ld, const int *sta_used, double *A) {

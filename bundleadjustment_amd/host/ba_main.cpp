@@ -169,7 +169,8 @@ static void usage() {
           "        --pcg-rows: whether the ranks split the rows of the product inside the block-sparse PCG (one more sum per\n"
           "        PCG iteration); auto: when the network is large enough for that to pay.\n"
           "  --covariance: standard deviations of all parameters in the result files (the reference's COMPUTECX\n"
-          "        branch, src/main.cpp:5261); small networks only.\n");
+          "        branch, src/main.cpp:5261): from the dense inverse of the reduced system while it fits the device, from a\n"
+          "        dissection of the station graph beyond (networks of 50 000 stations take seconds).\n");
 }
 
 int main(int argc, char **argv) {
@@ -348,7 +349,8 @@ int main(int argc, char **argv) {
     std::vector<double> ve(6 * (size_t)d.n_sta + 1), vx(3 * (size_t)d.n_pts + 1), vi(3 * (size_t)d.n_cam + 1), va(16 * (size_t)d.n_cam + 1);
     const int rc = ba_covariance(p, ve.data(), vx.data(), vi.data(), va.data());
     if (rc == BA_ERR_UNSUPPORTED) {
-      // too large for the dense inverse: the camera parameters only, the other files keep the default sigma
+      // neither route applies (no block-sparse reduced system, or a station graph without separators): the camera
+      // parameters only, the other files keep the default sigma
       printf("  %s: standard deviations of the camera parameters only\n", ba_last_error());
       if (ba_covariance_cameras(p, vi.data(), va.data())) { fprintf(stderr, "error: %s\n", ba_last_error()); return 1; }
       ba_net_set_variances(net, nullptr, nullptr, vi.data(), va.data());

@@ -267,11 +267,31 @@ int ba_evaluate(ba_problem *p, const double *eop, const double *xyz, const doubl
  * var_eop [6*n_sta], var_xyz [3*n_pts], var_iop [3*n_cam], var_ap [16*n_cam] (any may be NULL);
  * parameters held constant and stations without observations get 0.  The reference multiplies by
  * aposterioriVariance, which it has reset to 1 at :4955, so the values are not scaled here either.
- * Computed from the inverse of the dense reduced camera system: networks with 6*n_sta + free camera
- * parameters <= 8192 only (BA_ERR_UNSUPPORTED beyond).  A rank-deficient network is an error
- * (the reference's DENSE_SVD pseudo-inverse would truncate it instead).
+ * Two routes, both on the reduced camera system with the points eliminated.  While the reduced matrix
+ * (order 6*n_sta + free camera parameters) and a work matrix of the same size fit the device memory that
+ * is free, its dense inverse is formed on the matrix cores.  Beyond that, the station graph is cut into
+ * clusters by level-set separators and only the blocks of the inverse that the variances need are formed
+ * (cluster inverses, the Schur complement on the separator stations and the camera columns, and the
+ * update of the cluster blocks from its inverse); this needs the block-sparse reduced system and a
+ * station graph that has separators, BA_ERR_UNSUPPORTED otherwise.  A rank-deficient network is an
+ * error (the reference's DENSE_SVD pseudo-inverse would truncate it instead).
  */
 int ba_covariance(ba_problem *p, double *var_eop, double *var_xyz, double *var_iop, double *var_ap);
+
+/*
+ * Which route ba_covariance takes: 0 chooses (the default: the dissection when the dense inverse does not
+ * fit the free memory and from order 16384 on, where it is the faster one; the dense inverse otherwise and
+ * for station graphs without separators), 1 the dense inverse only, 2 the dissection at any size.  max_cluster_stations bounds the stations per cluster of route 2
+ * (0: the default, 1536).  No counterpart in the reference, whose ceres::Covariance call has one route.
+ */
+int ba_set_covariance_route(ba_problem *p, int32_t route, int32_t max_cluster_stations);
+
+/*
+ * What the last ba_covariance call did: the route (1 or 2) and, for route 2, the number of clusters, the
+ * order of the boundary system and the order of the largest cluster (any pointer may be NULL).
+ */
+int ba_covariance_stats(const ba_problem *p, int32_t *route_used, int32_t *clusters, int32_t *boundary_order,
+                        int32_t *largest_cluster_order);
 
 /*
  * The camera part of the same: variances of xp, yp, c [3*n_cam] and of the additional parameters [16*n_cam] only

@@ -109,21 +109,66 @@ def test_full_size_properties(name):
         eop, xyz, iop, ap = P.get_parameters()
         assert np.sqrt(np.mean((xyz - t["xyz"]) ** 2)) < np.sqrt(np.mean((net.xyz - t["xyz"]) ** 2))
         if name == "cfg5":
-            # variances at this size: the dense inverse of the reduced system (order 300 007, two matrices of 720 GB) is
-            # refused with a message; the camera parameters' variances come from one PCG solve per camera column
-            with pytest.raises(solver.BaError) as e:
-                P.covariance()
-            assert e.value.code == capi.ERR_UNSUPPORTED
+            # variances at this size: the dense inverse of the reduced system (order 300 007, two matrices of 720 GB) does
+            # not fit, so ba_covariance cuts the station graph into clusters and inverts those and the boundary system;
+            # the camera parameters' variances also come from one PCG solve per camera column, to compare
+            import time
+            t0 = time.time()
+            ve, vx, di, da = P.covariance()
+            st = P.covariance_stats()
+            print(f"cfg5 variances by dissection: {time.time() - t0:.1f} s, {st}")
+            assert st["route"] == 2 and st["clusters"] >= 32 and st["largest_cluster_order"] <= 6 * 1536
             vi, va = P.covariance_cameras()
             k = [2, 3, 5, 6]  # k1 k2 p1 p2
             assert np.all(np.isfinite(vi)) and np.all(vi > 0.0) and np.all(va[0, k] > 0.0) and np.all(np.delete(va[0], k) == 0.0)
+            assert np.all(np.abs(di - vi) <= 1e-6 * vi) and np.all(np.abs(da[0, k] - va[0, k]) <= 1e-6 * va[0, k])
+            assert np.all(np.delete(da[0], k) == 0.0)
             # five times the observations of the 10M network, same geometry: the camera is known better, not worse
             assert np.all(np.sqrt(vi) < 1e-1)
+            assert ve.shape == (S, 6) and np.all(np.isfinite(ve)) and np.all(ve > 0.0)
+            assert vx.shape == (Pn, 3) and np.all(np.isfinite(vx)) and np.all(vx > 0.0)
+            assert np.all(vx <= net.pt_sigma ** 2 * (1.0 + 1e-9))       # an observation can only add information
+            # stations in the middle of the block are held by neighbours on every side: better known than the median edge station
+            gx = int(np.ceil(np.sqrt(S)))
+            ix, iy = np.arange(S) % gx, np.arange(S) // gx
+            edge = (ix < 2) | (iy < 2) | (ix >= gx - 2) | (iy >= (S - 1) // gx - 1)
+            assert np.median(ve[~edge, 3:].sum(axis=1)) < np.median(ve[edge, 3:].sum(axis=1))
         if name == "cfg3":
             assert np.array_equal(iop, net.iop) and np.array_equal(ap, net.ap)  # constant blocks stay
             nr, nc, rws, cols = P.sparsity()
             assert nr == 2 * N + 3 * Pn + 3 and nc == 6 * S + 3 * Pn + 3 + 16
             assert rws[-1] == 2 * N * (6 + 3) + 9 * Pn
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name", ["cfg3", "cfg4"])
+def test_full_size_dissection_equals_dense_inverse(name):
+    # 1800 stations (reduced order 10 800) and 10 000 stations (order 60 007): both fit the dense inverse, so the
+    # dissection route can be held against it entry by entry: all station, camera and point variances to 1e-8
+    import time
+    hn = host.synth_config(name, outlier_fraction=0.0)
+    net = hn.net
+    with solver.Problem(net) as P:
+        opt = solver.default_options()
+        opt.max_num_iterations = 3
+        P.set_parameters()
+        P.solve_resident(opt)
+        P.covariance_route(1)
+        t0 = time.time()
+        dense = P.covariance()
+        t1 = time.time()
+        P.covariance_route(2)
+        sel = P.covariance()
+        t2 = time.time()
+        st = P.covariance_stats()
+    print(f"{name}: dense inverse {t1 - t0:.1f} s, dissection {t2 - t1:.1f} s, {st}")
+    assert st["route"] == 2 and st["clusters"] >= 2
+    for g, w, what in zip(sel, dense, ("eop", "xyz", "iop", "ap")):
+        assert np.array_equal(g == 0.0, w == 0.0), what
+        nz = w != 0.0
+        if nz.any():
+            err = np.abs(g[nz] - w[nz]) / w[nz]
+            assert np.all(err <= 1e-8), (what, float(err.max()))
 
 
 @pytest.mark.timeout(600)

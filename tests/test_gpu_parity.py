@@ -300,10 +300,11 @@ def test_blocked_cholesky_solve_and_covariance_against_the_oracle(n_sta):
 
 
 def test_covariance_too_large_is_refused():
-    # 50 000 stations: the dense inverse would need 2 x 720 GB
+    # 50 000 stations: the dense inverse would need 2 x 720 GB; asked for that route only, the call says so
     net = host.synth(n_cam=1, n_sta=50000, n_pts=60000, rays_per_point=3, seed=1).net
     with solver.Problem(net) as P:
         P.set_parameters()
+        P.covariance_route(1)
         with pytest.raises(solver.BaError) as e:
             P.covariance()
         assert e.value.code == capi.ERR_UNSUPPORTED
