@@ -75,6 +75,7 @@ SOLVER_DENSE_SCHUR = 0
 SOLVER_PCG_SCHUR = 1
 SOLVER_PCG_IMPLICIT = 2
 SOLVER_AUTO = 3
+SOLVER_SPARSE_SCHUR = 4
 AUTO_DENSE_ORDER = 4096
 CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
 ERR_INVALID, ERR_DEVICE, ERR_NUMERIC, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -4, -5

@@ -138,6 +138,8 @@ struct ba_problem {
   double *d_Y = nullptr, *d_bsr_val = nullptr, *d_Sdiag = nullptr, *d_Jt = nullptr, *d_corner = nullptr, *d_campart = nullptr, *d_elim = nullptr;
   double *d_part_pq = nullptr, *d_part_qc = nullptr, *d_part_rz = nullptr, *d_cg2scal = nullptr;
   std::vector<int> ub_lo_h, ub_hi_h, bsr_rowptr_h, bsr_col_h;  // host copies of the block structure
+  SparseChol *sparse = nullptr;  // BA_SOLVER_SPARSE_SCHUR: the tree and the fronts, built at the first solve
+  bool sparse_failed = false;
   int cov_route = 0, cov_max_cluster = 1536, cov_route_used = 0;  // ba_set_covariance_route / ba_covariance_stats
   SelInvStats cov_stats{};
   std::vector<int> cam_used_h;
@@ -1402,6 +1404,31 @@ int solve_dense(ba_problem *p, bool explicit_blocks) {
   return 0;
 }
 
+// Sparse direct solve of the block-sparse reduced system (its blocks carry the LM diagonal already)
+int solve_sparse(ba_problem *p) {
+  hipStream_t s = p->stream;
+  if (!p->sparse) {
+    p->sparse = sparse_chol_create();
+    std::string why;
+    int leaf = 21;  // stations per leaf: 126 unknowns, one panel
+    const int rc = sparse_chol_analyse(p->sparse, p->S, p->ncam, p->bsr_rowptr_h, p->bsr_col_h, p->sta_used_h, leaf, why);
+    if (rc) {
+      sparse_chol_destroy(p->sparse);
+      p->sparse = nullptr;
+      return fail(rc == 1 ? BA_ERR_UNSUPPORTED : BA_ERR_DEVICE, "sparse Cholesky of the reduced system: %s", why.c_str());
+    }
+  }
+  sparse_chol_factor(p->sparse, s, p->d_bsr_val, p->d_Ssc, p->d_Scc, p->d_info);
+  HIP_OK(hipMemsetAsync(p->d_x, 0, (size_t)p->nr * sizeof(double), s));  // stations outside the program keep a zero step
+  sparse_chol_solve(p->sparse, s, p->d_b, p->d_x);
+  int info = 0;
+  HIP_OK(hipMemcpyAsync(&info, p->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  BA_TRY(p->check_kernels());
+  if (info) return fail(BA_ERR_NUMERIC, "sparse Cholesky of the reduced system: a pivot is not positive");
+  return 0;
+}
+
 int make_candidate(ba_problem *p, double alpha, bool reduce = true);
 int cost_local(ba_problem *p, const double *eop, const double *xyz, const CamRec *cam, double *sta_buf, int slot, int apply_loss,
                double *res_out);
@@ -1601,6 +1628,7 @@ void ba_destroy(ba_problem *p) {
   if (p->cg_graph) hipGraphExecDestroy(p->cg_graph);
   if (p->cg_graph_tail) hipGraphExecDestroy(p->cg_graph_tail);
   if (p->amg) ba::amg_destroy(p->amg);
+  if (p->sparse) ba::sparse_chol_destroy(p->sparse);
   for (void *q : p->allocs) hipFree(q);
   if (p->h_scal) hipHostFree(p->h_scal);
   if (p->h_cgscal) hipHostFree(p->h_cgscal);
@@ -1780,8 +1808,11 @@ int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary,
   if (!p->have_params) return fail(BA_ERR_INVALID, "ba_solve_resident: call ba_set_parameters first");
   int linear_solver = opt->linear_solver;
   if (linear_solver == BA_SOLVER_AUTO) linear_solver = p->nr <= BA_AUTO_DENSE_ORDER ? BA_SOLVER_DENSE_SCHUR : BA_SOLVER_PCG_SCHUR;
-  if (linear_solver != BA_SOLVER_DENSE_SCHUR && linear_solver != BA_SOLVER_PCG_SCHUR && linear_solver != BA_SOLVER_PCG_IMPLICIT)
+  if (linear_solver != BA_SOLVER_DENSE_SCHUR && linear_solver != BA_SOLVER_PCG_SCHUR && linear_solver != BA_SOLVER_PCG_IMPLICIT &&
+      linear_solver != BA_SOLVER_SPARSE_SCHUR)
     return fail(BA_ERR_UNSUPPORTED, "linear_solver %d", opt->linear_solver);
+  if (linear_solver == BA_SOLVER_SPARSE_SCHUR && !p->explicit_ok)
+    return fail(BA_ERR_UNSUPPORTED, "BA_SOLVER_SPARSE_SCHUR needs the reduced system in block-sparse form (this network's is too dense for it)");
   // The kernels of the explicit block-sparse PCG hold the camera columns in LDS arrays of fixed size: a network with
   // more free camera parameters than they take (many cameras) runs the same PCG on the matrix-free operator instead.
   const bool pcg_too_wide = linear_solver == BA_SOLVER_PCG_SCHUR && p->ncam > cg2_max_cam();
@@ -1878,6 +1909,7 @@ int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary,
     int lin_iters = 0;
     int lrc;
     if (linear_solver == BA_SOLVER_DENSE_SCHUR) lrc = solve_dense(p, use_explicit);
+    else if (linear_solver == BA_SOLVER_SPARSE_SCHUR) lrc = solve_sparse(p);
     else if (use_explicit) lrc = solve_pcg_explicit(p, opt, &lin_iters);
     else lrc = solve_pcg(p, opt, &lin_iters);
     it.linear_iterations = lin_iters;
@@ -1992,6 +2024,21 @@ int ba_solve(ba_problem *p, const ba_options *opt, double *eop, double *xyz, dou
   BA_TRY(ba_set_parameters(p, eop, xyz, iop, ap));
   BA_TRY(ba_solve_resident(p, opt, summary, rows, rows_cap));
   return ba_get_parameters(p, eop, xyz, iop, ap);
+}
+
+int ba_sparse_solver_stats(const ba_problem *p, int32_t *fronts, int32_t *levels, int32_t *largest_front, int32_t *critical_panels,
+                           double *front_bytes, double *factor_flops) {
+  if (!p) return fail(BA_ERR_INVALID, "ba_sparse_solver_stats: null problem");
+  if (!p->sparse) return fail(BA_ERR_INVALID, "ba_sparse_solver_stats: no solve with BA_SOLVER_SPARSE_SCHUR has run on this problem");
+  SparseCholStats st;
+  sparse_chol_stats(p->sparse, &st);
+  if (fronts) *fronts = st.fronts;
+  if (levels) *levels = st.levels;
+  if (largest_front) *largest_front = st.largest_front;
+  if (critical_panels) *critical_panels = st.critical_panels;
+  if (front_bytes) *front_bytes = st.arena_bytes;
+  if (factor_flops) *factor_flops = st.factor_flops;
+  return 0;
 }
 
 int ba_set_covariance_route(ba_problem *p, int32_t route, int32_t max_cluster_stations) {
@@ -2590,6 +2637,10 @@ static int sync_shards(ba_problem *p) {
   if (p->amg) {  // built on the old pattern
     amg_destroy(p->amg);
     p->amg = nullptr;
+  }
+  if (p->sparse) {
+    sparse_chol_destroy(p->sparse);
+    p->sparse = nullptr;
   }
   p->have_G = false;
   return 0;

@@ -99,9 +99,7 @@ __device__ __forceinline__ void tri_tile(int b, int &ti, int &tj) {
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(256, 2)  // two workgroups per CU: one multiplies while the other waits for its loads
-k_gemm_nt(GemmArgs g) {
-  __shared__ double sA[KC * LDT], sB[KC * LDT];
+__device__ __forceinline__ void gemm_nt_block(const GemmArgs &g, const int bx, double *sA, double *sB) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wr = w >> 1, wc = w & 1, lr = lane & 15, lk = lane >> 4;
   d4 acc[4][4];
@@ -116,14 +114,14 @@ k_gemm_nt(GemmArgs g) {
   bool lower_only = false;
   if (MODE == GEMM_TRSM) {
     // X = A[r0 .., k0 .. k0+kw) W^T, in place (a workgroup reads its rows completely before it writes them)
-    r0 = g.k0 + g.kw + CB * blockIdx.x;
+    r0 = g.k0 + g.kw + CB * bx;
     gemm_tile_nt(g.A + g.k0, ld, r0, n, g.W, CB, 0, g.kw, 0, g.kw, sA, sB, acc);
     C = g.A + g.k0;
     c0 = 0;
     cmax = g.kw;
   } else if (MODE == GEMM_SYRK) {
     int ti, tj;
-    tri_tile(blockIdx.x, ti, tj);
+    tri_tile(bx, ti, tj);
     const int t0 = g.k0 + g.kw;
     r0 = t0 + CB * ti;
     c0 = t0 + CB * tj;
@@ -134,7 +132,7 @@ k_gemm_nt(GemmArgs g) {
     lower_only = true;
   } else if (MODE == GEMM_INV_T) {
     // T^T[k-block rows][i-block cols] = sum_{j = k .. i-1} U[k, j] L[i, j]^T   (blocks of CB), one tile per k < ib
-    const int kblk = blockIdx.x;
+    const int kblk = bx;
     r0 = CB * kblk;
     gemm_tile_nt(g.U, ld, r0, n, g.A, ld, CB * g.ib, n, CB * kblk, CB * g.ib, sA, sB, acc);
     // T (CB x ld) holds tile k as a CB x CB block at column CB k: rows = rows of block k, columns = rows of block ib
@@ -145,7 +143,7 @@ k_gemm_nt(GemmArgs g) {
     cmax = CB * kblk + min(CB, n - CB * g.ib);
   } else if (MODE == GEMM_INV_U) {
     // U[k, ib] = - T^T[k] W_ib^T
-    const int kblk = blockIdx.x;
+    const int kblk = bx;
     gemm_tile_nt(g.T + CB * kblk, ld, 0, CB, g.W + (int64_t)g.ib * CB * CB, CB, 0, CB, 0, min(CB, n - CB * g.ib), sA, sB, acc);
     C = g.U;
     r0 = CB * kblk;
@@ -154,7 +152,7 @@ k_gemm_nt(GemmArgs g) {
   } else {
     // S^-1[a, b] = sum_{t >= a} U[a, t] U[b, t]^T over the lower tiles (a >= b); written to A (the factor is no longer needed)
     int ti, tj;
-    tri_tile(blockIdx.x, ti, tj);
+    tri_tile(bx, ti, tj);
     r0 = CB * ti;
     c0 = CB * tj;
     gemm_tile_nt(g.U, ld, r0, n, g.U, ld, c0, n, CB * ti, n, sA, sB, acc);
@@ -192,6 +190,13 @@ k_gemm_nt(GemmArgs g) {
         }
       }
   }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 2)  // two workgroups per CU: one multiplies while the other waits for its loads
+k_gemm_nt(GemmArgs g) {
+  __shared__ double sA[KC * LDT], sB[KC * LDT];
+  gemm_nt_block<MODE>(g, blockIdx.x, sA, sB);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -265,9 +270,8 @@ __device__ __forceinline__ void mfma_nn16(const double *xa, const double *pb, in
   }
 }
 
-__global__ void __launch_bounds__(256)
-k_chol_diag(double *__restrict__ A, int n, int ld, int k0, double *__restrict__ Wk, int *__restrict__ info) {
-  extern __shared__ double Tm[];  // CB x TS
+__device__ __forceinline__ void chol_diag_block(double *__restrict__ A, int n, int ld, int k0, double *__restrict__ Wk, int *__restrict__ info,
+                                                double *Tm) {  // Tm: CB x TS + CB doubles of LDS
   double *Il = Tm + CB * TS;      // CB: reciprocals of the diagonal of the factor
   const int kw = min(CB, n - k0);
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, lr = lane & 15, lk = lane >> 4;
@@ -491,6 +495,42 @@ k_chol_diag(double *__restrict__ A, int n, int ld, int k0, double *__restrict__ 
   }
 }
 
+__global__ void __launch_bounds__(256)
+k_chol_diag(double *__restrict__ A, int n, int ld, int k0, double *__restrict__ Wk, int *__restrict__ info) {
+  extern __shared__ double Tm[];  // CB x TS + CB
+  chol_diag_block(A, n, ld, k0, Wk, info, Tm);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the same three steps for many matrices at once: the fronts of one level of a sparse factorisation
+// ------------------------------------------------------------------------------------------------------------------
+// A front is a dense symmetric matrix of order m = nvp + nu (lower triangle, row-major, even ld) of which only the first
+// nv columns are eliminated; rows nv .. nvp are padding (nvp a multiple of CB: the rows that stay start on a panel
+// boundary), treated as identity rows by the diagonal step.  Panel kp of every front of the list in one launch; a front
+// with fewer panels has nothing to do.
+__global__ void __launch_bounds__(256)
+k_front_diag(const FrontDesc *__restrict__ fd, int kp, int *__restrict__ info) {
+  extern __shared__ double Tm[];
+  const FrontDesc f = fd[blockIdx.x];
+  const int k0 = CB * kp;
+  if (k0 >= f.nvp) return;
+  chol_diag_block(f.A, f.nv, f.ld, k0, f.W + (int64_t)kp * CB * CB, info, Tm);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 2)
+k_front_gemm(const FrontDesc *__restrict__ fd, int kp) {
+  __shared__ double sA[KC * LDT], sB[KC * LDT];
+  const FrontDesc f = fd[blockIdx.y];
+  const int k0 = CB * kp;
+  if (k0 >= f.nvp) return;
+  const int T = (f.m - k0 - CB + CB - 1) / CB;  // tiles of rows below the panel
+  if ((int)blockIdx.x >= (MODE == GEMM_TRSM ? T : T * (T + 1) / 2)) return;
+  GemmArgs g{};
+  g.A = f.A; g.W = f.W + (int64_t)kp * CB * CB; g.n = f.m; g.ld = f.ld; g.k0 = k0; g.kw = CB;
+  gemm_nt_block<MODE>(g, blockIdx.x, sA, sB);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // triangular solves with the factor and the inverted diagonal blocks, one launch per panel
 // ------------------------------------------------------------------------------------------------------------------
@@ -703,5 +743,23 @@ void launch_gemm_nt(hipStream_t s, const double *A, int lda, int am, const doubl
   GemmNtArgs g{A, B, C, lda, ldb, ldc, am, bm, k, alpha, accumulate ? 1 : 0};
   hipLaunchKernelGGL(k_gemm_nt_general, dim3((am + CB - 1) / CB, (bm + CB - 1) / CB), dim3(256), 0, s, g);
 }
+
+void launch_front_panels(hipStream_t s, const FrontDesc *fd, int n_fronts, int n_panels, int max_m, int *info) {
+  if (n_fronts <= 0) return;
+  const size_t lds = (size_t)(CB * TS + CB) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_front_diag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  for (int kp = 0; kp < n_panels; ++kp) {
+    hipLaunchKernelGGL(k_front_diag, dim3(n_fronts), dim3(256), lds, s, fd, kp, info);
+    const int T = (max_m - CB * kp - CB + CB - 1) / CB;  // of the largest front
+    if (T <= 0) continue;
+    hipLaunchKernelGGL(k_front_gemm<GEMM_TRSM>, dim3(T, n_fronts), dim3(256), 0, s, fd, kp);
+    hipLaunchKernelGGL(k_front_gemm<GEMM_SYRK>, dim3(T * (T + 1) / 2, n_fronts), dim3(256), 0, s, fd, kp);
+  }
+}
+int front_panel() { return CB; }
 
 }  // namespace ba

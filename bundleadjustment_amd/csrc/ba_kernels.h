@@ -311,6 +311,34 @@ void launch_chol_inverse_blocked(hipStream_t s, double *A, int n, int ld, const 
 // even, the column after an odd k holds zero, A and B 16-byte aligned
 void launch_gemm_nt(hipStream_t s, const double *A, int lda, int am, const double *B, int ldb, int bm, int k, double alpha,
                     bool accumulate, double *C, int ldc);
+// One front of a sparse factorisation: dense, order m = nvp + nu, the first nv columns eliminated (nvp = nv rounded up to
+// the panel width front_panel(), the rows between are padding), W the inverted diagonal blocks of its panels, f its part
+// of the right-hand side / solution.
+struct FrontDesc {
+  double *A, *W, *f;
+  double *g;          // [4 x nvp] partial sums of the backward solve
+  int nv, nvp, m, ld;
+  int parent;         // index of the parent's descriptor, -1 at the root
+  const int *up_map;  // [m - nvp] position in the parent's front of every row that stays
+  const int *vidx;    // [nvp] index in the global vector of every eliminated row, -1 for padding
+};
+// panels 0 .. n_panels-1 of every front of the list: diagonal block, rows below, trailing update (max_m: largest order)
+void launch_front_panels(hipStream_t s, const FrontDesc *fd, int n_fronts, int n_panels, int max_m, int *info);
+int front_panel();
+// ba_sparse_chol.hip: sparse direct Cholesky of the block-sparse reduced system (nested dissection, dense fronts)
+struct SparseChol;
+struct SparseCholStats {
+  int fronts, levels, leaves, largest_front, critical_panels;
+  double arena_bytes, factor_flops;
+};
+SparseChol *sparse_chol_create();
+void sparse_chol_destroy(SparseChol *sc);
+// structure, once per network; 0, 1 (does not fit / no valid tree: err says why) or 2 (device failure)
+int sparse_chol_analyse(SparseChol *sc, int S, int ncam, const std::vector<int> &rowptr, const std::vector<int> &col,
+                        const std::vector<int> &used, int leaf_stations, std::string &err);
+void sparse_chol_factor(SparseChol *sc, hipStream_t s, const double *bsr_val, const double *Ssc, const double *Scc, int *d_info);
+void sparse_chol_solve(SparseChol *sc, hipStream_t s, const double *b, double *x);  // entries of x outside the program are left alone
+void sparse_chol_stats(const SparseChol *sc, SparseCholStats *st);
 void launch_chol_solve(hipStream_t s, const double *L, int n, double *b);
 void launch_chol_inverse(hipStream_t s, const double *L, int n, double *B);  // B = (L L^T)^-1, n x n
 

@@ -23,7 +23,7 @@ EXPORTS = ("ba_default_options", "ba_create", "ba_destroy", "ba_set_parameters",
            "ba_solve_resident", "ba_solve", "ba_evaluate", "ba_covariance", "ba_sparsity", "ba_residual_jacobian", "ba_time_kernel",
            "ba_set_allreduce", "ba_copy_to_host", "ba_copy_to_device", "ba_rccl_unique_id", "ba_use_rccl", "ba_evaluate_noalloc",
            "ba_device_count", "ba_set_device", "ba_reduction_timing", "ba_reduction_stats",
-           "ba_shard_reduced_solve", "ba_reduced_solve_rows", "ba_set_covariance_route", "ba_covariance_stats",
+           "ba_shard_reduced_solve", "ba_reduced_solve_rows", "ba_set_covariance_route", "ba_covariance_stats", "ba_sparse_solver_stats",
            "ba_last_error")
 
 
@@ -58,6 +58,7 @@ def lib():
         L.ba_set_iop_bounds.argtypes = [C.c_void_p, c_double_p, c_double_p]
         L.ba_set_covariance_route.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.ba_covariance_stats.argtypes = [C.c_void_p] + [c_int32_p] * 4
+        L.ba_sparse_solver_stats.argtypes = [C.c_void_p] + [c_int32_p] * 4 + [c_double_p] * 2
         L.ba_line_search_contract.argtypes = [C.POINTER(BaLsSample)] * 3 + [C.c_double, C.c_double]
         L.ba_line_search_contract.restype = C.c_double
         L.ba_solve_resident.argtypes = [C.c_void_p, C.POINTER(BaOptions), C.POINTER(BaSummary), C.POINTER(BaIterRow), C.c_int32]
@@ -192,6 +193,14 @@ class Problem:
     def covariance_route(self, route=0, max_cluster_stations=0):
         """0: dense inverse while it fits, dissection of the station graph beyond; 1: dense only; 2: dissection."""
         _check(lib().ba_set_covariance_route(self._h, int(route), int(max_cluster_stations)))
+
+    def sparse_solver_stats(self):
+        """Of the sparse direct solver's elimination tree: dict(fronts, levels, largest_front, critical_panels, front_bytes, factor_flops)."""
+        v = [C.c_int32() for _ in range(4)]
+        d = [C.c_double() for _ in range(2)]
+        _check(lib().ba_sparse_solver_stats(self._h, *[C.byref(x) for x in v], *[C.byref(x) for x in d]))
+        return dict(zip(("fronts", "levels", "largest_front", "critical_panels", "front_bytes", "factor_flops"),
+                        [x.value for x in v] + [x.value for x in d]))
 
     def covariance_stats(self):
         """Of the last covariance(): dict(route, clusters, boundary_order, largest_cluster_order)."""

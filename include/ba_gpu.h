@@ -62,10 +62,15 @@ enum ba_linear_solver {
                                 block-Jacobi when the system is too dense for that form, or when the cameras
                                 have more than 79 free parameters between them) */
   BA_SOLVER_PCG_IMPLICIT = 2, /* same PCG, always matrix-free: S p = Jc^T (I - Jp V^-1 Jp^T) Jc p */
-  BA_SOLVER_AUTO = 3          /* the default: DENSE_SCHUR while the reduced system has at most
+  BA_SOLVER_AUTO = 3,         /* the default: DENSE_SCHUR while the reduced system has at most
                                  BA_AUTO_DENSE_ORDER unknowns (6 per station + the free camera
                                  parameters), PCG_SCHUR above.  The reference fixes its solver at
                                  src/main.cpp:4706, so a caller coming from it never chooses one. */
+  BA_SOLVER_SPARSE_SCHUR = 4  /* point elimination + sparse direct Cholesky of the block-sparse reduced system:
+                                 nested dissection of the station graph, multifrontal factorisation with dense
+                                 fronts on the matrix cores -- the counterpart of the reference's
+                                 SPARSE_NORMAL_CHOLESKY (src/main.cpp:4706) on the reduced system.  Needs the
+                                 block-sparse form (BA_ERR_UNSUPPORTED otherwise). */
 };
 #define BA_AUTO_DENSE_ORDER 4096
 
@@ -277,6 +282,16 @@ int ba_evaluate(ba_problem *p, const double *eop, const double *xyz, const doubl
  * error (the reference's DENSE_SVD pseudo-inverse would truncate it instead).
  */
 int ba_covariance(ba_problem *p, double *var_eop, double *var_xyz, double *var_iop, double *var_ap);
+
+/*
+ * What BA_SOLVER_SPARSE_SCHUR has built for this problem (after its first solve): the number of fronts of the
+ * elimination tree and of its levels, the order of the largest front, the number of 128-column panels on the
+ * critical path (the sum over the levels of the most panels any front of the level has), the bytes the fronts
+ * take and the floating-point operations of one factorisation.  Any pointer may be NULL.  No counterpart in the
+ * reference (Ceres keeps such figures in Solver::Summary::FullReport, which the reference prints at :4726).
+ */
+int ba_sparse_solver_stats(const ba_problem *p, int32_t *fronts, int32_t *levels, int32_t *largest_front,
+                           int32_t *critical_panels, double *front_bytes, double *factor_flops);
 
 /*
  * Which route ba_covariance takes: 0 chooses (the default: the dissection when the dense inverse does not
