@@ -140,7 +140,7 @@ struct ShmComm {
 static void usage() {
   fprintf(stderr,
           "usage: ba_main <file.pho> <file.eop> <file.iop> <file.xyz> [--out DIR] [--free-ap MASK] [--free-iop MASK]\n"
-          "               [--solver auto|dense|pcg|implicit] [--pcg-rtol X] [--max-iter N] [--covariance] [--model M]\n"
+          "               [--solver auto|dense|sparse|pcg|implicit] [--pcg-rtol X] [--max-iter N] [--covariance] [--model M]\n"
           "               [--bins B] [--truth file.xyz] [--iop-bounds]\n"
           "       ba_main --synth C S P RAYS [same options]\n"
           "       ba_main ... --ranks N --rank R --id-file PATH [--run-id ID] [--comm rccl|shm] [--comm-timeout SECONDS]\n"
@@ -195,7 +195,8 @@ int main(int argc, char **argv) {
     else if (a == "--free-iop") iop_mask = (unsigned)strtoul(next(), nullptr, 0);
     else if (a == "--solver") {
       const std::string v = next();
-      opt.linear_solver = v == "pcg" ? BA_SOLVER_PCG_SCHUR : v == "implicit" ? BA_SOLVER_PCG_IMPLICIT : v == "dense" ? BA_SOLVER_DENSE_SCHUR : BA_SOLVER_AUTO;
+      opt.linear_solver = v == "pcg" ? BA_SOLVER_PCG_SCHUR : v == "implicit" ? BA_SOLVER_PCG_IMPLICIT : v == "dense" ? BA_SOLVER_DENSE_SCHUR :
+                          v == "sparse" ? BA_SOLVER_SPARSE_SCHUR : BA_SOLVER_AUTO;
     }
     else if (a == "--pcg-rtol") opt.pcg_rtol = atof(next());
     else if (a == "--max-iter") opt.max_num_iterations = atoi(next());

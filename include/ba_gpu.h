@@ -64,8 +64,9 @@ enum ba_linear_solver {
   BA_SOLVER_PCG_IMPLICIT = 2, /* same PCG, always matrix-free: S p = Jc^T (I - Jp V^-1 Jp^T) Jc p */
   BA_SOLVER_AUTO = 3,         /* the default: DENSE_SCHUR while the reduced system has at most
                                  BA_AUTO_DENSE_ORDER unknowns (6 per station + the free camera
-                                 parameters), PCG_SCHUR above.  The reference fixes its solver at
-                                 src/main.cpp:4706, so a caller coming from it never chooses one. */
+                                 parameters), SPARSE_SCHUR up to BA_AUTO_SPARSE_ORDER when the block-sparse
+                                 form exists, PCG_SCHUR above and otherwise.  The reference fixes its solver
+                                 at src/main.cpp:4706, so a caller coming from it never chooses one. */
   BA_SOLVER_SPARSE_SCHUR = 4  /* point elimination + sparse direct Cholesky of the block-sparse reduced system:
                                  nested dissection of the station graph, multifrontal factorisation with dense
                                  fronts on the matrix cores -- the counterpart of the reference's
@@ -73,6 +74,7 @@ enum ba_linear_solver {
                                  block-sparse form (BA_ERR_UNSUPPORTED otherwise). */
 };
 #define BA_AUTO_DENSE_ORDER 4096
+#define BA_AUTO_SPARSE_ORDER 32768
 
 typedef struct {
   int32_t n_obs; /* rows of the .pho file  */

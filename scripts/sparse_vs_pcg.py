@@ -8,7 +8,9 @@ from bundleadjustment_amd import capi, host, solver
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 only = sys.argv[3] if len(sys.argv) > 3 else ""
-net = host.synth_config(name).net
+scale = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
+net = host.synth_config(name, scale=scale).net
+print(name, "scale", scale, "stations", net.n_sta, "observations", net.n_obs)
 with solver.Problem(net) as P:
     for ls, label in ((capi.SOLVER_SPARSE_SCHUR, "sparse"), (capi.SOLVER_PCG_SCHUR, "pcg")):
         if only and label != only:

@@ -93,7 +93,8 @@ def test_full_size_properties(name):
         del res, img
         c2, _ = P.evaluate(t["eop"], t["xyz"], t["iop"], t["ap"], apply_loss=False, residuals=False)
         assert c2 == c_truth                                                 # same bits twice
-        opt = solver.default_options()                                      # picks the PCG at these sizes
+        opt = solver.default_options()
+        opt.linear_solver = capi.SOLVER_PCG_SCHUR                           # (the default takes the sparse direct solver at cfg3's size)
         opt.max_num_iterations = 2
         opt.pcg_rtol = 1e-10
         P.set_parameters()
@@ -233,7 +234,7 @@ def test_full_size_pcg_step_equals_dense_cholesky_step(name, big):
     # shares none of that.  Same candidate cost and same parameters after the step to 1e-9.
     net = big if name == "cfg4" else host.synth_config("cfg3", outlier_fraction=0.0).net
     out = {}
-    for ls in (capi.SOLVER_PCG_SCHUR, capi.SOLVER_DENSE_SCHUR):
+    for ls in (capi.SOLVER_PCG_SCHUR, capi.SOLVER_DENSE_SCHUR, capi.SOLVER_SPARSE_SCHUR):
         with solver.Problem(net) as P:
             opt = solver.default_options()
             opt.linear_solver = ls
@@ -245,6 +246,11 @@ def test_full_size_pcg_step_equals_dense_cholesky_step(name, big):
             sm, rows = P.solve_resident(opt)
             assert sm["linear_solver_used"] == ls and len(rows) == 2 and rows[1]["step_is_successful"]
             out[ls] = (rows, P.get_parameters())
+    (rs, ps), (rd, pd) = out[capi.SOLVER_SPARSE_SCHUR], out[capi.SOLVER_DENSE_SCHUR]
+    assert rs[0]["cost"] == rd[0]["cost"]
+    assert abs(rs[1]["cost"] - rd[1]["cost"]) <= RTOL * rd[1]["cost"], (rs[1]["cost"], rd[1]["cost"])
+    for a, b, what in zip(ps, pd, ("eop", "xyz", "iop", "ap")):
+        assert rel(a, b) < RTOL, ("sparse", what, rel(a, b))
     (rp, pp), (rd, pd) = out[capi.SOLVER_PCG_SCHUR], out[capi.SOLVER_DENSE_SCHUR]
     assert rp[0]["cost"] == rd[0]["cost"]
     assert abs(rp[1]["cost"] - rd[1]["cost"]) <= RTOL * rd[1]["cost"], (rp[1]["cost"], rd[1]["cost"])

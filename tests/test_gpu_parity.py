@@ -146,10 +146,18 @@ def test_default_options_pick_the_solver_by_size():
     large = host.synth(n_cam=1, n_sta=700, n_pts=20000, rays_per_point=6, seed=3).net
     assert 6 * large.n_sta > capi.AUTO_DENSE_ORDER
     g = gpu_solve(large, opt)
-    assert g[4]["linear_solver_used"] == capi.SOLVER_PCG_SCHUR and g[4]["total_linear_iterations"] > 0
+    assert g[4]["linear_solver_used"] == capi.SOLVER_SPARSE_SCHUR and g[4]["total_linear_iterations"] == 0
     assert g[4]["termination"] == capi.CONVERGENCE
-    explicit = gpu_solve(large, options(capi.SOLVER_PCG_SCHUR))
+    explicit = gpu_solve(large, options(capi.SOLVER_SPARSE_SCHUR))
     assert g[4]["final_cost"] == explicit[4]["final_cost"]
+    pcg = gpu_solve(large, options(capi.SOLVER_PCG_SCHUR))
+    assert pcg[4]["total_linear_iterations"] > 0 and abs(pcg[4]["final_cost"] - g[4]["final_cost"]) <= 1e-9 * g[4]["final_cost"]
+    huge = host.synth(n_cam=1, n_sta=6000, n_pts=30000, rays_per_point=4, seed=3).net
+    assert 6 * huge.n_sta > capi.AUTO_SPARSE_ORDER
+    opt2 = solver.default_options()
+    opt2.max_num_iterations = 2
+    g = gpu_solve(huge, opt2)
+    assert g[4]["linear_solver_used"] == capi.SOLVER_PCG_SCHUR and g[4]["total_linear_iterations"] > 0
 
 
 def test_multilevel_preconditioner_same_answer_fewer_iterations():
