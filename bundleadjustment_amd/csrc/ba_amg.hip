@@ -236,8 +236,6 @@ enum { AMG_PT_ELL = 64, AMG_P_ELL = 8 };
 struct AmgApplyArgs {
   int n_transfers;
   AmgTransfer t[AMG_MAX_LEVELS - 1];
-  int has_flat;      // three levels applied as two transfers from the finest level: t[0] = P0 and flat = P0 P1
-  AmgTransfer flat;
   double *part;  // per-workgroup partials of rc . y from the restrictions that run as kernels of their own
   int n_part;
   double *totals;  // 1 + AMG_DEFL_NC sums for the last kernel (k_amg_prolong's folding workgroup)
@@ -367,7 +365,7 @@ k_amg_restrict(AmgTransfer t, const double *__restrict__ v, double *__restrict__
 // nothing but arithmetic waits for the fold.  The residual is double buffered by iteration parity because the two
 // groups run concurrently.
 __global__ void __launch_bounds__(256, 2)
-k_amg_update1_restrict(BsrCgArgs a, AmgTransfer t1, AmgTransfer t2, int nbr1, int parity, int nblk_spmv, int nbv, double *__restrict__ part) {
+k_amg_update1_restrict(BsrCgArgs a, AmgTransfer t, int parity, int nblk_spmv, int nbv, double *__restrict__ part) {
   __shared__ Cg2Shared sh;
   pcg_mark(a.trace, 1, 0, blockIdx.x);
   const double done = a.scal[8 + parity], rz = a.scal[parity];
@@ -458,11 +456,8 @@ k_amg_update1_restrict(BsrCgArgs a, AmgTransfer t1, AmgTransfer t2, int nbr1, in
     pcg_mark(a.trace, 1, 4, blockIdx.x);
     return;
   }
-  // workgroups [0, nbr1) of this role restrict with t1, the ones behind them with t2 (the flattened second transfer)
   const int cb = blockIdx.x - nbv;
-  const bool second = cb >= nbr1;
-  const AmgTransfer &t = second ? t2 : t1;
-  const int c = (second ? cb - nbr1 : cb) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, r = lane & 7;
+  const int c = cb * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, r = lane & 7;
   double d[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, sv = 0.0, sq = 0.0;
   RestrictIdx ri{-1, 0, 0, 0};
   if (c < t.nc) {
@@ -613,7 +608,7 @@ k_amg_prolong(AmgTransfer t, double *__restrict__ yf, double tau, AmgFoldArgs fo
 // p = z + beta p (mode 1) or p = z (mode 0, start of the solve); 8 lanes per station.
 // Workgroup 0 publishes the scalars for the next iteration in the other parity slot.
 __global__ void __launch_bounds__(256)
-k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, AmgTransfer t2, int has_flat, const double *__restrict__ part, int n_part, int n_part_rz,
+k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, const double *__restrict__ part, int n_part, int n_part_rz,
               int parity, int mode, double rtol, double sigma, double tau, int np0, const double *__restrict__ totals) {
   __shared__ double lds[4];
   __shared__ double rzn_s;
@@ -636,8 +631,6 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, AmgTransfer t2, int h
   const double rcv = (defl && (int)threadIdx.x < cg.ncam) ? ((mode == 1 && !parity) ? cg.r2 : cg.r)[o + threadIdx.x] : 0.0;
   ProlongIdx pi{-1, 0, 0};
   if (has_coarse) pi = prolong_issue(t, on ? i : 0, threadIdx.x & 63);
-  ProlongIdx pi2{-1, 0, 0};
-  if (has_flat) pi2 = prolong_issue(t2, on ? i : 0, threadIdx.x & 63);
   if (done != 0.0) {  // waits for the flag alone; an iteration after convergence costs one trip
     if (blockIdx.x == 0 && threadIdx.x == 0) cg.scal[8 + (parity ^ 1)] = done;  // keep both slots set
     return;
@@ -676,8 +669,7 @@ k_amg_update2(BsrCgArgs cg, AmgTransfer t, int has_coarse, AmgTransfer t2, int h
       s += (v[0] + v[1]) + (v[2] + v[3]);
     }
   }
-  double corr = has_coarse ? prolong_finish(t, pi, threadIdx.x & 63) : 0.0;
-  if (has_flat) corr += tau * prolong_finish(t2, pi2, threadIdx.x & 63);  // the third level straight from its own vector
+  const double corr = has_coarse ? prolong_finish(t, pi, threadIdx.x & 63) : 0.0;
   pcg_mark(cg.trace, 4, 1, blockIdx.x);
   // ---- scalars
   if (defl) {
@@ -777,13 +769,6 @@ struct Amg {
   double *d_tmp = nullptr, *d_tmp2 = nullptr, *d_part = nullptr, *d_norm = nullptr, *d_totals = nullptr;
   unsigned *d_flags = nullptr;
   int n_part = 0;  // per-workgroup partials of all restrictions
-  // F = P0 P1, the two transfers of a three-level hierarchy as one from the finest level (lists as for a level's P)
-  bool flat = false;
-  int nF = 0;
-  int *F_rowptr = nullptr, *F_col = nullptr, *F_pos = nullptr, *Ft_ptr = nullptr, *Ft_blk = nullptr, *Ft_row = nullptr, *F_col_ell = nullptr;
-  int2 *Ft_ell = nullptr;
-  int *FP_ptr = nullptr, *FP_la = nullptr, *FP_lb = nullptr;
-  double *F_val = nullptr, *Fc_val = nullptr;
   char err[256] = {0};
 
   template <class T>
@@ -810,7 +795,6 @@ struct Amg {
     for (void *q : allocs) (void)hipFree(q);
     allocs.clear();
     levels.clear();
-    flat = false;
   }
 };
 
@@ -1066,66 +1050,6 @@ void numeric_level(hipStream_t s, const Level &L, unsigned *flags) {
   launch_invert_blocks(s, L.nc, L.Ac_val, L.Ac_diag, L.used_c, L.Dinv_c, flags);
 }
 
-// F = P0 P1 for the current numbers of both transfers, and its column-ordered copy
-void numeric_flat(hipStream_t s, const Amg *a) {
-  if (!a->flat) return;
-  hipLaunchKernelGGL(k_amg_products<0>, dim3(nblk(a->nF, 8)), dim3(256), 0, s, a->nF, a->FP_ptr, a->FP_la, a->FP_lb, a->levels[0].P_val,
-                     a->levels[1].P_val, a->F_val);
-  hipLaunchKernelGGL(k_amg_permute_blocks, dim3(nblk(36 * (int64_t)a->nF, 256)), dim3(256), 0, s, a->nF, a->F_val, a->F_pos, a->Fc_val);
-}
-
-// Pattern of F = P0 P1 with the lists of its products, and the row / column lists the kernels of the iteration read
-// (the same ones symbolic() makes for a level's own P).
-bool build_flat(Amg *a, const std::vector<int> &P0_rowptr, const std::vector<int> &P0_col, const std::vector<int> &P1_rowptr,
-                const std::vector<int> &P1_col) {
-  const int nb = a->levels[0].nb, nc = a->levels[1].nc;
-  std::vector<int> F_rowptr(nb + 1, 0), F_col, F_row, FP_ptr(1, 0), FP_la, FP_lb;
-  std::vector<std::pair<int, std::pair<int, int>>> tri;
-  for (int i = 0; i < nb; ++i) {
-    tri.clear();
-    for (int t = P0_rowptr[i]; t < P0_rowptr[i + 1]; ++t) {
-      const int c1 = P0_col[t];
-      for (int u = P1_rowptr[c1]; u < P1_rowptr[c1 + 1]; ++u) tri.push_back({P1_col[u], {t, u}});
-    }
-    std::sort(tri.begin(), tri.end());
-    for (size_t k = 0; k < tri.size(); ++k) {
-      if (k == 0 || tri[k].first != tri[k - 1].first) {
-        if (k) FP_ptr.push_back((int)FP_la.size());
-        F_col.push_back(tri[k].first);
-        F_row.push_back(i);
-      }
-      FP_la.push_back(tri[k].second.first);
-      FP_lb.push_back(tri[k].second.second);
-    }
-    if (!tri.empty()) FP_ptr.push_back((int)FP_la.size());
-    F_rowptr[i + 1] = (int)F_col.size();
-  }
-  const int nF = (int)F_col.size();
-  std::vector<int> Ft_ptr(nc + 1, 0), Ft_blk(nF), F_pos(nF), Ft_row(nF);
-  for (int t = 0; t < nF; ++t) Ft_ptr[F_col[t] + 1] += 1;
-  for (int c = 0; c < nc; ++c) Ft_ptr[c + 1] += Ft_ptr[c];
-  std::vector<int> fill(Ft_ptr.begin(), Ft_ptr.end() - 1);
-  for (int t = 0; t < nF; ++t) {
-    const int k = fill[F_col[t]]++;
-    Ft_blk[k] = t;
-    F_pos[t] = k;
-    Ft_row[k] = F_row[t];
-  }
-  std::vector<int2> Ft_ell((size_t)nc * AMG_PT_ELL, make_int2(-1, 0));
-  for (int c = 0; c < nc; ++c)
-    for (int k = Ft_ptr[c]; k < Ft_ptr[c + 1] && k - Ft_ptr[c] < AMG_PT_ELL; ++k)
-      Ft_ell[(size_t)c * AMG_PT_ELL + (k - Ft_ptr[c])] = make_int2(k, Ft_row[k]);
-  std::vector<int> F_col_ell((size_t)nb * AMG_P_ELL, -1);
-  for (int i = 0; i < nb; ++i)
-    for (int k = F_rowptr[i]; k < F_rowptr[i + 1] && k - F_rowptr[i] < AMG_P_ELL; ++k)
-      F_col_ell[(size_t)i * AMG_P_ELL + (k - F_rowptr[i])] = F_col[k];
-  a->nF = nF;
-  return a->upload(&a->F_rowptr, F_rowptr) && a->upload(&a->F_col, F_col) && a->upload(&a->F_pos, F_pos) && a->upload(&a->Ft_ptr, Ft_ptr) &&
-         a->upload(&a->Ft_blk, Ft_blk) && a->upload(&a->Ft_row, Ft_row) && a->upload(&a->Ft_ell, Ft_ell) &&
-         a->upload(&a->F_col_ell, F_col_ell) && a->upload(&a->FP_ptr, FP_ptr) && a->upload(&a->FP_la, FP_la) && a->upload(&a->FP_lb, FP_lb) &&
-         a->dalloc(&a->F_val, 36 * (size_t)nF) && a->dalloc(&a->Fc_val, 36 * (size_t)nF);
-}
-
 }  // namespace
 
 Amg *amg_create() { return new Amg(); }
@@ -1160,9 +1084,7 @@ int amg_build(Amg *a, hipStream_t s, int nb0, const std::vector<int> &rowptr, co
   if (!a->dalloc(&a->d_tmp, tmp_cap) || !a->dalloc(&a->d_tmp2, n0) || !a->dalloc(&a->d_norm, 2) || !a->dalloc(&a->d_flags, 1))
     return -1;
   (void)hipMemsetAsync(a->d_flags, 0, sizeof(unsigned), s);
-  int max_levels = AMG_MAX_LEVELS;
-  if (const char *e = std::getenv("BA_AMG_LEVELS")) max_levels = std::min(std::max(std::atoi(e), 1), (int)AMG_MAX_LEVELS);
-  std::vector<std::vector<int>> hP_rowptr, hP_col;
+  const int max_levels = std::min(std::max((int)tuning_value("amg_levels", (double)AMG_MAX_LEVELS), 1), (int)AMG_MAX_LEVELS);
   const bool verbose = std::getenv("BA_AMG_VERBOSE") != nullptr;
   auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (int l = 0; l < max_levels - 1 && A.nb >= 2 * AMG_MIN_BLOCKS; ++l) {
@@ -1229,27 +1151,9 @@ int amg_build(Amg *a, hipStream_t s, int nb0, const std::vector<int> &rowptr, co
       fprintf(stderr, "amg: level %d (%d -> %d blocks): block norms %.1f ms, aggregation %.1f, lists %.1f, uploads %.1f, damping factor %.1f\n", l,
               A.nb, nc, t_norms - t_start, t_agg - t_norms, t_sym - t_agg, t_up - t_sym, now() - t_up);
     a->levels.push_back(L);
-    hP_rowptr.push_back(sy.P_rowptr);
-    hP_col.push_back(sy.P_col);
     A = sy.Ac;
     used = sy.used_c;
     dA_rowptr = L.Ac_rowptr; dA_col = L.Ac_col; dA_val = L.Ac_val; dDinv = L.Dinv_c;
-  }
-  // BA_AMG_FLAT=1, three levels: both coarse levels are reached from the finest one (F = P0 P1), which takes the two
-  // launches between the levels out of every PCG iteration -- three launches instead of five.  Same iterates to rounding,
-  // but slower as it stands, hence off by default: at 10 000 stations (levels of 10 000 / 1268 / 176 blocks) F has 107 337
-  // blocks where P1 has 9488, and a column of F has 610 of them for the one wave that restricts it -- 60 us per iteration
-  // against 43 (second kernel 29 instead of 9 us, last kernel 16 instead of 9).
-  {
-    const char *e = std::getenv("BA_AMG_FLAT");
-    if (a->levels.size() == 2 && e && std::atoi(e) == 1) {
-      if (!build_flat(a, hP_rowptr[0], hP_col[0], hP_rowptr[1], hP_col[1])) return -1;
-      a->flat = true;
-      numeric_flat(s, a);
-      if (std::getenv("BA_AMG_VERBOSE"))
-        fprintf(stderr, "amg: levels %d / %d / %d blocks, P0 %d, P1 %d, F %d blocks\n", a->levels[0].nb, a->levels[0].nc, a->levels[1].nc,
-                a->levels[0].nP, a->levels[1].nP, a->nF);
-    }
   }
   a->n_part = 0;
   for (const Level &L : a->levels) a->n_part += nblk(L.nc, 4);
@@ -1267,7 +1171,6 @@ void amg_numeric(Amg *a, hipStream_t s, const double *d_val, const double *d_Din
   a->levels[0].A_val = d_val;
   a->levels[0].Dinv = d_Dinv;
   for (const Level &L : a->levels) numeric_level(s, L, a->d_flags);
-  numeric_flat(s, a);
 }
 
 static AmgApplyArgs apply_args(const Amg *a) {
@@ -1279,15 +1182,6 @@ static AmgApplyArgs apply_args(const Amg *a) {
     t.nb = L.nb; t.nc = L.nc; t.P_rowptr = L.P_rowptr; t.P_col = L.P_col; t.P_val = L.P_val; t.Pc_val = L.Pc_val; t.Pt_ptr = L.Pt_ptr;
     t.Pt_blk = L.Pt_blk; t.Pt_row = L.Pt_row; t.Dinv_c = L.Dinv_c; t.rc = L.rc; t.y = L.y;
     t.Pt_ell = L.Pt_ell; t.P_col_ell = L.P_col_ell;
-  }
-  aa.has_flat = a->flat ? 1 : 0;
-  aa.flat = aa.t[0];
-  if (a->flat) {
-    const Level &L1 = a->levels[1];
-    AmgTransfer &f = aa.flat;
-    f.nb = a->levels[0].nb; f.nc = L1.nc; f.P_rowptr = a->F_rowptr; f.P_col = a->F_col; f.P_val = a->F_val; f.Pc_val = a->Fc_val;
-    f.Pt_ptr = a->Ft_ptr; f.Pt_blk = a->Ft_blk; f.Pt_row = a->Ft_row; f.Pt_ell = a->Ft_ell; f.P_col_ell = a->F_col_ell;
-    f.Dinv_c = L1.Dinv_c; f.rc = L1.rc; f.y = L1.y;
   }
   aa.part = a->d_part;
   aa.n_part = a->n_part;
@@ -1305,19 +1199,16 @@ static void amg_finish_iteration(hipStream_t s, const BsrCgArgs &cg, const Amg *
   int off = 0;
   for (int l = 0; l < aa.n_transfers; ++l) {
     const int nb = nblk(aa.t[l].nc, 4);
-    if (first_done && (l == 0 || aa.has_flat)) {
+    if (first_done && l == 0) {
       off += nb;
       continue;
     }
-    if (l == 1 && aa.has_flat)  // straight from the fine residual
-      hipLaunchKernelGGL(k_amg_restrict, dim3(nb), dim3(256), 0, s, aa.flat, cg.r, aa.part + off, cg.trace);
-    else
-      hipLaunchKernelGGL(k_amg_restrict, dim3(nb), dim3(256), 0, s, aa.t[l], l == 0 ? cg.r : aa.t[l - 1].rc, aa.part + off, cg.trace);
+    hipLaunchKernelGGL(k_amg_restrict, dim3(nb), dim3(256), 0, s, aa.t[l], l == 0 ? cg.r : aa.t[l - 1].rc, aa.part + off, cg.trace);
     off += nb;
   }
   const int np0 = aa.n_transfers > 0 ? nblk(aa.t[0].nc, 4) : 0;
   const double *totals = nullptr;
-  for (int l = aa.n_transfers - 1; l >= 1 && !aa.has_flat; --l) {
+  for (int l = aa.n_transfers - 1; l >= 1; --l) {
     AmgFoldArgs fa{};
     if (l == 1) {  // the last launch before the final kernel: one more workgroup sums what that kernel needs
       fa.part_rz = cg.part_rz; fa.part = aa.part; fa.part_gr = cg.G ? cg.part_gr : nullptr;
@@ -1329,7 +1220,7 @@ static void amg_finish_iteration(hipStream_t s, const BsrCgArgs &cg, const Amg *
                        AMG_DEEP_WEIGHT, fa, cg.trace);
   }
   hipLaunchKernelGGL(k_amg_update2, dim3(nblk(cg.S, 32) > 0 ? nblk(cg.S, 32) : 1), dim3(256), 0, s, cg, aa.t[0],
-                     aa.n_transfers > 0 ? 1 : 0, aa.flat, aa.has_flat, aa.part, aa.n_part, n_part_rz, parity, mode, rtol,
+                     aa.n_transfers > 0 ? 1 : 0, aa.part, aa.n_part, n_part_rz, parity, mode, rtol,
                      AMG_COARSE_WEIGHT, AMG_DEEP_WEIGHT, np0, totals);
 }
 
@@ -1353,9 +1244,8 @@ bool amg_cg_iteration_splits(const BsrCgArgs &cg, const Amg *a) { return apply_a
 
 void launch_amg_cg_iteration_after_product(hipStream_t s, const BsrCgArgs &cg, const Amg *a, int parity) {
   const AmgApplyArgs aa = apply_args(a);
-  const int nbv = cg2_blocks_vec8(cg.S), nbr = nblk(aa.t[0].nc, 4), nbr2 = aa.has_flat ? nblk(aa.flat.nc, 4) : 0;
-  hipLaunchKernelGGL(k_amg_update1_restrict, dim3(nbv + nbr + nbr2), dim3(256), 0, s, cg, aa.t[0], aa.flat, nbr, parity,
-                     cg2_blocks_spmv(cg.S), nbv, aa.part);
+  const int nbv = cg2_blocks_vec8(cg.S), nbr = nblk(aa.t[0].nc, 4);
+  hipLaunchKernelGGL(k_amg_update1_restrict, dim3(nbv + nbr), dim3(256), 0, s, cg, aa.t[0], parity, cg2_blocks_spmv(cg.S), nbv, aa.part);
   amg_finish_iteration(s, cg, a, parity, 1, 0.0, 1, nbv);
 }
 

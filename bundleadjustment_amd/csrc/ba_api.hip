@@ -683,7 +683,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
     BA_TRY(p->dalloc(&p->d_part_rz, npart));
     BA_TRY(p->dalloc(&p->d_cg2scal, 32));
   }
-  if (p->explicit_ok && p->n_pairs > 0 && !std::getenv("BA_NO_SCHUR_WINDOWS")) {
+  if (p->explicit_ok && p->n_pairs > 0 && tuning_value("schur_windows", 1.0) != 0.0) {
     std::vector<int> pts_host;
     const int *pts = pt_start.data();
     if (on_device) {
@@ -712,7 +712,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
   }
   BA_TRY(alloc_reduced_sums(p));
   int campart_rows = obs_rows_blocks(N);
-  if (p->explicit_ok && N > 0 && (single_camera_path || p->ncam == 0) && !std::getenv("BA_NO_FUSED_SUMS")) {
+  if (p->explicit_ok && N > 0 && (single_camera_path || p->ncam == 0) && tuning_value("fused_sums", 1.0) != 0.0) {
     // The station sums and the camera border can come out of the observation kernel when no tile of 64 observations
     // sees more stations than a wave's table has rows, and the partial records stay a small part of the traffic.
     std::vector<int> sta_host;
@@ -723,7 +723,7 @@ int build_problem(ba_problem *p, const ba_dims *d, const ba_inputs *in) {
       sta_of_obs = sta_host.data();
     }
     int tps = 16;
-    if (const char *e = std::getenv("BA_KEYED_TILES")) tps = std::max(1, std::atoi(e));
+    tps = std::max(1, (int)tuning_value("keyed_tiles", (double)tps));
     KeyedPlanHost kh;
     const int ncolp = keyed_ncolp(single_camera_path);
     if (build_keyed_plan(N, S, sta_of_obs, tps, setup_threads(), kh) && (double)kh.n_rec * ncolp * 8.0 <= 48.0 * (double)N + 1e6) {
@@ -1118,8 +1118,7 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
   if (use_amg) {
     if (!p->amg) {
       p->amg = amg_create();
-      double theta = 0.5;  // strength threshold of the aggregation
-      if (const char *e = std::getenv("BA_AMG_THETA")) theta = std::atof(e);
+      const double theta = tuning_value("amg_theta", 0.5);  // strength threshold of the aggregation
       if (amg_build(p->amg, s, p->S, p->bsr_rowptr_h, p->bsr_col_h, p->sta_used_h, p->d_bsr_rowptr, p->d_bsr_col, p->d_bsr_val,
                     p->d_Minv, theta) != 0) {
         const int rc = fail(BA_ERR_DEVICE, "%s", amg_error(p->amg));
@@ -1240,8 +1239,7 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
     if (p->cg_graph_tail) hipGraphExecDestroy(p->cg_graph_tail);
     p->cg_graph = p->cg_graph_tail = nullptr;
   }
-  if (const char *e = std::getenv("BA_PCG_GRAPH"))  // 0: queue the iterations launch by launch (for comparisons)
-    if (std::atoi(e) == 0) p->cg_graph_failed = true;
+  if (tuning_value("pcg_graph", 1.0) == 0.0) p->cg_graph_failed = true;  // queue the iterations launch by launch (for comparisons)
   if (!p->cg_graph && !p->cg_graph_failed && !shard_rows) {
     p->cg_graph_precond = precond;
     // the launch sequence of a batch never changes for this problem: capture it into a graph once
@@ -1410,7 +1408,7 @@ int solve_sparse(ba_problem *p) {
   if (!p->sparse) {
     p->sparse = sparse_chol_create();
     std::string why;
-    int leaf = 21;  // stations per leaf: 126 unknowns, one panel
+    int leaf = 63;  // stations per leaf: 378 unknowns, three panels
     const int rc = sparse_chol_analyse(p->sparse, p->S, p->ncam, p->bsr_rowptr_h, p->bsr_col_h, p->sta_used_h, leaf, why);
     if (rc) {
       sparse_chol_destroy(p->sparse);
@@ -2040,6 +2038,11 @@ int ba_solve(ba_problem *p, const ba_options *opt, double *eop, double *xyz, dou
   BA_TRY(ba_set_parameters(p, eop, xyz, iop, ap));
   BA_TRY(ba_solve_resident(p, opt, summary, rows, rows_cap));
   return ba_get_parameters(p, eop, xyz, iop, ap);
+}
+
+int ba_tuning(const char *name, double value) {
+  if (!name || !tuning_set(name, value)) return fail(BA_ERR_INVALID, "ba_tuning: no switch named '%s'", name ? name : "(null)");
+  return 0;
 }
 
 int ba_sparse_solver_stats(const ba_problem *p, int32_t *fronts, int32_t *levels, int32_t *largest_front, int32_t *critical_panels,

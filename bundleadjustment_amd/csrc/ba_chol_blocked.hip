@@ -33,13 +33,14 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------------------------
 // acc += A[rows ar0 .. ar0+127][kb .. ke) * B[rows br0 .. br0+127][kb .. ke)^T ; rows >= am / bm read as zero.
 // kb is even; columns up to the next even number after ke are read (padding or zeros).
-__device__ __forceinline__ void gemm_tile_nt(const double *__restrict__ A, int lda, int ar0, int am, const double *__restrict__ B,
+template <int KCT>
+__device__ __forceinline__ void gemm_tile_nt_k(const double *__restrict__ A, int lda, int ar0, int am, const double *__restrict__ B,
                                              int ldb, int br0, int bm, int kb, int ke, double *sA, double *sB, d4 (&acc)[4][4]) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wr = w >> 1, wc = w & 1, lr = lane & 15, lk = lane >> 4;
   const int row = t >> 1, h = t & 1;
   const bool aon = ar0 + row < am, bon = br0 + row < bm;
-  constexpr int HK = KC / 2, NJ = KC / 4;  // a thread stages half a chunk row: HK columns as NJ 16-byte pieces
+  constexpr int HK = KCT / 2, NJ = KCT / 4;  // a thread stages half a chunk row: HK columns as NJ 16-byte pieces
   const double *ap = A + (int64_t)(ar0 + row) * lda + HK * h, *bp = B + (int64_t)(br0 + row) * ldb + HK * h;
   double2 ra[NJ], rb[NJ];
   auto fetch = [&](int k0) {
@@ -51,7 +52,7 @@ __device__ __forceinline__ void gemm_tile_nt(const double *__restrict__ A, int l
     }
   };
   fetch(kb);
-  for (int k0 = kb; k0 < ke; k0 += KC) {
+  for (int k0 = kb; k0 < ke; k0 += KCT) {
     __syncthreads();  // the previous chunk has been read
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -61,9 +62,9 @@ __device__ __forceinline__ void gemm_tile_nt(const double *__restrict__ A, int l
       sB[(HK * h + 2 * j + 1) * LDT + row] = rb[j].y;
     }
     __syncthreads();
-    if (k0 + KC < ke) fetch(k0 + KC);  // in flight during the products below
+    if (k0 + KCT < ke) fetch(k0 + KCT);  // in flight during the products below
 #pragma unroll
-    for (int kk = 0; kk < KC / 4; ++kk) {
+    for (int kk = 0; kk < KCT / 4; ++kk) {
       double fa[4], fb[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
@@ -76,6 +77,11 @@ __device__ __forceinline__ void gemm_tile_nt(const double *__restrict__ A, int l
         for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[c], acc[a][c], 0, 0, 0);
     }
   }
+}
+
+__device__ __forceinline__ void gemm_tile_nt(const double *__restrict__ A, int lda, int ar0, int am, const double *__restrict__ B,
+                                             int ldb, int br0, int bm, int kb, int ke, double *sA, double *sB, d4 (&acc)[4][4]) {
+  gemm_tile_nt_k<KC>(A, lda, ar0, am, B, ldb, br0, bm, kb, ke, sA, sB, acc);
 }
 
 enum { GEMM_TRSM = 0, GEMM_SYRK = 1, GEMM_INV_T = 2, GEMM_INV_U = 3, GEMM_INV_S = 4 };
@@ -98,7 +104,7 @@ __device__ __forceinline__ void tri_tile(int b, int &ti, int &tj) {
   tj = b - (int)((int64_t)i * (i + 1) / 2);
 }
 
-template <int MODE>
+template <int MODE, int KCT = KC>
 __device__ __forceinline__ void gemm_nt_block(const GemmArgs &g, const int bx, double *sA, double *sB) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wr = w >> 1, wc = w & 1, lr = lane & 15, lk = lane >> 4;
@@ -115,7 +121,7 @@ __device__ __forceinline__ void gemm_nt_block(const GemmArgs &g, const int bx, d
   if (MODE == GEMM_TRSM) {
     // X = A[r0 .., k0 .. k0+kw) W^T, in place (a workgroup reads its rows completely before it writes them)
     r0 = g.k0 + g.kw + CB * bx;
-    gemm_tile_nt(g.A + g.k0, ld, r0, n, g.W, CB, 0, g.kw, 0, g.kw, sA, sB, acc);
+    gemm_tile_nt_k<KCT>(g.A + g.k0, ld, r0, n, g.W, CB, 0, g.kw, 0, g.kw, sA, sB, acc);
     C = g.A + g.k0;
     c0 = 0;
     cmax = g.kw;
@@ -125,7 +131,7 @@ __device__ __forceinline__ void gemm_nt_block(const GemmArgs &g, const int bx, d
     const int t0 = g.k0 + g.kw;
     r0 = t0 + CB * ti;
     c0 = t0 + CB * tj;
-    gemm_tile_nt(g.A + g.k0, ld, r0, n, g.A + g.k0, ld, c0, n, 0, g.kw, sA, sB, acc);
+    gemm_tile_nt_k<KCT>(g.A + g.k0, ld, r0, n, g.A + g.k0, ld, c0, n, 0, g.kw, sA, sB, acc);
     C = g.A;
     alpha = -1.0;
     beta = 1.0;
@@ -134,7 +140,7 @@ __device__ __forceinline__ void gemm_nt_block(const GemmArgs &g, const int bx, d
     // T^T[k-block rows][i-block cols] = sum_{j = k .. i-1} U[k, j] L[i, j]^T   (blocks of CB), one tile per k < ib
     const int kblk = bx;
     r0 = CB * kblk;
-    gemm_tile_nt(g.U, ld, r0, n, g.A, ld, CB * g.ib, n, CB * kblk, CB * g.ib, sA, sB, acc);
+    gemm_tile_nt_k<KCT>(g.U, ld, r0, n, g.A, ld, CB * g.ib, n, CB * kblk, CB * g.ib, sA, sB, acc);
     // T (CB x ld) holds tile k as a CB x CB block at column CB k: rows = rows of block k, columns = rows of block ib
     C = g.T;
     r0 = 0;
@@ -144,7 +150,7 @@ __device__ __forceinline__ void gemm_nt_block(const GemmArgs &g, const int bx, d
   } else if (MODE == GEMM_INV_U) {
     // U[k, ib] = - T^T[k] W_ib^T
     const int kblk = bx;
-    gemm_tile_nt(g.T + CB * kblk, ld, 0, CB, g.W + (int64_t)g.ib * CB * CB, CB, 0, CB, 0, min(CB, n - CB * g.ib), sA, sB, acc);
+    gemm_tile_nt_k<KCT>(g.T + CB * kblk, ld, 0, CB, g.W + (int64_t)g.ib * CB * CB, CB, 0, CB, 0, min(CB, n - CB * g.ib), sA, sB, acc);
     C = g.U;
     r0 = CB * kblk;
     c0 = CB * g.ib;
@@ -155,7 +161,7 @@ __device__ __forceinline__ void gemm_nt_block(const GemmArgs &g, const int bx, d
     tri_tile(bx, ti, tj);
     r0 = CB * ti;
     c0 = CB * tj;
-    gemm_tile_nt(g.U, ld, r0, n, g.U, ld, c0, n, CB * ti, n, sA, sB, acc);
+    gemm_tile_nt_k<KCT>(g.U, ld, r0, n, g.U, ld, c0, n, CB * ti, n, sA, sB, acc);
     C = g.A;
   }
   // C layout of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4 * reg.

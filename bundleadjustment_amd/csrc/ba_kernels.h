@@ -325,6 +325,17 @@ struct FrontDesc {
 // panels 0 .. n_panels-1 of every front of the list: diagonal block, rows below, trailing update (max_m: largest order)
 void launch_front_panels(hipStream_t s, const FrontDesc *fd, int n_fronts, int n_panels, int max_m, int *info);
 int front_panel();
+// Process-wide switches for comparisons and tests (ba_tuning in the C-ABI); a name that was never set has its default.
+//   "setup"          0: the problem's lists are built on the host, 1: on the device, -1 (default): by size
+//   "pcg_graph"      0: the PCG's batches are queued launch by launch, 1 (default): replayed as graphs
+//   "amg_levels"     levels of the multilevel preconditioner at most (default and maximum 3)
+//   "amg_theta"      strength threshold of its aggregation (default 0.5)
+//   "fused_sums"     0: the station sums are formed by separate sweeps, 1 (default): inside the observation kernel
+//   "schur_windows"  0: the off-diagonal blocks are summed pair list by pair list, 1 (default): window by window
+//   "keyed_tiles"    tiles per segment of the station-sum plan (default 16)
+double tuning_value(const char *name, double dflt);
+bool tuning_set(const char *name, double value);
+
 // ba_sparse_chol.hip: sparse direct Cholesky of the block-sparse reduced system (nested dissection, dense fronts)
 struct SparseChol;
 struct SparseCholStats {

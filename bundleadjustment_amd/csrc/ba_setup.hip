@@ -153,11 +153,35 @@ int point_order_station_bits(int S, int dmax) {
   return bits_for((uint64_t)dmax) + sbits <= 32 ? sbits : 0;
 }
 
+namespace {
+struct Tuning {
+  const char *name;
+  double value;
+  bool set;
+};
+Tuning g_tuning[] = {{"setup", -1.0, false},     {"pcg_graph", 1.0, false},     {"amg_levels", 3.0, false},  {"amg_theta", 0.5, false},
+                     {"fused_sums", 1.0, false}, {"schur_windows", 1.0, false}, {"keyed_tiles", 16.0, false}};
+}  // namespace
+
+double tuning_value(const char *name, double dflt) {
+  for (const Tuning &t : g_tuning)
+    if (std::string(t.name) == name) return t.set ? t.value : dflt;
+  return dflt;
+}
+bool tuning_set(const char *name, double value) {
+  for (Tuning &t : g_tuning)
+    if (std::string(t.name) == name) {
+      t.value = value;
+      t.set = true;
+      return true;
+    }
+  return false;
+}
+
 bool setup_on_device(int64_t n_obs) {
-  if (const char *e = std::getenv("BA_SETUP")) {
-    if (std::string(e) == "host") return false;
-    if (std::string(e) == "gpu") return n_obs > 0;
-  }
+  const int mode = (int)tuning_value("setup", -1.0);
+  if (mode == 0) return false;
+  if (mode == 1) return n_obs > 0;
   return n_obs >= (1 << 16);  // below that the transfers and launches cost more than the host loops
 }
 

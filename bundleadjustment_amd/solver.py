@@ -23,7 +23,7 @@ EXPORTS = ("ba_default_options", "ba_create", "ba_destroy", "ba_set_parameters",
            "ba_solve_resident", "ba_solve", "ba_evaluate", "ba_covariance", "ba_sparsity", "ba_residual_jacobian", "ba_time_kernel",
            "ba_set_allreduce", "ba_copy_to_host", "ba_copy_to_device", "ba_rccl_unique_id", "ba_use_rccl", "ba_evaluate_noalloc",
            "ba_device_count", "ba_set_device", "ba_reduction_timing", "ba_reduction_stats",
-           "ba_shard_reduced_solve", "ba_reduced_solve_rows", "ba_set_covariance_route", "ba_covariance_stats", "ba_sparse_solver_stats",
+           "ba_shard_reduced_solve", "ba_reduced_solve_rows", "ba_set_covariance_route", "ba_covariance_stats", "ba_sparse_solver_stats", "ba_tuning",
            "ba_last_error")
 
 
@@ -58,6 +58,7 @@ def lib():
         L.ba_set_iop_bounds.argtypes = [C.c_void_p, c_double_p, c_double_p]
         L.ba_set_covariance_route.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.ba_covariance_stats.argtypes = [C.c_void_p] + [c_int32_p] * 4
+        L.ba_tuning.argtypes = [C.c_char_p, C.c_double]
         L.ba_sparse_solver_stats.argtypes = [C.c_void_p] + [c_int32_p] * 4 + [c_double_p] * 2
         L.ba_line_search_contract.argtypes = [C.POINTER(BaLsSample)] * 3 + [C.c_double, C.c_double]
         L.ba_line_search_contract.restype = C.c_double
@@ -301,6 +302,11 @@ def device_count() -> int:
 def set_device(device: int):
     """The GPU of the calling thread: before the first Problem of a process that owns one GPU of several."""
     _check(lib().ba_set_device(int(device)))
+
+
+def tuning(name, value):
+    """Process-wide comparison switch (see ba_tuning in include/ba_gpu.h)."""
+    _check(lib().ba_tuning(name.encode(), float(value)))
 
 
 def rccl_unique_id() -> bytes:

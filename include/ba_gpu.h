@@ -286,6 +286,17 @@ int ba_evaluate(ba_problem *p, const double *eop, const double *xyz, const doubl
 int ba_covariance(ba_problem *p, double *var_eop, double *var_xyz, double *var_iop, double *var_ap);
 
 /*
+ * Process-wide switches that exist for comparisons and tests, not for production use; they apply to problems created
+ * (or, for the PCG ones, solved) afterwards.  Names: "setup" (0 host / 1 device / -1 by size: where ba_create builds
+ * its lists), "pcg_graph" (0: PCG iterations queued launch by launch instead of replayed as graphs), "amg_levels"
+ * (1..3), "amg_theta" (aggregation threshold, default 0.5), "fused_sums" (0: station sums by separate sweeps),
+ * "schur_windows" (0: off-diagonal blocks pair list by pair list), "keyed_tiles" (tiles per segment of the station-sum
+ * plan).  Every setting gives the same results to rounding.  BA_ERR_INVALID for an unknown name.  No counterpart in
+ * the reference.
+ */
+int ba_tuning(const char *name, double value);
+
+/*
  * What BA_SOLVER_SPARSE_SCHUR has built for this problem (after its first solve): the number of fronts of the
  * elimination tree and of its levels, the order of the largest front, the number of 128-column panels on the
  * critical path (the sum over the levels of the most panels any front of the level has), the bytes the fronts

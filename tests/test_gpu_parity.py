@@ -175,20 +175,6 @@ def test_multilevel_preconditioner_same_answer_fewer_iterations():
     assert g_ml[4]["total_linear_iterations"] < 0.6 * g_bj[4]["total_linear_iterations"]
 
 
-def test_flattened_hierarchy_gives_the_same_iterates(monkeypatch):
-    # BA_AMG_FLAT=1: the third level is reached straight from the finest one (F = P0 P1, three launches per PCG iteration
-    # instead of five); the same preconditioner up to rounding, so the same answer in the same number of iterations
-    net = host.synth_config("cfg4", scale=0.03).net
-    opt = options(capi.SOLVER_PCG_SCHUR, preconditioner=0)
-    g = gpu_solve(net, opt)
-    monkeypatch.setenv("BA_AMG_FLAT", "1")
-    f = gpu_solve(net, opt)
-    monkeypatch.delenv("BA_AMG_FLAT")
-    o = po.solve(net, opt, po.SCHUR_DENSE)
-    assert_solve_parity(f, o)
-    assert abs(f[4]["total_linear_iterations"] - g[4]["total_linear_iterations"]) <= 2 * g[4]["num_iterations"]
-
-
 def test_multilevel_preconditioner_several_cameras():
     # more than one camera: the camera border comes from the general (probing) path
     net = host.synth(n_cam=3, n_sta=90, n_pts=6000, rays_per_point=6, ap_free_mask=host.AP_K1K2P1P2, seed=5).net
@@ -481,7 +467,7 @@ def test_many_camera_columns_through_the_pcg_solvers():
     assert_solve_parity(d, o, par_rtol=1e-8)
 
 
-def test_index_structures_built_on_the_device_match_the_host_construction(monkeypatch):
+def test_index_structures_built_on_the_device_match_the_host_construction():
     # The same network set up twice: by the host loops (the rule for small networks) and by the sorts and scans on the
     # device (the rule from 65 536 observations on).  Both must give the same arrays, so everything downstream --
     # evaluation, sparsity pattern, every iteration of the solve -- is the same bits.  Three cameras and few rays per
@@ -499,7 +485,7 @@ def test_index_structures_built_on_the_device_match_the_host_construction(monkey
     net.obs_sta[dup[1]] = net.obs_sta[dup[0]]           # two observations of one point from the same station
     out = {}
     for mode in ("host", "gpu"):
-        monkeypatch.setenv("BA_SETUP", mode)
+        solver.tuning("setup", {"host": 0, "gpu": 1}[mode])
         opt = solver.default_options()
         opt.linear_solver = capi.SOLVER_PCG_SCHUR
         opt.max_num_iterations = 6
@@ -508,6 +494,7 @@ def test_index_structures_built_on_the_device_match_the_host_construction(monkey
             sp = P.sparsity()
             sol = P.solve(opt)
         out[mode] = (c, res, sp, sol)
+    solver.tuning("setup", -1)
     a, b = out["host"], out["gpu"]
     assert a[0] == b[0] and np.array_equal(a[1], b[1])
     assert a[2][0] == b[2][0] and a[2][1] == b[2][1] and np.array_equal(a[2][2], b[2][2]) and np.array_equal(a[2][3], b[2][3])
