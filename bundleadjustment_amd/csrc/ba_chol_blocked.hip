@@ -33,14 +33,13 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------------------------
 // acc += A[rows ar0 .. ar0+127][kb .. ke) * B[rows br0 .. br0+127][kb .. ke)^T ; rows >= am / bm read as zero.
 // kb is even; columns up to the next even number after ke are read (padding or zeros).
-template <int KCT>
-__device__ __forceinline__ void gemm_tile_nt_k(const double *__restrict__ A, int lda, int ar0, int am, const double *__restrict__ B,
+__device__ __forceinline__ void gemm_tile_nt(const double *__restrict__ A, int lda, int ar0, int am, const double *__restrict__ B,
                                              int ldb, int br0, int bm, int kb, int ke, double *sA, double *sB, d4 (&acc)[4][4]) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wr = w >> 1, wc = w & 1, lr = lane & 15, lk = lane >> 4;
   const int row = t >> 1, h = t & 1;
   const bool aon = ar0 + row < am, bon = br0 + row < bm;
-  constexpr int HK = KCT / 2, NJ = KCT / 4;  // a thread stages half a chunk row: HK columns as NJ 16-byte pieces
+  constexpr int HK = KC / 2, NJ = KC / 4;  // a thread stages half a chunk row: HK columns as NJ 16-byte pieces
   const double *ap = A + (int64_t)(ar0 + row) * lda + HK * h, *bp = B + (int64_t)(br0 + row) * ldb + HK * h;
   double2 ra[NJ], rb[NJ];
   auto fetch = [&](int k0) {
@@ -52,7 +51,7 @@ __device__ __forceinline__ void gemm_tile_nt_k(const double *__restrict__ A, int
     }
   };
   fetch(kb);
-  for (int k0 = kb; k0 < ke; k0 += KCT) {
+  for (int k0 = kb; k0 < ke; k0 += KC) {
     __syncthreads();  // the previous chunk has been read
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -62,9 +61,9 @@ __device__ __forceinline__ void gemm_tile_nt_k(const double *__restrict__ A, int
       sB[(HK * h + 2 * j + 1) * LDT + row] = rb[j].y;
     }
     __syncthreads();
-    if (k0 + KCT < ke) fetch(k0 + KCT);  // in flight during the products below
+    if (k0 + KC < ke) fetch(k0 + KC);  // in flight during the products below
 #pragma unroll
-    for (int kk = 0; kk < KCT / 4; ++kk) {
+    for (int kk = 0; kk < KC / 4; ++kk) {
       double fa[4], fb[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
@@ -77,11 +76,6 @@ __device__ __forceinline__ void gemm_tile_nt_k(const double *__restrict__ A, int
         for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[c], acc[a][c], 0, 0, 0);
     }
   }
-}
-
-__device__ __forceinline__ void gemm_tile_nt(const double *__restrict__ A, int lda, int ar0, int am, const double *__restrict__ B,
-                                             int ldb, int br0, int bm, int kb, int ke, double *sA, double *sB, d4 (&acc)[4][4]) {
-  gemm_tile_nt_k<KC>(A, lda, ar0, am, B, ldb, br0, bm, kb, ke, sA, sB, acc);
 }
 
 enum { GEMM_TRSM = 0, GEMM_SYRK = 1, GEMM_INV_T = 2, GEMM_INV_U = 3, GEMM_INV_S = 4 };
@@ -104,7 +98,7 @@ __device__ __forceinline__ void tri_tile(int b, int &ti, int &tj) {
   tj = b - (int)((int64_t)i * (i + 1) / 2);
 }
 
-template <int MODE, int KCT = KC>
+template <int MODE>
 __device__ __forceinline__ void gemm_nt_block(const GemmArgs &g, const int bx, double *sA, double *sB) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wr = w >> 1, wc = w & 1, lr = lane & 15, lk = lane >> 4;
@@ -121,7 +115,7 @@ __device__ __forceinline__ void gemm_nt_block(const GemmArgs &g, const int bx, d
   if (MODE == GEMM_TRSM) {
     // X = A[r0 .., k0 .. k0+kw) W^T, in place (a workgroup reads its rows completely before it writes them)
     r0 = g.k0 + g.kw + CB * bx;
-    gemm_tile_nt_k<KCT>(g.A + g.k0, ld, r0, n, g.W, CB, 0, g.kw, 0, g.kw, sA, sB, acc);
+    gemm_tile_nt(g.A + g.k0, ld, r0, n, g.W, CB, 0, g.kw, 0, g.kw, sA, sB, acc);
     C = g.A + g.k0;
     c0 = 0;
     cmax = g.kw;
@@ -131,7 +125,7 @@ __device__ __forceinline__ void gemm_nt_block(const GemmArgs &g, const int bx, d
     const int t0 = g.k0 + g.kw;
     r0 = t0 + CB * ti;
     c0 = t0 + CB * tj;
-    gemm_tile_nt_k<KCT>(g.A + g.k0, ld, r0, n, g.A + g.k0, ld, c0, n, 0, g.kw, sA, sB, acc);
+    gemm_tile_nt(g.A + g.k0, ld, r0, n, g.A + g.k0, ld, c0, n, 0, g.kw, sA, sB, acc);
     C = g.A;
     alpha = -1.0;
     beta = 1.0;
@@ -140,7 +134,7 @@ __device__ __forceinline__ void gemm_nt_block(const GemmArgs &g, const int bx, d
     // T^T[k-block rows][i-block cols] = sum_{j = k .. i-1} U[k, j] L[i, j]^T   (blocks of CB), one tile per k < ib
     const int kblk = bx;
     r0 = CB * kblk;
-    gemm_tile_nt_k<KCT>(g.U, ld, r0, n, g.A, ld, CB * g.ib, n, CB * kblk, CB * g.ib, sA, sB, acc);
+    gemm_tile_nt(g.U, ld, r0, n, g.A, ld, CB * g.ib, n, CB * kblk, CB * g.ib, sA, sB, acc);
     // T (CB x ld) holds tile k as a CB x CB block at column CB k: rows = rows of block k, columns = rows of block ib
     C = g.T;
     r0 = 0;
@@ -150,7 +144,7 @@ __device__ __forceinline__ void gemm_nt_block(const GemmArgs &g, const int bx, d
   } else if (MODE == GEMM_INV_U) {
     // U[k, ib] = - T^T[k] W_ib^T
     const int kblk = bx;
-    gemm_tile_nt_k<KCT>(g.T + CB * kblk, ld, 0, CB, g.W + (int64_t)g.ib * CB * CB, CB, 0, CB, 0, min(CB, n - CB * g.ib), sA, sB, acc);
+    gemm_tile_nt(g.T + CB * kblk, ld, 0, CB, g.W + (int64_t)g.ib * CB * CB, CB, 0, CB, 0, min(CB, n - CB * g.ib), sA, sB, acc);
     C = g.U;
     r0 = CB * kblk;
     c0 = CB * g.ib;
@@ -161,7 +155,7 @@ __device__ __forceinline__ void gemm_nt_block(const GemmArgs &g, const int bx, d
     tri_tile(bx, ti, tj);
     r0 = CB * ti;
     c0 = CB * tj;
-    gemm_tile_nt_k<KCT>(g.U, ld, r0, n, g.U, ld, c0, n, CB * ti, n, sA, sB, acc);
+    gemm_tile_nt(g.U, ld, r0, n, g.U, ld, c0, n, CB * ti, n, sA, sB, acc);
     C = g.A;
   }
   // C layout of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4 * reg.
@@ -523,18 +517,138 @@ k_front_diag(const FrontDesc *__restrict__ fd, int kp, int *__restrict__ info) {
   chol_diag_block(f.A, f.nv, f.ld, k0, f.W + (int64_t)kp * CB * CB, info, Tm);
 }
 
-template <int MODE>
+// Product tile for the panel steps of the fronts: BM x BN of C from K = 128 columns, four waves of (BM/2) x (BN/2), two
+// chunks of 16 columns in flight.  A 128 x 128 tile keeps one CU busy for 24 us whatever the size of the front (4.2
+// MFLOP at a CU's 0.3 TFLOP/s), and a panel step of a front of a few thousand rows has only a few dozen of them for 256
+// CUs: tiles of 64 rows spread the same step over four times as many CUs.
+template <int BM, int BN>
+__device__ __forceinline__ void front_tile_nt(const double *__restrict__ A, int lda, int ar0, int am, const double *__restrict__ B, int ldb, int br0,
+                                              int bm, double *sA, double *sB, d4 (&acc)[BM / 32][BN / 32]) {
+  constexpr int LA = BM + 16, LB = BN + 16;               // strides = 16 mod 32: the four k rows a wave reads fall into both bank halves
+  constexpr int TA = 256 / BM, TB = 256 / BN;             // threads per staged row
+  constexpr int CA = KC / TA, CBN = KC / TB;              // columns of a chunk per thread
+  constexpr int NA = CA / 2, NB = CBN / 2;                // as 16-byte pieces
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wr = w >> 1, wc = w & 1, lr = lane & 15, lk = lane >> 4;
+  const int rowa = t / TA, qa = t % TA, rowb = t / TB, qb = t % TB;
+  const bool aon = ar0 + rowa < am, bon = br0 + rowb < bm;
+  const double *ap = A + (int64_t)(aon ? ar0 + rowa : ar0) * lda + CA * qa, *bp = B + (int64_t)(bon ? br0 + rowb : br0) * ldb + CBN * qb;
+  double2 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
+  auto fetch = [&](int k0, double2 (&xa)[NA], double2 (&xb)[NB]) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) xa[j] = aon ? *reinterpret_cast<const double2 *>(ap + k0 + 2 * j) : make_double2(0.0, 0.0);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) xb[j] = bon ? *reinterpret_cast<const double2 *>(bp + k0 + 2 * j) : make_double2(0.0, 0.0);
+  };
+  auto stage = [&](const double2 (&xa)[NA], const double2 (&xb)[NB]) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      sA[(CA * qa + 2 * j) * LA + rowa] = xa[j].x;
+      sA[(CA * qa + 2 * j + 1) * LA + rowa] = xa[j].y;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      sB[(CBN * qb + 2 * j) * LB + rowb] = xb[j].x;
+      sB[(CBN * qb + 2 * j + 1) * LB + rowb] = xb[j].y;
+    }
+    __syncthreads();
+  };
+  auto multiply = [&]() {
+#pragma unroll
+    for (int kk = 0; kk < KC / 4; ++kk) {
+      double fa[BM / 32], fb[BN / 32];
+#pragma unroll
+      for (int a = 0; a < BM / 32; ++a) fa[a] = sA[(4 * kk + lk) * LA + (BM / 2) * wr + 16 * a + lr];
+#pragma unroll
+      for (int c = 0; c < BN / 32; ++c) fb[c] = sB[(4 * kk + lk) * LB + (BN / 2) * wc + 16 * c + lr];
+#pragma unroll
+      for (int a = 0; a < BM / 32; ++a)
+#pragma unroll
+        for (int c = 0; c < BN / 32; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[c], acc[a][c], 0, 0, 0);
+    }
+  };
+  fetch(0, ra0, rb0);
+  fetch(KC, ra1, rb1);
+#pragma unroll
+  for (int k0 = 0; k0 < CB; k0 += 2 * KC) {
+    stage(ra0, rb0);
+    if (k0 + 2 * KC < CB) fetch(k0 + 2 * KC, ra0, rb0);
+    multiply();
+    stage(ra1, rb1);
+    if (k0 + 3 * KC < CB) fetch(k0 + 3 * KC, ra1, rb1);
+    multiply();
+  }
+}
+
+// rows below panel kp: X = A[rows, panel] W^T in place, 64 rows (all 128 columns: a workgroup owns its rows) per workgroup
 __global__ void __launch_bounds__(256, 2)
-k_front_gemm(const FrontDesc *__restrict__ fd, int kp) {
-  __shared__ double sA[KC * LDT], sB[KC * LDT];
+k_front_trsm(const FrontDesc *__restrict__ fd, int kp) {
+  __shared__ double sA[KC * (64 + 16)], sB[KC * (CB + 16)];
   const FrontDesc f = fd[blockIdx.y];
   const int k0 = CB * kp;
   if (k0 >= f.nvp) return;
-  const int T = (f.m - k0 - CB + CB - 1) / CB;  // tiles of rows below the panel
-  if ((int)blockIdx.x >= (MODE == GEMM_TRSM ? T : T * (T + 1) / 2)) return;
-  GemmArgs g{};
-  g.A = f.A; g.W = f.W + (int64_t)kp * CB * CB; g.n = f.m; g.ld = f.ld; g.k0 = k0; g.kw = CB;
-  gemm_nt_block<MODE>(g, blockIdx.x, sA, sB);
+  const int r0 = k0 + CB + 64 * blockIdx.x;
+  if (r0 >= f.m) return;
+  d4 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
+  front_tile_nt<64, CB>(f.A + k0, f.ld, r0, f.m, f.W + (int64_t)kp * CB * CB, CB, 0, CB, sA, sB, acc);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 1, wc = w & 1, lr = lane & 15, lk = lane >> 4;
+  double *C = f.A + k0;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int r = r0 + 32 * wr + 16 * a + lk + 4 * reg;
+      if (r >= f.m) continue;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) C[(int64_t)r * f.ld + 64 * wc + 16 * c + lr] = acc[a][c][reg];
+    }
+}
+
+// trailing update C -= X X^T over the 64 x 64 tiles of the lower triangle
+__global__ void __launch_bounds__(256, 2)
+k_front_syrk(const FrontDesc *__restrict__ fd, int kp) {
+  __shared__ double sA[KC * (64 + 16)], sB[KC * (64 + 16)];
+  const FrontDesc f = fd[blockIdx.y];
+  const int k0 = CB * kp;
+  if (k0 >= f.nvp) return;
+  const int t0 = k0 + CB, T = (f.m - t0 + 63) / 64;
+  if ((int)blockIdx.x >= T * (T + 1) / 2) return;
+  int ti, tj;
+  tri_tile(blockIdx.x, ti, tj);
+  const int r0 = t0 + 64 * ti, c0 = t0 + 64 * tj;
+  d4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
+  front_tile_nt<64, 64>(f.A + k0, f.ld, r0, f.m, f.A + k0, f.ld, c0, f.m, sA, sB, acc);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 1, wc = w & 1, lr = lane & 15, lk = lane >> 4;
+  double *dst[2][4][2];
+  double old[2][4][2];
+  bool ok[2][4][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int r = r0 + 32 * wr + 16 * a + lk + 4 * reg, cc = c0 + 32 * wc + 16 * c + lr;
+        ok[a][reg][c] = r < f.m && cc <= r;
+        dst[a][reg][c] = f.A + (int64_t)min(r, f.m - 1) * f.ld + min(cc, f.m - 1);
+        old[a][reg][c] = *dst[a][reg][c];
+      }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        if (ok[a][reg][c]) *dst[a][reg][c] = old[a][reg][c] - acc[a][c][reg];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -760,10 +874,10 @@ void launch_front_panels(hipStream_t s, const FrontDesc *fd, int n_fronts, int n
   }
   for (int kp = 0; kp < n_panels; ++kp) {
     hipLaunchKernelGGL(k_front_diag, dim3(n_fronts), dim3(256), lds, s, fd, kp, info);
-    const int T = (max_m - CB * kp - CB + CB - 1) / CB;  // of the largest front
+    const int T = (max_m - CB * kp - CB + 63) / 64;  // tiles of 64 rows below the panel, of the largest front
     if (T <= 0) continue;
-    hipLaunchKernelGGL(k_front_gemm<GEMM_TRSM>, dim3(T, n_fronts), dim3(256), 0, s, fd, kp);
-    hipLaunchKernelGGL(k_front_gemm<GEMM_SYRK>, dim3(T * (T + 1) / 2, n_fronts), dim3(256), 0, s, fd, kp);
+    hipLaunchKernelGGL(k_front_trsm, dim3(T, n_fronts), dim3(256), 0, s, fd, kp);
+    hipLaunchKernelGGL(k_front_syrk, dim3(T * (T + 1) / 2, n_fronts), dim3(256), 0, s, fd, kp);
   }
 }
 int front_panel() { return CB; }
