@@ -73,6 +73,8 @@ def kernel_bytes(which, n_obs, n_pts, n_sta, n_blocks=0, n_pairs=0, ncam=0):
 
 JS_PAIR = "Jacobian + Schur assembly (k_point_elim + k_obs_rows + k_schur_blocks)"
 KERNEL_NAMES = {0: "linearisation (k_point_elim + k_obs_rows)", 7: "k_point_elim", 8: "k_obs_rows", 1: "k_point_apply", 2: "k_station_pass<GATHER>", 3: "k_cost_obs",
+                13: "sparse Cholesky factorisation (front assembly + k_front_diag + k_front_trsm + k_front_syrk per panel and level)",
+                14: "sparse Cholesky factorisation + forward and backward solves on the tree",
                 4: "k_schur_blocks", 5: "pcg iteration (k_bsr_spmv + k_cg2_update1 + k_amg_restrict x levels + k_amg_prolong + k_amg_update2)", 6: "k_bsr_spmv"}
 
 
@@ -171,6 +173,9 @@ def main():
     ap.add_argument("--config", default="cfg4")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the network (stations and points) for quick runs")
     ap.add_argument("--pcg-rtol", type=float, default=1e-12, help="PCG stopping tolerance; 1e-12 is what the parity tests use")
+    ap.add_argument("--solver", choices=("auto", "pcg", "sparse"), default="auto",
+                    help="reduced solve of the networks beyond the dense limit: what BA_SOLVER_AUTO picks (the sparse direct "
+                         "Cholesky up to order 100 000, the PCG beyond), or one of the two by name")
     ap.add_argument("--cpu-scale", type=float, default=0.02, help="size of the CPU-baseline sample relative to the config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full-budget", type=float, default=90.0,
@@ -225,11 +230,14 @@ def main():
     P.set_parameters()
 
     free_cam = int(sum(bin(int(a)).count("1") + bin(int(b) & 7).count("1") for a, b in zip(full.ap_free_mask, full.iop_free_mask)))
-    dense = 6 * full.n_sta + free_cam <= capi.AUTO_DENSE_ORDER  # what BA_SOLVER_AUTO picks: the two small networks
+    n_red = 6 * full.n_sta + free_cam
+    dense = n_red <= capi.AUTO_DENSE_ORDER  # what BA_SOLVER_AUTO picks: the two small networks
+    sparse = not dense and (args.solver == "sparse" or (args.solver == "auto" and n_red <= capi.AUTO_SPARSE_ORDER))
+    ls_main = capi.SOLVER_DENSE_SCHUR if dense else capi.SOLVER_SPARSE_SCHUR if sparse else capi.SOLVER_PCG_SCHUR
 
-    def options(iters):
+    def options(iters, ls=None):
         o = solver.default_options()
-        o.linear_solver = capi.SOLVER_DENSE_SCHUR if dense else capi.SOLVER_PCG_SCHUR
+        o.linear_solver = ls_main if ls is None else ls
         o.pcg_rtol = args.pcg_rtol
         o.pcg_max_iters = 20000
         o.max_num_iterations = iters
@@ -306,8 +314,31 @@ def main():
             dist.destroy_process_group()
         return
 
+    # the other sparse solver on the same network, outside the timed region: its time per step and its final cost
+    other = None
+    if world == 1:
+        ls_other = capi.SOLVER_PCG_SCHUR if sparse else capi.SOLVER_SPARSE_SCHUR
+        try:
+            P.set_parameters()
+            P.solve_resident(options(1, ls_other))  # its structures (hierarchy or tree) are built once, untimed
+            P.set_parameters()
+            barrier()
+            t1 = time.perf_counter()
+            sm_o, rows_o = P.solve_resident(options(args.steps, ls_other))
+            barrier()
+            other = {"solver": "pcg (multilevel preconditioner)" if sparse else "sparse Cholesky (nested dissection, multifrontal)",
+                     "ms_per_step": 1e3 * (time.perf_counter() - t1) / args.steps, "final_cost": sm_o["final_cost"],
+                     "linear_iterations_per_step": sm_o["total_linear_iterations"] / args.steps,
+                     "final_cost_relative_difference": abs(sm_o["final_cost"] - sm["final_cost"]) / sm["final_cost"]}
+        except solver.BaError as e:
+            other = {"error": str(e)}
+        # leave the problem as the timed solve left its structures: the kernels below are timed on the main solver's
+        P.set_parameters()
+        P.solve_resident(options(1))
+        P.set_parameters()
+
     # per-kernel timing with HIP events on the solver's stream (live, same process)
-    which_all = (0, 7, 8, 4, 6, 5, 3)
+    which_all = (0, 7, 8, 4, 14, 13, 3) if sparse else (0, 7, 8, 4, 6, 5, 3)
     ktime = {w: P.time_kernel(w, 10) for w in which_all}
     if world > 1:
         t = torch.tensor([ktime[w] for w in which_all], dtype=torch.float64, device=red_dev)
@@ -315,7 +346,8 @@ def main():
         ktime = {w: float(t[i].item()) for i, w in enumerate(which_all)}
     lin_iters = sm["total_linear_iterations"]
     n_lin = sum(1 for r in rows if r["step_is_successful"]) + 1
-    calls = {0: n_lin, 7: n_lin, 8: n_lin, 4: n_lin, 5: lin_iters, 6: lin_iters, 3: args.steps}
+    calls = {0: n_lin, 7: n_lin, 8: n_lin, 4: n_lin, 5: lin_iters, 6: lin_iters, 3: args.steps, 13: args.steps, 14: args.steps}
+    tree = P.sparse_solver_stats() if sparse else None
     n_pairs, n_blocks = structure_counts(net)
     ncam = int(sum(bin(int(a)).count("1") + bin(int(b) & 7).count("1") for a, b in zip(net.ap_free_mask, net.iop_free_mask)))
     full_pairs, full_blocks = (n_pairs, n_blocks) if world == 1 else structure_counts(full)
@@ -336,6 +368,14 @@ def main():
     traffic = [measured_traffic(KERNEL_NAMES[w], args.config, args.scale, world) for w in (7, 8, 4)]
     kernels = []
     for w in which_all:
+        if w in (13, 14):
+            # not a memory-bound kernel: the operations of the factorisation against the fp64 peak of the matrix cores
+            kernels.append({"kernel": KERNEL_NAMES[w], "ms": ktime[w] * 1e3, "launches_in_timed_region": calls[w],
+                            "flops": tree["factor_flops"], "TFLOPs": tree["factor_flops"] / ktime[w] / 1e12,
+                            "frac_of_mfma_peak": tree["factor_flops"] / ktime[w] / 78.6e12, "share_of_step_time": ktime[w] * calls[w] / elapsed,
+                            "note": "a chain of %d panel steps (diagonal block, rows below, trailing update) over %d levels of the "
+                                    "elimination tree: bound by the length of the chain, not by the operations" % (tree["critical_panels"], tree["levels"])})
+            continue
         b = kb(w)
         kernels.append({"kernel": KERNEL_NAMES[w], "ms": ktime[w] * 1e3, "launches_in_timed_region": calls[w],
                         "algorithmic_GB": b / 1e9, "GBps": b / ktime[w] / 1e9, "frac": b / ktime[w] / 1e9 / HBM_PEAK_GBS,
@@ -348,7 +388,7 @@ def main():
     # every rank (multi-GPU); four sums over the ranks per LM iteration, of which one is large.
     lin_ms = 1e3 * sum(r["t_linearize_s"] for r in rows[1:]) / max(len(rows) - 1, 1)
     solve_ms = 1e3 * sum(r["t_solve_s"] + r["t_eval_s"] for r in rows[1:]) / max(len(rows) - 1, 1)
-    pcg_ms = 1e3 * ktime[5] * lin_iters / args.steps
+    pcg_ms = 1e3 * ktime[14] if sparse else 1e3 * ktime[5] * lin_iters / args.steps
     divides_ms = world * (1e3 * (ktime[7] + ktime[8] + ktime[4] + ktime[3]))  # Jacobians, Schur assembly, candidate cost
     red_bytes = [8.0 * (39 * full.n_sta + 3 * ncam + 1), 16.0, 8.0 * (36 * full_blocks + 6 * full.n_sta * ncam + max(64, ncam * ncam)), 64.0]
 
@@ -359,11 +399,11 @@ def main():
     other_ms = max(1e3 * step_s - divides_ms / world - sum(t_allreduce_ms(b, world) for b in red_bytes), 0.0)
     scaling_model = {
         "assumptions": "points and observations divide by N (Jacobian kernels, Schur assembly, candidate cost); everything else "
-                       "of a step -- the PCG on the summed reduced system, its hierarchy, folds, back substitution -- is counted as "
+                       "of a step -- the solve of the summed reduced system (sparse Cholesky or PCG), folds, back substitution -- is counted as "
                        "not dividing (the back substitution does divide: the prediction errs on the slow side); four all-reduces per "
                        "LM iteration priced as a ring over 150 GB/s links + 30 us each",
         "measured_on_n_gpus": world, "ms_per_step_measured": 1e3 * step_s,
-        "divides_ms_at_1_gpu": divides_ms, "does_not_divide_ms": other_ms, "pcg_ms_per_step": pcg_ms,
+        "divides_ms_at_1_gpu": divides_ms, "does_not_divide_ms": other_ms, "reduced_solve_ms_per_step": pcg_ms,
         "linearise_phase_ms": lin_ms, "solve_phase_ms": solve_ms,
         "reduction_bytes_per_lm_iteration": red_bytes,
         "predicted_ms_per_step": {str(n): divides_ms / n + other_ms + sum(t_allreduce_ms(b, n) for b in red_bytes) for n in (1, 2, 4, 8)},
@@ -384,9 +424,12 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"{args.config}: {full.n_cam} camera(s), {full.n_sta} stations, {full.n_pts} points, "
-                               f"{full.n_obs} observations, self-calibrating (IOP + k1 k2 p1 p2), point elimination + PCG with a multilevel "
-                               f"(smoothed aggregation) preconditioner on the block-sparse reduced system",
-                   "scale": args.scale, "pcg_rtol": args.pcg_rtol, "sharding": f"points/{world}"},
+                               f"{full.n_obs} observations, self-calibrating (IOP + k1 k2 p1 p2), point elimination + " +
+                               ("sparse direct Cholesky of the block-sparse reduced system (nested dissection, multifrontal, dense fronts on the "
+                                "matrix cores)" if sparse else
+                                "PCG with a multilevel (smoothed aggregation) preconditioner on the block-sparse reduced system"),
+                   "scale": args.scale, "pcg_rtol": args.pcg_rtol, "sharding": f"points/{world}",
+                   "reduced_solver": "sparse_cholesky" if sparse else "pcg"},
         "jacobian_obs_per_s": full.n_obs / ktime[0],
         "pcg_iterations_per_step": lin_iters / args.steps,
         "final_cost": sm["final_cost"],
@@ -396,6 +439,10 @@ def main():
         "kernels": kernels,
         "scaling_model": scaling_model,
     }
+    if tree is not None:
+        out["elimination_tree"] = tree
+    if other is not None:
+        out["other_reduced_solver"] = other
     if per_rank is not None:
         out["per_rank"] = per_rank
     parity_failed = None

@@ -139,7 +139,8 @@ struct ba_problem {
   double *d_part_pq = nullptr, *d_part_qc = nullptr, *d_part_rz = nullptr, *d_cg2scal = nullptr;
   std::vector<int> ub_lo_h, ub_hi_h, bsr_rowptr_h, bsr_col_h;  // host copies of the block structure
   SparseChol *sparse = nullptr;  // BA_SOLVER_SPARSE_SCHUR: the tree and the fronts, built at the first solve
-  bool sparse_failed = false;
+  bool sparse_failed = false, sparse_clear_queued = false;
+  hipEvent_t ev_sparse_clear = nullptr;
   int cov_route = 0, cov_max_cluster = 1536, cov_route_used = 0;  // ba_set_covariance_route / ba_covariance_stats
   SelInvStats cov_stats{};
   std::vector<int> cam_used_h;
@@ -1416,9 +1417,22 @@ int solve_sparse(ba_problem *p) {
       return fail(rc == 1 ? BA_ERR_UNSUPPORTED : BA_ERR_DEVICE, "sparse Cholesky of the reduced system: %s", why.c_str());
     }
   }
+  if (p->sparse_clear_queued) {
+    HIP_OK(hipStreamWaitEvent(s, p->ev_sparse_clear, 0));  // the fronts were zeroed on the second stream after the last solve
+    p->sparse_clear_queued = false;
+  }
   sparse_chol_factor(p->sparse, s, p->d_bsr_val, p->d_Ssc, p->d_Scc, p->d_info);
   HIP_OK(hipMemsetAsync(p->d_x, 0, (size_t)p->nr * sizeof(double), s));  // stations outside the program keep a zero step
   sparse_chol_solve(p->sparse, s, p->d_b, p->d_x);
+  if (p->stream2) {
+    // zeros for the next factorisation while the step is evaluated and the next linearisation runs
+    if (!p->ev_sparse_clear) HIP_OK(hipEventCreateWithFlags(&p->ev_sparse_clear, hipEventDisableTiming));
+    HIP_OK(hipEventRecord(p->ev_sparse_clear, s));
+    HIP_OK(hipStreamWaitEvent(p->stream2, p->ev_sparse_clear, 0));
+    sparse_chol_clear(p->sparse, p->stream2);
+    HIP_OK(hipEventRecord(p->ev_sparse_clear, p->stream2));
+    p->sparse_clear_queued = true;
+  }
   int info = 0;
   HIP_OK(hipMemcpyAsync(&info, p->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
@@ -1627,6 +1641,7 @@ void ba_destroy(ba_problem *p) {
   if (p->cg_graph_tail) hipGraphExecDestroy(p->cg_graph_tail);
   if (p->amg) ba::amg_destroy(p->amg);
   if (p->sparse) ba::sparse_chol_destroy(p->sparse);
+  if (p->ev_sparse_clear) hipEventDestroy(p->ev_sparse_clear);
   for (void *q : p->allocs) hipFree(q);
   if (p->h_scal) hipHostFree(p->h_scal);
   if (p->h_cgscal) hipHostFree(p->h_cgscal);
@@ -1806,8 +1821,9 @@ int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary,
   if (!p->have_params) return fail(BA_ERR_INVALID, "ba_solve_resident: call ba_set_parameters first");
   int linear_solver = opt->linear_solver;
   // The default: dense Cholesky for small reduced systems; the sparse direct solver where it is the faster of the two
-  // sparse routes (measured on the benchmark geometry: 3.6 against 5.9 ms per solve at order 10 800, 6.6 against 7.5 at
-  // 30 000, 9.4 against 8.6 at 45 000); the PCG beyond, and wherever the block-sparse form or a tree is not to be had.
+  // sparse routes (measured on the benchmark geometry, ms per solve against the PCG's: 3.0 / 5.9 at order 10 800, 8.2 / 10.1
+  // at 60 000, 14.7 / 14.9 at 120 000, 38 / 37 at 300 000); the PCG beyond, and wherever the block-sparse form or a tree is
+  // not to be had.
   bool auto_sparse = false;
   if (linear_solver == BA_SOLVER_AUTO) {
     if (p->nr <= BA_AUTO_DENSE_ORDER) linear_solver = BA_SOLVER_DENSE_SCHUR;
@@ -2413,6 +2429,34 @@ int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *second
     *seconds_per_launch = 1e-3 * total_ms / repeats;
     return p->check_kernels();
   }
+  if (which == 13 || which == 14) {
+    // 13: assembly of the fronts and the sparse factorisation; 14: the same with the solve on the tree
+    if (!p->explicit_ok) return fail(BA_ERR_INVALID, "ba_time_kernel: the block-sparse system was not built for this network");
+    if (!p->sparse) return fail(BA_ERR_INVALID, "ba_time_kernel: no solve with BA_SOLVER_SPARSE_SCHUR has run on this problem");
+    if (p->sparse_clear_queued) {
+      HIP_OK(hipStreamWaitEvent(s, p->ev_sparse_clear, 0));
+      p->sparse_clear_queued = false;
+    }
+    double total_ms = 0.0;
+    hipEvent_t f0, f1;
+    HIP_OK(hipEventCreate(&f0));
+    HIP_OK(hipEventCreate(&f1));
+    for (int k = 0; k < repeats + 1; ++k) {
+      sparse_chol_clear(p->sparse, s);  // untimed, as in a solve (there it runs beside the evaluation of the step)
+      HIP_OK(hipEventRecord(f0, s));
+      sparse_chol_factor(p->sparse, s, p->d_bsr_val, p->d_Ssc, p->d_Scc, p->d_info);
+      if (which == 14) sparse_chol_solve(p->sparse, s, p->d_b, p->d_x);
+      HIP_OK(hipEventRecord(f1, s));
+      HIP_OK(hipEventSynchronize(f1));
+      float ms = 0.f;
+      HIP_OK(hipEventElapsedTime(&ms, f0, f1));
+      if (k > 0) total_ms += ms;
+    }
+    hipEventDestroy(f0);
+    hipEventDestroy(f1);
+    *seconds_per_launch = 1e-3 * total_ms / repeats;
+    return p->check_kernels();
+  }
   if (which == 9) {
     // one PCG iteration with time stamps at the phase marks of its kernels, table on stderr
     if (!p->explicit_ok || !with_amg) return fail(BA_ERR_INVALID, "ba_time_kernel: the traced iteration needs the multilevel PCG (solve once first)");
@@ -2658,8 +2702,10 @@ static int sync_shards(ba_problem *p) {
     p->amg = nullptr;
   }
   if (p->sparse) {
+    if (p->stream2) (void)hipStreamSynchronize(p->stream2);
     sparse_chol_destroy(p->sparse);
     p->sparse = nullptr;
+    p->sparse_clear_queued = false;
   }
   p->have_G = false;
   return 0;

@@ -347,6 +347,7 @@ void sparse_chol_destroy(SparseChol *sc);
 // structure, once per network; 0, 1 (does not fit / no valid tree: err says why) or 2 (device failure)
 int sparse_chol_analyse(SparseChol *sc, int S, int ncam, const std::vector<int> &rowptr, const std::vector<int> &col,
                         const std::vector<int> &used, int leaf_stations, std::string &err);
+void sparse_chol_clear(SparseChol *sc, hipStream_t s);  // zeros in the fronts ahead of the next factorisation (optional)
 void sparse_chol_factor(SparseChol *sc, hipStream_t s, const double *bsr_val, const double *Ssc, const double *Scc, int *d_info);
 void sparse_chol_solve(SparseChol *sc, hipStream_t s, const double *b, double *x);  // entries of x outside the program are left alone
 void sparse_chol_stats(const SparseChol *sc, SparseCholStats *st);

@@ -298,6 +298,7 @@ struct SparseChol {
   int root_ld = 0;
   double *d_root_A = nullptr;
   std::vector<void *> allocs;
+  bool zeroed = false;  // the fronts hold zeros already (sparse_chol_clear has run since the last factorisation)
   // statistics
   int n_leaves = 0, largest_front = 0, critical_panels = 0;
   double factor_flops = 0.0;
@@ -635,14 +636,23 @@ int sparse_chol_analyse(SparseChol *sc, int S, int ncam, const std::vector<int> 
   }
   sc->d_root_A = sc->d_arena + lay[0].a_off;
   sc->root_ld = lay[0].ld;
+  sc->zeroed = false;
   return 0;
 }
 
 // Numbers: the blocks of S (with whatever diagonal the caller has added) into the fronts, then the factorisation.
 // info (device) receives a non-zero value when a pivot is not positive.
+// Zeros in the fronts ahead of the next factorisation, on any stream (the caller orders it after the last solve and
+// before the next sparse_chol_factor): 2 GB at the 10 000-station network, a third of a millisecond off the critical path.
+void sparse_chol_clear(SparseChol *sc, hipStream_t s) {
+  (void)hipMemsetAsync(sc->d_arena, 0, (size_t)sc->arena_doubles * sizeof(double), s);
+  sc->zeroed = true;
+}
+
 void sparse_chol_factor(SparseChol *sc, hipStream_t s, const double *bsr_val, const double *Ssc, const double *Scc, int *d_info) {
   (void)hipMemsetAsync(d_info, 0, sizeof(int), s);
-  (void)hipMemsetAsync(sc->d_arena, 0, (size_t)sc->arena_doubles * sizeof(double), s);
+  if (!sc->zeroed) (void)hipMemsetAsync(sc->d_arena, 0, (size_t)sc->arena_doubles * sizeof(double), s);
+  sc->zeroed = false;
   const int64_t n36 = 36 * sc->n_blocks;
   if (n36 > 0) hipLaunchKernelGGL(k_sc_gather_blocks, dim3(nblk(n36, 256)), dim3(256), 0, s, n36, sc->d_blk_dst, sc->d_blk_ld, bsr_val, sc->d_arena);
   if (sc->ncam > 0) {

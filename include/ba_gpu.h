@@ -74,7 +74,7 @@ enum ba_linear_solver {
                                  block-sparse form (BA_ERR_UNSUPPORTED otherwise). */
 };
 #define BA_AUTO_DENSE_ORDER 4096
-#define BA_AUTO_SPARSE_ORDER 32768
+#define BA_AUTO_SPARSE_ORDER 100000
 
 typedef struct {
   int32_t n_obs; /* rows of the .pho file  */
@@ -362,6 +362,9 @@ int ba_residual_jacobian(ba_problem *p, double *r, double *J);
  *   9  one PCG iteration with time stamps at the phase marks of its kernels, printed to stderr (returns 0)
  *  10  Cholesky factorisation of the dense reduced system (n^3 / 3 multiply-adds, n = 6 n_sta + free camera parameters)
  *  11  the same with the two triangular solves
+ *  12  the per-observation kernel that also forms the station sums, with clock counters around its phases (table on stderr)
+ *  13  BA_SOLVER_SPARSE_SCHUR: assembly of the fronts and the sparse factorisation (after a solve with that solver)
+ *  14  the same with the forward and backward solves on the tree
  * No counterpart in the reference (its timers are wall-clock prints, src/main.cpp:3027, 4703).
  */
 int ba_time_kernel(ba_problem *p, int32_t which, int32_t repeats, double *seconds_per_launch);
