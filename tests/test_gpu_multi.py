@@ -96,7 +96,8 @@ def _worker(rank, world, port, ls, n_cam, out, bounded=False, by_rows=False):
 
 
 # one camera: the fused single-camera border and the camera coarse space; three cameras: the general border
-@pytest.mark.parametrize("ls,n_cam,bounded", [(0, 1, False), (1, 1, False), (2, 1, False), (0, 3, False), (1, 3, False), (1, 1, True)])
+@pytest.mark.parametrize("ls,n_cam,bounded", [(0, 1, False), (1, 1, False), (2, 1, False), (0, 3, False), (1, 3, False), (1, 1, True),
+                                               (4, 1, False), (4, 3, False)])  # 4: the sparse direct solver
 def test_two_ranks_match_oracle(ls, n_cam, bounded):
     from oracle import py_oracle as po
     from bundleadjustment_amd import capi
@@ -127,7 +128,7 @@ def test_two_ranks_match_oracle(ls, n_cam, bounded):
         assert res[4]["reductions_in_solve"] <= 4 * len(res[5]) + 4, (res[4]["reductions_in_solve"], len(res[5]))
 
 
-@pytest.mark.parametrize("ls", [0, 1])
+@pytest.mark.parametrize("ls", [0, 1, 4])
 def test_a_rank_without_rows_of_a_camera(ls):
     """A camera that only one rank's share of the points sees: the other rank carries its columns with sums of zero
     (ba_inputs.cam_in_use, filled by the sharding) and the two-rank solve matches the oracle's solve of the network."""
