@@ -643,15 +643,30 @@ int sparse_chol_analyse(SparseChol *sc, int S, int ncam, const std::vector<int> 
 // Numbers: the blocks of S (with whatever diagonal the caller has added) into the fronts, then the factorisation.
 // info (device) receives a non-zero value when a pivot is not positive.
 // Zeros in the fronts ahead of the next factorisation, on any stream (the caller orders it after the last solve and
-// before the next sparse_chol_factor): 2 GB at the 10 000-station network, a third of a millisecond off the critical path.
+// before the next sparse_chol_factor): 1 GB at the 10 000-station network.
+// Only the lower triangles are ever read: half the bytes of a plain fill.  Sixteen rows of one front per workgroup.
+__global__ void __launch_bounds__(256)
+k_sc_zero_lower(const FrontDesc *__restrict__ fd) {
+  const FrontDesc f = fd[blockIdx.y];
+  const int r0 = 16 * blockIdx.x;
+  if (r0 >= f.m) return;
+  const double2 z = make_double2(0.0, 0.0);
+  for (int r = r0 + (threadIdx.x >> 4); r < min(f.m, r0 + 16); r += 16) {
+    double2 *row = reinterpret_cast<double2 *>(f.A + (int64_t)r * f.ld);
+    const int n2 = min(f.ld, r + 2) / 2;  // columns 0 .. r, rounded up to a pair
+    for (int c = threadIdx.x & 15; c < n2; c += 16) row[c] = z;
+  }
+}
+
 void sparse_chol_clear(SparseChol *sc, hipStream_t s) {
-  (void)hipMemsetAsync(sc->d_arena, 0, (size_t)sc->arena_doubles * sizeof(double), s);
+  if (sc->n_fronts > 0 && sc->largest_front > 0)
+    hipLaunchKernelGGL(k_sc_zero_lower, dim3(nblk(sc->largest_front, 16), sc->n_fronts), dim3(256), 0, s, sc->d_desc);
   sc->zeroed = true;
 }
 
 void sparse_chol_factor(SparseChol *sc, hipStream_t s, const double *bsr_val, const double *Ssc, const double *Scc, int *d_info) {
   (void)hipMemsetAsync(d_info, 0, sizeof(int), s);
-  if (!sc->zeroed) (void)hipMemsetAsync(sc->d_arena, 0, (size_t)sc->arena_doubles * sizeof(double), s);
+  if (!sc->zeroed) sparse_chol_clear(sc, s);
   sc->zeroed = false;
   const int64_t n36 = 36 * sc->n_blocks;
   if (n36 > 0) hipLaunchKernelGGL(k_sc_gather_blocks, dim3(nblk(n36, 256)), dim3(256), 0, s, n36, sc->d_blk_dst, sc->d_blk_ld, bsr_val, sc->d_arena);
