@@ -2284,6 +2284,105 @@ int ba_covariance_cameras(ba_problem *p, double *var_iop, double *var_ap) {
   return 0;
 }
 
+int ba_covariance_camera_rows(ba_problem *p, int32_t *n_rows, int32_t *cam_param, double *cov_eop, double *cov_xyz, double *cov_cam) {
+  if (!p) return fail(BA_ERR_INVALID, "ba_covariance_camera_rows: null problem");
+  if (!p->have_params) return fail(BA_ERR_INVALID, "ba_covariance_camera_rows: no parameters set");
+  if (p->ar) return fail(BA_ERR_UNSUPPORTED, "ba_covariance_camera_rows: one rank only (the points of a sharded problem lie on several)");
+  const int n = p->nr, ncam = p->ncam;
+  const size_t ns = 6 * (size_t)p->S, np3 = 3 * (size_t)p->P;
+  if (n_rows) *n_rows = ncam;
+  if (cam_param)
+    for (int c = 0; c < p->C; ++c) {
+      const CamRec &r = p->cam_h[c];
+      int pos = 0;
+      for (int q = 0; q < BA_NCAMPAR; ++q)
+        if (r.mask & (1u << q)) cam_param[r.off + pos++] = BA_NCAMPAR * c + q;
+    }
+  if (ncam == 0) return 0;
+  hipStream_t s = p->stream;
+  ba_options opt;
+  ba_default_options(&opt);
+  // as ba_covariance: Jacobi scaling for the conditioning (undone below), no damping.  Row k of the camera part of Cx is
+  // the solution of S x = e_k on the reduced unknowns and -V^-1 W^T x on the points: the back substitution of a step
+  // with the point gradient set to zero.
+  BA_TRY(init_scaling(p, &opt));
+  LmState st{1e300, opt.min_lm_diagonal, opt.max_lm_diagonal, false, false, p->explicit_ok ? 2 : 1};
+  st.full_rows = true;  // the back substitution below reads the rows
+  BA_TRY(linearize(p, st));
+  int how = 0;  // 0 dense factor, 1 sparse factor, 2 one PCG solve per row
+  if (p->explicit_ok && n > BA_AUTO_DENSE_ORDER) how = (n <= BA_AUTO_SPARSE_ORDER && !p->sparse_failed) ? 1 : 2;
+  const int forced = (int)tuning_value("rows_solver", -1.0);  // for comparisons of the three routes
+  if (forced >= 0 && forced <= 2 && (forced == 0 || p->explicit_ok)) how = forced;
+  if (how == 2 && ncam > cg2_max_cam())
+    return fail(BA_ERR_UNSUPPORTED, "ba_covariance_camera_rows: %d free camera parameters, the block-sparse PCG takes at most %d", ncam, cg2_max_cam());
+  std::vector<double> sc_sta(std::max<size_t>(ns, 1)), sc_cam((size_t)ncam), sc_pt, x((size_t)n), y;
+  HIP_OK(hipMemcpyAsync(sc_sta.data(), p->d_scale_sta, ns * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(sc_cam.data(), p->d_scale_cam, ncam * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (cov_xyz) {
+    sc_pt.resize(std::max<size_t>(np3, 1));
+    y.resize(std::max<size_t>(np3, 1));
+    HIP_OK(hipMemcpyAsync(sc_pt.data(), p->d_scale_pt, np3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemsetAsync(p->d_g_pt, 0, np3 * sizeof(double), s));
+  }
+  bool factored = false;
+  for (int k = 0; k < ncam; ++k) {
+    launch_unit(s, n, p->d_b, (int64_t)ns + k);
+    if (how == 1) {
+      if (!factored) {
+        const int rc = solve_sparse(p);
+        if (rc == BA_ERR_UNSUPPORTED) {  // no tree for this network: the PCG after all
+          p->sparse_failed = true;
+          if (ncam > cg2_max_cam()) return rc;
+          how = 2;
+        } else if (rc) {
+          return rc;
+        }
+        factored = true;
+      } else {
+        HIP_OK(hipMemsetAsync(p->d_x, 0, (size_t)n * sizeof(double), s));
+        sparse_chol_solve(p->sparse, s, p->d_b, p->d_x);
+      }
+    }
+    if (how == 0) {
+      if (!factored) {
+        BA_TRY(build_dense(p, p->explicit_ok));
+        launch_dense_fix_unused(s, p->S, p->dense_ld, p->d_sta_used, p->d_Sdense);
+        BA_TRY(factor_dense(p));
+        int info = 0;
+        HIP_OK(hipMemcpyAsync(&info, p->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        if (info) return fail(BA_ERR_NUMERIC, "ba_covariance_camera_rows: the reduced normal matrix is rank deficient (column %d of %d)", info - 1, n);
+        factored = true;
+      }
+      launch_copy(s, n, p->d_b, p->d_x);
+      if (p->dense_blocked) launch_chol_solve_blocked(s, p->d_Sdense, n, p->dense_ld, p->d_cholW, p->d_x);
+      else launch_chol_solve(s, p->d_Sdense, n, p->d_x);
+    } else if (how == 2) {
+      int iters = 0;
+      BA_TRY(solve_pcg_explicit(p, &opt, &iters));
+    }
+    if (cov_xyz) {
+      PointArgs pa = point_args(p, p->d_x);
+      launch_point_pass(s, pa, MODE_BACKSUB, true);
+      HIP_OK(hipMemcpyAsync(y.data(), p->d_y_pt, np3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    HIP_OK(hipMemcpyAsync(x.data(), p->d_x, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    BA_TRY(p->check_kernels());
+    const double sk = sc_cam[k];
+    if (!(x[ns + k] > 0.0) || !std::isfinite(x[ns + k]))
+      return fail(BA_ERR_NUMERIC, "ba_covariance_camera_rows: camera column %d: the reduced normal matrix is not positive definite", k);
+    if (cov_eop)
+      for (size_t i = 0; i < ns; ++i) cov_eop[(size_t)k * ns + i] = p->sta_used_h[i / 6] ? x[i] * sc_sta[i] * sk : 0.0;
+    if (cov_cam)
+      for (int m = 0; m < ncam; ++m) cov_cam[(size_t)k * ncam + m] = x[ns + m] * sc_cam[m] * sk;
+    if (cov_xyz)
+      for (size_t jj = 0; jj < (size_t)p->P; ++jj)
+        for (int m = 0; m < 3; ++m) cov_xyz[(size_t)k * np3 + 3 * (size_t)p->pt_file[jj] + m] = y[3 * jj + m] * sc_pt[3 * jj + m] * sk;
+  }
+  return 0;
+}
+
 int ba_evaluate(ba_problem *p, const double *eop, const double *xyz, const double *iop, const double *ap, int apply_loss,
                 double *cost, double *residuals) {
   if (!p) return fail(BA_ERR_INVALID, "ba_evaluate: null problem");

@@ -160,7 +160,8 @@ struct Tuning {
   bool set;
 };
 Tuning g_tuning[] = {{"setup", -1.0, false},     {"pcg_graph", 1.0, false},     {"amg_levels", 3.0, false},  {"amg_theta", 0.5, false},
-                     {"fused_sums", 1.0, false}, {"schur_windows", 1.0, false}, {"keyed_tiles", 16.0, false}};
+                     {"fused_sums", 1.0, false}, {"schur_windows", 1.0, false}, {"keyed_tiles", 16.0, false},
+                     {"rows_solver", -1.0, false}};
 }  // namespace
 
 double tuning_value(const char *name, double dflt) {

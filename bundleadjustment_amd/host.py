@@ -47,6 +47,15 @@ class Qc(C.Structure):
                 ("rmse_average", C.c_double)]
 
 
+class Correlations(C.Structure):
+    """ba_correlations: [max, median, mean, min] tables of |correlation| and the camera corner."""
+    _fields_ = [("eop_iop", C.c_double * 3 * 6 * 4), ("eop_ap", C.c_double * 16 * 6 * 4), ("xyz_iop", C.c_double * 3 * 3 * 4),
+                ("xyz_ap", C.c_double * 16 * 3 * 4), ("iop_ap", C.c_double * 16 * 3), ("ap_ap", C.c_double * 16 * 16)]
+
+    def as_dict(self):
+        return {k: np.ctypeslib.as_array(getattr(self, k)).copy() for k, _ in self._fields_}
+
+
 # AP bit positions: a1 a2 k1 k2 k3 p1 p2 ep1..ep9 (src/main.cpp:3588-3604)
 AP_BITS = {"a1": 0, "a2": 1, "k1": 2, "k2": 3, "k3": 4, "p1": 5, "p2": 6,
            **{f"ep{i}": 6 + i for i in range(1, 10)}}
@@ -128,6 +137,9 @@ def lib():
         L.ba_net_set_corrections.argtypes = [C.c_void_p, c_double_p, c_double_p]
         L.ba_read_ml_cost.argtypes = [C.c_char_p, c_double_p, c_double_p, c_double_p]
         L.ba_append_costs.argtypes = [C.c_char_p, C.c_int32] + [C.c_double] * 6 + [c_double_p]
+        L.ba_correlations_compute.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, c_int32_p] + [c_double_p] * 7 + \
+                                             [C.POINTER(Correlations)]
+        L.ba_print_correlations.argtypes = [C.POINTER(Correlations), C.c_char_p]
         L.ba_sigma0.restype = C.c_double
         L.ba_sigma0.argtypes = [C.POINTER(BaSummary), C.c_int32, C.c_int32, c_double_p]
         _lib = L
@@ -317,6 +329,25 @@ def synth_config(name, scale=1.0, **kw):
         cfg["n_pts"] = max(16, int(round(cfg["n_pts"] * scale)))
     cfg.update(kw)
     return synth(**cfg)
+
+
+def correlations(variances, rows, camera=0, path=None, text=False):
+    """The correlation tables of src/main.cpp:5592-6495 for one camera.  variances = Problem.covariance(),
+    rows = Problem.covariance_camera_rows(); returns a dict of arrays (eop_iop [4,6,3], eop_ap [4,6,16], xyz_iop
+    [4,3,3], xyz_ap [4,3,16]: max, median, mean, min of |correlation|; iop_ap [3,16], ap_ap [16,16]); text=True also
+    writes the reference's console lines to `path` (None: stdout)."""
+    ve, vx, vi, va = (np.ascontiguousarray(a, dtype=np.float64) for a in variances)
+    par, ce, cx, cc = rows
+    par = np.ascontiguousarray(par, dtype=np.int32)
+    ce, cc = np.ascontiguousarray(ce, dtype=np.float64), np.ascontiguousarray(cc, dtype=np.float64)
+    cx = None if cx is None else np.ascontiguousarray(cx, dtype=np.float64)
+    dp = lambda a: None if a is None else a.ctypes.data_as(c_double_p)  # noqa: E731
+    out = Correlations()
+    _check(lib().ba_correlations_compute(ve.size // 6, vx.size // 3, int(camera), len(par), par.ctypes.data_as(c_int32_p), dp(ve), dp(vx),
+                                         dp(vi), dp(va), dp(ce), dp(cx), dp(cc), C.byref(out)))
+    if text:
+        _check(lib().ba_print_correlations(C.byref(out), None if path is None else path.encode()))
+    return out.as_dict()
 
 
 def read_ml_cost(path):

@@ -1010,6 +1010,171 @@ int ba_net_print_report(const ba_network *n, const ba_report *r, const ba_bin_st
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// correlation analysis
+// ---------------------------------------------------------------------------------------------
+namespace {
+// |correlation| of one camera parameter against one coordinate of every station (or point), NaN left out
+// (extractAPCorrelation, src/main.cpp:837-848), then calcStatistics (:851-881) into slots max, median, mean, min
+void correlation_column(const double *cov_row, const double *var, int64_t count, int stride, int coord, double var_cam,
+                        bool have_row, double *t_max, double *t_median, double *t_mean, double *t_min) {
+  std::vector<double> v;
+  if (have_row && cov_row && var) {
+    v.reserve((size_t)count);
+    for (int64_t i = 0; i < count; ++i) {
+      const double c = cov_row[stride * i + coord] / (std::sqrt(var[stride * i + coord]) * std::sqrt(var_cam));
+      if (!std::isnan(c)) v.push_back(std::fabs(c));
+    }
+  }
+  ba_stats st;
+  ba_stat_all(v.data(), (int64_t)v.size(), &st);
+  if (v.empty()) st.max = st.median = st.mean = NAN;  // :5833-5834; min stays 0
+  *t_max = st.max; *t_median = st.median; *t_mean = st.mean; *t_min = st.min;
+}
+
+// one row of an Eigen matrix on a stream: coefficients right-aligned to the widest of the row, one blank between
+void print_row(std::ostringstream &o, const double *v, int n) {
+  std::vector<std::string> t((size_t)n);
+  size_t w = 0;
+  for (int i = 0; i < n; ++i) {
+    std::ostringstream c;
+    c.copyfmt(o);
+    c << v[i];
+    t[i] = c.str();
+    w = std::max(w, t[i].size());
+  }
+  for (int i = 0; i < n; ++i) {
+    if (i) o << " ";
+    o << std::string(w - t[i].size(), ' ') << t[i];
+  }
+}
+
+// "Mean(fabs)" and "Median(fabs)" lines over the entries of a table that are not NaN (:5885-5896)
+void print_table_stats(std::ostringstream &o, const double *v, int n, bool off_diagonal_of_16 = false) {
+  std::vector<double> s;
+  for (int i = 0; i < n; ++i) {
+    if (off_diagonal_of_16 && i / 16 == i % 16) continue;
+    if (!std::isnan(v[i])) s.push_back(std::fabs(v[i]));
+  }
+  ba_stats st;
+  ba_stat_all(s.data(), (int64_t)s.size(), &st);
+  o << "   Mean(fabs): " << st.mean << " +/- " << st.stdev << std::endl;
+  o << "   Median(fabs): " << st.median << " (" << st.min << " to " << st.max << ")" << std::endl;
+}
+}  // namespace
+
+int ba_correlations_compute(int32_t n_sta, int64_t n_pts, int32_t camera, int32_t n_rows, const int32_t *cam_param,
+                            const double *var_eop, const double *var_xyz, const double *var_iop, const double *var_ap,
+                            const double *cov_eop, const double *cov_xyz, const double *cov_cam, ba_correlations *out) {
+  if (!out || n_sta < 0 || n_pts < 0 || camera < 0 || n_rows < 0 || (n_rows > 0 && !cam_param) || !var_iop || !var_ap)
+    return fail(BA_ERR_INVALID, "ba_correlations_compute: bad argument");
+  int row_of[19];
+  for (int q = 0; q < 19; ++q) row_of[q] = -1;
+  for (int k = 0; k < n_rows; ++k)
+    if (cam_param[k] / 19 == camera) row_of[cam_param[k] % 19] = k;
+  auto var_cam = [&](int q) { return q < 3 ? var_iop[3 * (size_t)camera + q] : var_ap[16 * (size_t)camera + q - 3]; };
+  for (int q = 0; q < 19; ++q) {
+    const int k = row_of[q];
+    const double vc = var_cam(q);
+    for (int m = 0; m < 6; ++m) {
+      double *t = q < 3 ? &out->eop_iop[0][m][q] : &out->eop_ap[0][m][q - 3];
+      const size_t step = q < 3 ? 6 * 3 : 6 * 16;
+      correlation_column(k >= 0 && cov_eop ? cov_eop + (size_t)k * 6 * n_sta : nullptr, var_eop, n_sta, 6, m, vc, k >= 0, t, t + step,
+                         t + 2 * step, t + 3 * step);
+    }
+    for (int m = 0; m < 3; ++m) {
+      double *t = q < 3 ? &out->xyz_iop[0][m][q] : &out->xyz_ap[0][m][q - 3];
+      const size_t step = q < 3 ? 3 * 3 : 3 * 16;
+      correlation_column(k >= 0 && cov_xyz ? cov_xyz + (size_t)k * 3 * n_pts : nullptr, var_xyz, n_pts, 3, m, vc, k >= 0, t, t + step,
+                         t + 2 * step, t + 3 * step);
+    }
+  }
+  // camera corner: a constant parameter has zero covariance and zero variance, 0 / 0 = NaN as in the reference
+  auto cov_cc = [&](int qa, int qb) {
+    const int ka = row_of[qa], kb = row_of[qb];
+    return (ka >= 0 && kb >= 0 && cov_cam) ? cov_cam[(size_t)ka * n_rows + kb] : 0.0;
+  };
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 16; ++b) out->iop_ap[a][b] = cov_cc(a, 3 + b) / (std::sqrt(var_cam(a)) * std::sqrt(var_cam(3 + b)));
+  for (int a = 0; a < 16; ++a)
+    for (int b = 0; b < 16; ++b) out->ap_ap[a][b] = cov_cc(3 + a, 3 + b) / (std::sqrt(var_cam(3 + a)) * std::sqrt(var_cam(3 + b)));
+  return 0;
+}
+
+int ba_print_correlations(const ba_correlations *c, const char *path) {
+  if (!c) return fail(BA_ERR_INVALID, "ba_print_correlations: null argument");
+  std::ostringstream o;
+  o << std::setprecision(2) << std::fixed;  // :5618-5619
+  static const char *kind[4] = {"Max", "Median", "Mean", "Min"};
+  static const char *eop_name[6] = {"omega: ", "phi  : ", "kappa: ", "Xo   : ", "Yo   : ", "Zo   : "};
+  static const char *xyz_name[3] = {"X: ", "Y: ", "Z: "};
+  static const char *iop_head = "       xp\typ\tc", *ap_head = "       a1\ta2\tk1\tk2\tk3\tp1\tp2\tk4\tk5...";
+  o << "Correlation Matrix AP-AP..." << std::endl;  // :5621-5636
+  print_table_stats(o, &c->ap_ap[0][0], 256, true);
+  for (int a = 0; a < 16; ++a) {
+    print_row(o, c->ap_ap[a], 16);
+    o << std::endl;
+  }
+  o << "============================= Correlation EOP-IOP =============================" << std::endl;  // :5882-5967
+  for (int t = 0; t < 4; ++t) {
+    o << "Correlation EOP-IOP " << kind[t] << "(fabs)" << std::endl;
+    print_table_stats(o, &c->eop_iop[t][0][0], 18);
+    o << iop_head << std::endl;
+    for (int m = 0; m < 6; ++m) {
+      o << eop_name[m];
+      print_row(o, c->eop_iop[t][m], 3);
+      o << std::endl;
+    }
+  }
+  for (int t = 0; t < 4; ++t) {  // :6052-6139
+    o << "Correlation EOP-AP " << kind[t] << "(fabs)" << std::endl;
+    print_table_stats(o, &c->eop_ap[t][0][0], 96);
+    o << ap_head << std::endl;
+    for (int m = 0; m < 6; ++m) {
+      o << eop_name[m];
+      print_row(o, c->eop_ap[t][m], 16);
+      o << std::endl;
+    }
+  }
+  for (int t = 0; t < 4; ++t) {  // :6263-6338
+    o << "Correlation XYZ-IOP " << kind[t] << "(fabs)" << std::endl;
+    print_table_stats(o, &c->xyz_iop[t][0][0], 9);
+    o << iop_head << std::endl;
+    for (int m = 0; m < 3; ++m) {
+      o << xyz_name[m];
+      print_row(o, c->xyz_iop[t][m], 3);
+      o << std::endl;
+    }
+  }
+  o << "Correlation XYZ-AP Max(fabs)" << std::endl;  // :6391-6408: the maxima only
+  print_table_stats(o, &c->xyz_ap[0][0][0], 48);
+  o << ap_head << std::endl;
+  for (int m = 0; m < 3; ++m) {
+    o << xyz_name[m];
+    print_row(o, c->xyz_ap[0][m], 16);
+    o << std::endl;
+  }
+  o << "Correlation IOP-AP" << std::endl;  // :6469-6492
+  print_table_stats(o, &c->iop_ap[0][0], 48);
+  o << ap_head << std::endl;
+  static const char *iop_name[3] = {"xp: ", "yp: ", "c : "};
+  for (int a = 0; a < 3; ++a) {
+    o << iop_name[a];
+    print_row(o, c->iop_ap[a], 16);
+    o << std::endl;
+  }
+  const std::string text = o.str();
+  if (!path) {
+    fputs(text.c_str(), stdout);
+    return 0;
+  }
+  FILE *f = fopen(path, "w");
+  if (!f) return fail(BA_ERR_INVALID, "cannot write %s", path);
+  fputs(text.c_str(), f);
+  fclose(f);
+  return 0;
+}
+
 int ba_net_qc(const ba_network *n, const char *truth_path, ba_qc *out) {  // src/main.cpp:7242-7346
   if (!n || !truth_path || !out) return fail(BA_ERR_INVALID, "ba_net_qc: null argument");
   std::memset(out, 0, sizeof *out);

@@ -140,7 +140,7 @@ struct ShmComm {
 static void usage() {
   fprintf(stderr,
           "usage: ba_main <file.pho> <file.eop> <file.iop> <file.xyz> [--out DIR] [--free-ap MASK] [--free-iop MASK]\n"
-          "               [--solver auto|dense|sparse|pcg|implicit] [--pcg-rtol X] [--max-iter N] [--covariance] [--model M]\n"
+          "               [--solver auto|dense|sparse|pcg|implicit] [--pcg-rtol X] [--max-iter N] [--covariance] [--correlations] [--model M]\n"
           "               [--bins B] [--truth file.xyz] [--iop-bounds]\n"
           "       ba_main --synth C S P RAYS [same options]\n"
           "       ba_main ... --ranks N --rank R --id-file PATH [--run-id ID] [--comm rccl|shm] [--comm-timeout SECONDS]\n"
@@ -170,14 +170,16 @@ static void usage() {
           "        PCG iteration); auto: when the network is large enough for that to pay.\n"
           "  --covariance: standard deviations of all parameters in the result files (the reference's COMPUTECX\n"
           "        branch, src/main.cpp:5261): from the dense inverse of the reduced system while it fits the device, from a\n"
-          "        dissection of the station graph beyond (networks of 50 000 stations take seconds).\n");
+          "        dissection of the station graph beyond (networks of 50 000 stations take seconds).\n"
+          "  --correlations: --covariance and the correlation tables of the reference's COMPUTECORRELATION branch\n"
+          "        (src/main.cpp:5592-6495): camera parameters against station parameters, point coordinates and each other.\n");
 }
 
 int main(int argc, char **argv) {
   std::vector<std::string> pos;
   std::string out = ".";
   unsigned ap_mask = 0x4, iop_mask = 7;
-  bool synth = false, covariance = false, iop_bounds = false;
+  bool synth = false, covariance = false, correlations = false, iop_bounds = false;
   int model = 0, bins = 30;
   std::string truth, id_file, comm = "rccl", pcg_rows = "auto";
   uint64_t run_id = 0;
@@ -202,6 +204,7 @@ int main(int argc, char **argv) {
     else if (a == "--max-iter") opt.max_num_iterations = atoi(next());
     else if (a == "--synth") synth = true;
     else if (a == "--covariance") covariance = true;
+    else if (a == "--correlations") covariance = correlations = true;
     else if (a == "--iop-bounds") iop_bounds = true;
     else if (a == "--model") model = atoi(next());
     else if (a == "--bins") bins = atoi(next());
@@ -360,6 +363,22 @@ int main(int argc, char **argv) {
       return 1;
     } else {
       ba_net_set_variances(net, ve.data(), vx.data(), vi.data(), va.data());
+      if (correlations) {
+        // the reference's COMPUTECORRELATION block (src/main.cpp:5592-6495): the camera rows of Cx, then the tables
+        int32_t n_rows = 0;
+        if (ba_covariance_camera_rows(p, &n_rows, nullptr, nullptr, nullptr, nullptr)) { fprintf(stderr, "error: %s\n", ba_last_error()); return 1; }
+        std::vector<int32_t> par((size_t)n_rows + 1);
+        std::vector<double> ce((size_t)n_rows * 6 * d.n_sta + 1), cx((size_t)n_rows * 3 * d.n_pts + 1), cc((size_t)n_rows * n_rows + 1);
+        if (ba_covariance_camera_rows(p, nullptr, par.data(), ce.data(), cx.data(), cc.data())) { fprintf(stderr, "error: %s\n", ba_last_error()); return 1; }
+        ba_correlations corr;
+        // one slot per station in the reference's matrices, overwritten camera by camera: the last camera's figures
+        if (ba_correlations_compute(d.n_sta, d.n_pts, d.n_cam - 1, n_rows, par.data(), ve.data(), vx.data(), vi.data(), va.data(), ce.data(),
+                                    cx.data(), cc.data(), &corr) ||
+            ba_print_correlations(&corr, nullptr)) {
+          fprintf(stderr, "error: %s\n", ba_host_last_error());
+          return 1;
+        }
+      }
     }
   }
   std::vector<double> res(2 * (size_t)d.n_obs + 3 * (size_t)d.n_pts + 3 * (size_t)d.n_cam);

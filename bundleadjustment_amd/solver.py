@@ -23,7 +23,7 @@ EXPORTS = ("ba_default_options", "ba_create", "ba_destroy", "ba_set_parameters",
            "ba_solve_resident", "ba_solve", "ba_evaluate", "ba_covariance", "ba_sparsity", "ba_residual_jacobian", "ba_time_kernel",
            "ba_set_allreduce", "ba_copy_to_host", "ba_copy_to_device", "ba_rccl_unique_id", "ba_use_rccl", "ba_evaluate_noalloc",
            "ba_device_count", "ba_set_device", "ba_reduction_timing", "ba_reduction_stats",
-           "ba_shard_reduced_solve", "ba_reduced_solve_rows", "ba_set_covariance_route", "ba_covariance_stats", "ba_sparse_solver_stats", "ba_tuning",
+           "ba_shard_reduced_solve", "ba_reduced_solve_rows", "ba_set_covariance_route", "ba_covariance_stats", "ba_sparse_solver_stats", "ba_tuning", "ba_covariance_camera_rows",
            "ba_last_error")
 
 
@@ -55,6 +55,7 @@ def lib():
         L.ba_get_parameters.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]
         L.ba_set_corrections.argtypes = [C.c_void_p, c_double_p, c_double_p]
         L.ba_covariance_cameras.argtypes = [C.c_void_p, c_double_p, c_double_p]
+        L.ba_covariance_camera_rows.argtypes = [C.c_void_p, c_int32_p, c_int32_p, c_double_p, c_double_p, c_double_p]
         L.ba_set_iop_bounds.argtypes = [C.c_void_p, c_double_p, c_double_p]
         L.ba_set_covariance_route.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.ba_covariance_stats.argtypes = [C.c_void_p] + [c_int32_p] * 4
@@ -190,6 +191,19 @@ class Problem:
         vi, va = np.zeros((n.n_cam, 3)), np.zeros((n.n_cam, 16))
         _check(lib().ba_covariance_cameras(self._h, _dp(vi), _dp(va)))
         return vi, va
+
+    def covariance_camera_rows(self, points=True):
+        """Covariances of the free camera parameters with all parameters: (cam_param [n], cov_eop [n,S,6],
+        cov_xyz [n,P,3] or None, cov_cam [n,n]); cam_param = 19 * camera + parameter (0..2 xp yp c, 3..18 AP)."""
+        net = self.net
+        n = C.c_int32()
+        _check(lib().ba_covariance_camera_rows(self._h, C.byref(n), None, None, None, None))
+        n = n.value
+        par = np.zeros(max(n, 1), dtype=np.int32)
+        ce, cc = np.zeros((n, net.n_sta, 6)), np.zeros((n, n))
+        cx = np.zeros((n, net.n_pts, 3)) if points else None
+        _check(lib().ba_covariance_camera_rows(self._h, None, par.ctypes.data_as(c_int32_p), _dp(ce), _dp(cx) if points else None, _dp(cc)))
+        return par[:n], ce, cx, cc
 
     def covariance_route(self, route=0, max_cluster_stations=0):
         """0: dense inverse while it fits, dissection of the station graph beyond; 1: dense only; 2: dissection."""

@@ -291,7 +291,8 @@ int ba_covariance(ba_problem *p, double *var_eop, double *var_xyz, double *var_i
  * its lists), "pcg_graph" (0: PCG iterations queued launch by launch instead of replayed as graphs), "amg_levels"
  * (1..3), "amg_theta" (aggregation threshold, default 0.5), "fused_sums" (0: station sums by separate sweeps),
  * "schur_windows" (0: off-diagonal blocks pair list by pair list), "keyed_tiles" (tiles per segment of the station-sum
- * plan).  Every setting gives the same results to rounding.  BA_ERR_INVALID for an unknown name.  No counterpart in
+ * plan), "rows_solver" (0 dense / 1 sparse direct / 2 PCG / -1 by size: the reduced solver of
+ * ba_covariance_camera_rows).  Every setting gives the same results to rounding.  BA_ERR_INVALID for an unknown name.  No counterpart in
  * the reference.
  */
 int ba_tuning(const char *name, double value);
@@ -327,6 +328,23 @@ int ba_covariance_stats(const ba_problem *p, int32_t *route_used, int32_t *clust
  * reduced system per free camera parameter (right-hand side e_k, PCG to 1e-12) instead of the dense inverse.
  */
 int ba_covariance_cameras(ba_problem *p, double *var_iop, double *var_ap);
+
+/*
+ * The rows of Cx that belong to the free camera parameters: their covariances with every station parameter, every
+ * point coordinate and each other.  These are the blocks the reference's correlation analysis asks ceres::Covariance
+ * for and reads with GetCovarianceBlock: EOP x IOP and EOP x AP (src/main.cpp:5720-5778), XYZ x IOP and XYZ x AP
+ * (:6154-6189), IOP x AP (:6423-6436), AP x AP (:5592-5598); ba_correlations of ba_host.h turns them, with the
+ * variances of ba_covariance, into the reference's correlation tables.  Row k belongs to the k-th free camera
+ * parameter in the order of the program (camera by camera: xp, yp, c, AP[0..15], free ones only);
+ * cam_param[k] = 19 * camera + parameter (0..2 xp yp c, 3..18 AP[0..15]); *n_rows = their number (at most 19 per
+ * camera, for sizing call with every array NULL).  cov_eop [n_rows][6*n_sta], cov_xyz [n_rows][3*n_pts] (file order),
+ * cov_cam [n_rows][n_rows]; any may be NULL.  One factorisation of the reduced system (dense up to
+ * BA_AUTO_DENSE_ORDER unknowns, the sparse direct solver up to BA_AUTO_SPARSE_ORDER) and one pair of triangular
+ * solves per row, beyond that one PCG solve per row; the point part is the back substitution of that solution.
+ * One rank only.
+ */
+int ba_covariance_camera_rows(ba_problem *p, int32_t *n_rows, int32_t *cam_param, double *cov_eop, double *cov_xyz,
+                              double *cov_cam);
 
 /*
  * Structure of the Jacobian that problem.Evaluate(..., &jacobian) returns at

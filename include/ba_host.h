@@ -145,6 +145,32 @@ int ba_net_report(const ba_network *net, const ba_summary *summary, const double
 /* The same as text, line for line as the reference's std::cout (path NULL: stdout). */
 int ba_net_print_report(const ba_network *net, const ba_report *report, const ba_bin_stats *bin_stats, const char *path);
 
+/* ---- correlation analysis (the COMPUTECORRELATION blocks, src/main.cpp:5592-5640, 5727-5778, 5801-6142, 6162-6188,
+ * 6211-6411, 6430-6495; helpers extractAPCorrelation :837 and calcStatistics :851) ---- */
+typedef struct {
+  /* first index: 0 max, 1 median, 2 mean, 3 min of |correlation| over the stations (or points); NaN (min: 0, as
+   * calcStatistics leaves it) where a parameter is held constant */
+  double eop_iop[4][6][3];   /* [omega phi kappa Xo Yo Zo][xp yp c], :5808-5879 */
+  double eop_ap[4][6][16];   /* :5979-6050 */
+  double xyz_iop[4][3][3];   /* [X Y Z][xp yp c], :6218-6260 */
+  double xyz_ap[4][3][16];   /* :6350-6389 */
+  double iop_ap[3][16];      /* correlationIOP_AP, :6434-6436 */
+  double ap_ap[16][16];      /* correlationAP_AP, :5598 */
+} ba_correlations;
+
+/* The correlation tables of one camera from the variances of ba_covariance (var_eop [6*n_sta], var_xyz [3*n_pts],
+ * var_iop [3*n_cam], var_ap [16*n_cam]) and the camera rows of ba_covariance_camera_rows (n_rows, cam_param, cov_eop,
+ * cov_xyz, cov_cam; cov_xyz may be NULL: the XYZ tables are NaN then).  correlation = covariance / (sqrt(variance) *
+ * sqrt(variance)) as at :5731, :5762, :6166, :6184, :6434, :5598; NaN entries (constant parameters, stations outside
+ * the program) are left out of the statistics as extractAPCorrelation does.  The reference's matrices have one slot
+ * per station and are overwritten camera by camera, so its figures are those of the last camera: camera = n_cam - 1
+ * gives the same. */
+int ba_correlations_compute(int32_t n_sta, int64_t n_pts, int32_t camera, int32_t n_rows, const int32_t *cam_param,
+                            const double *var_eop, const double *var_xyz, const double *var_iop, const double *var_ap,
+                            const double *cov_eop, const double *cov_xyz, const double *cov_cam, ba_correlations *out);
+/* The same as text in the layout of the reference's std::cout (two decimals, fixed; path NULL: stdout). */
+int ba_print_correlations(const ba_correlations *c, const char *path);
+
 typedef struct {
   int32_t n_truth, n_estimated, n_matches;
   double mean[3], min[3], max[3], rmse[3], rmse_average;

@@ -1158,45 +1158,57 @@ double bao_linearize_once(const ba_dims *d, const ba_inputs *in, const double *e
  * matrix has full rank and the pseudo-inverse is the inverse, which is what is computed here (by
  * Cholesky of the symmetrically scaled normal matrix).  A rank-deficient network is reported as an
  * error instead of being truncated. */
-int bao_covariance(const ba_dims *d, const ba_inputs *in, const double *eop, const double *xyz, const double *iop,
-                   const double *ap, double *var_eop, double *var_xyz, double *var_iop, double *var_ap) {
-  prob_t q;
-  int rc = prob_init(&q, d, in, 1);
-  if (rc) { prob_free(&q); return rc; }
-  linearize(&q, eop, xyz, iop, ap);
-  const int nt = q.nt, ncm = q.ncmax ? q.ncmax : 1;
-  if ((double)nt * nt * 8.0 > 6e9) { prob_free(&q); FAIL(BA_ERR_INVALID, "covariance: %d unknowns is too many for the dense oracle", nt); }
+/* The full normal matrix at the given point, scaled to a unit diagonal (sc: the scale factors) and replaced by its
+ * Cholesky factor (lower triangle, row-major); q is left initialised for the caller (prob_free). */
+static int cov_factor(prob_t *q, const ba_dims *d, const ba_inputs *in, const double *eop, const double *xyz, const double *iop,
+                      const double *ap, double **H_out, double **sc_out) {
+  int rc = prob_init(q, d, in, 1);
+  if (rc) { prob_free(q); return rc; }
+  linearize(q, eop, xyz, iop, ap);
+  const int nt = q->nt, ncm = q->ncmax ? q->ncmax : 1;
+  if ((double)nt * nt * 8.0 > 6e9) { prob_free(q); FAIL(BA_ERR_INVALID, "covariance: %d unknowns is too many for the dense oracle", nt); }
   double *H = calloc((size_t)nt * nt + 1, sizeof(double)), *sc = calloc(nt + 1, sizeof(double));
   int idx[9 + NCAMPAR];
   double v0[9 + NCAMPAR], v1[9 + NCAMPAR];
-  for (int n = 0; n < q.N; ++n) {
+  for (int n = 0; n < q->N; ++n) {
     const int i = in->obs_sta[n], j = in->obs_pt[n], c = in->sta_cam[i];
-    const double *Js = q.Js + 12 * (size_t)n, *Jp = q.Jp + 6 * (size_t)n, *Jc = q.Jc + 2 * (size_t)ncm * n;
+    const double *Js = q->Js + 12 * (size_t)n, *Jp = q->Jp + 6 * (size_t)n, *Jc = q->Jc + 2 * (size_t)ncm * n;
     int m = 0;
-    for (int k = 0; k < 6; ++k, ++m) { idx[m] = COL_STA(&q, i) + k; v0[m] = Js[k]; v1[m] = Js[6 + k]; }
-    for (int k = 0; k < 3; ++k, ++m) { idx[m] = COL_PT(&q, j) + k; v0[m] = Jp[k]; v1[m] = Jp[3 + k]; }
-    for (int k = 0; k < q.cam_nc[c]; ++k, ++m) { idx[m] = COL_CAM(&q, c) + k; v0[m] = Jc[k]; v1[m] = Jc[ncm + k]; }
+    for (int k = 0; k < 6; ++k, ++m) { idx[m] = COL_STA(q, i) + k; v0[m] = Js[k]; v1[m] = Js[6 + k]; }
+    for (int k = 0; k < 3; ++k, ++m) { idx[m] = COL_PT(q, j) + k; v0[m] = Jp[k]; v1[m] = Jp[3 + k]; }
+    for (int k = 0; k < q->cam_nc[c]; ++k, ++m) { idx[m] = COL_CAM(q, c) + k; v0[m] = Jc[k]; v1[m] = Jc[ncm + k]; }
     for (int a = 0; a < m; ++a)
       for (int b = 0; b < m; ++b) H[(size_t)idx[a] * nt + idx[b]] += v0[a] * v0[b] + v1[a] * v1[b];
   }
-  for (int j = 0; j < 3 * q.P; ++j) H[(size_t)(6 * q.S + j) * nt + 6 * q.S + j] += q.jp[j] * q.jp[j];
-  for (int k = 0; k < q.ncam; ++k) {
-    const size_t cidx = 6 * (size_t)q.S + 3 * (size_t)q.P + k;
-    H[cidx * nt + cidx] += q.jc[k] * q.jc[k];
+  for (int j = 0; j < 3 * q->P; ++j) H[(size_t)(6 * q->S + j) * nt + 6 * q->S + j] += q->jp[j] * q->jp[j];
+  for (int k = 0; k < q->ncam; ++k) {
+    const size_t cidx = 6 * (size_t)q->S + 3 * (size_t)q->P + k;
+    H[cidx * nt + cidx] += q->jc[k] * q->jc[k];
   }
   /* stations without observations are not in the program: keep them out of the inverse */
-  for (int i = 0; i < q.S; ++i)
-    if (!q.sta_used[i])
+  for (int i = 0; i < q->S; ++i)
+    if (!q->sta_used[i])
       for (int k = 0; k < 6; ++k) H[(size_t)(6 * i + k) * nt + 6 * i + k] = 1.0;
   for (int i = 0; i < nt; ++i) {
     const double dgl = H[(size_t)i * nt + i];
-    if (!(dgl > 0.0)) { free(H); free(sc); prob_free(&q); FAIL(BA_ERR_NUMERIC, "covariance: unknown %d has no information", i); }
+    if (!(dgl > 0.0)) { free(H); free(sc); prob_free(q); FAIL(BA_ERR_NUMERIC, "covariance: unknown %d has no information", i); }
     sc[i] = 1.0 / sqrt(dgl);
   }
   for (int i = 0; i < nt; ++i)
     for (int j = 0; j < nt; ++j) H[(size_t)i * nt + j] *= sc[i] * sc[j];
   const int bad = chol_factor(H, nt);
-  if (bad) { free(H); free(sc); prob_free(&q); FAIL(BA_ERR_NUMERIC, "covariance: normal matrix is rank deficient (column %d of %d)", bad - 1, nt); }
+  if (bad) { free(H); free(sc); prob_free(q); FAIL(BA_ERR_NUMERIC, "covariance: normal matrix is rank deficient (column %d of %d)", bad - 1, nt); }
+  *H_out = H; *sc_out = sc;
+  return 0;
+}
+
+int bao_covariance(const ba_dims *d, const ba_inputs *in, const double *eop, const double *xyz, const double *iop,
+                   const double *ap, double *var_eop, double *var_xyz, double *var_iop, double *var_ap) {
+  prob_t q;
+  double *H = NULL, *sc = NULL;
+  const int rc = cov_factor(&q, d, in, eop, xyz, iop, ap, &H, &sc);
+  if (rc) return rc;
+  const int nt = q.nt;
   /* diag((L L^T)^-1) = squared column norms of L^-1; L^-1 column c by forward substitution */
   double *var = calloc(nt + 1, sizeof(double)), *x = calloc(nt + 1, sizeof(double));
   for (int c = 0; c < nt; ++c) {
@@ -1223,6 +1235,51 @@ int bao_covariance(const ba_dims *d, const ba_inputs *in, const double *eop, con
     }
   }
   free(H); free(sc); free(var); free(x);
+  prob_free(&q);
+  return 0;
+}
+
+/* Rows of the same covariance matrix: the covariances of every free camera parameter with all parameters, which the
+ * reference's correlation analysis reads block by block (src/main.cpp:5720-5778 EOP x IOP and EOP x AP, :6154-6189
+ * XYZ x IOP and XYZ x AP, :6423-6436 IOP x AP, :5592-5598 AP x AP).  Row k belongs to the k-th camera column of the
+ * program; cam_param[k] = 19 * camera + parameter (0..2 xp yp c, 3..18 AP[0..15]).  cov_eop [ncam][6S],
+ * cov_xyz [ncam][3P], cov_cam [ncam][ncam]; any of the three may be NULL (room for 19 rows per camera is always
+ * enough); *n_rows = ncam. */
+int bao_covariance_rows(const ba_dims *d, const ba_inputs *in, const double *eop, const double *xyz, const double *iop,
+                        const double *ap, int32_t *n_rows, int32_t *cam_param, double *cov_eop, double *cov_xyz, double *cov_cam) {
+  prob_t q;
+  double *H = NULL, *sc = NULL;
+  const int rc = cov_factor(&q, d, in, eop, xyz, iop, ap, &H, &sc);
+  if (rc) return rc;
+  const int nt = q.nt;
+  if (n_rows) *n_rows = q.ncam;
+  double *x = calloc(nt + 1, sizeof(double));
+  for (int c = 0; c < q.C; ++c)
+    for (int k = 0; k < q.cam_nc[c]; ++k) {
+      const int col = COL_CAM(&q, c) + k, row = col - COL_CAM(&q, 0);
+      if (cam_param) cam_param[row] = NCAMPAR * c + q.cam_par[c * NCAMPAR + k];
+      /* L y = e_col, L^T z = y */
+      for (int i = 0; i < nt; ++i) {
+        double sum = (i == col) ? 1.0 : 0.0;
+        const double *Li = H + (size_t)i * nt;
+        if (i >= col) for (int m = col; m < i; ++m) sum -= Li[m] * x[m];
+        x[i] = i < col ? 0.0 : sum / Li[i];
+      }
+      for (int i = nt - 1; i >= 0; --i) {
+        double sum = x[i];
+        for (int m = i + 1; m < nt; ++m) sum -= H[(size_t)m * nt + i] * x[m];
+        x[i] = sum / H[(size_t)i * nt + i];
+      }
+      for (int i = 0; i < nt; ++i) x[i] *= sc[i] * sc[col];
+      if (cov_eop)
+        for (int i = 0; i < q.S; ++i)
+          for (int m = 0; m < 6; ++m) cov_eop[(size_t)row * 6 * q.S + 6 * i + m] = q.sta_used[i] ? x[COL_STA(&q, i) + m] : 0.0;
+      if (cov_xyz)
+        for (int j = 0; j < 3 * q.P; ++j) cov_xyz[(size_t)row * 3 * q.P + j] = x[6 * q.S + j];
+      if (cov_cam)
+        for (int m = 0; m < q.ncam; ++m) cov_cam[(size_t)row * q.ncam + m] = x[COL_CAM(&q, 0) + m];
+    }
+  free(H); free(sc); free(x);
   prob_free(&q);
   return 0;
 }

@@ -93,6 +93,14 @@ int bao_covariance(const ba_dims *d, const ba_inputs *in, const double *eop, con
                    const double *iop, const double *ap, double *var_eop, double *var_xyz, double *var_iop,
                    double *var_ap);
 
+/* The covariances of every free camera parameter with all parameters (the rows of Cx that the reference's correlation
+ * analysis reads, src/main.cpp:5720-5778, 6154-6189, 6423-6436, 5592-5598).  Row k = k-th camera column;
+ * cam_param[k] = 19 * camera + parameter (0..2 xp yp c, 3..18 AP[0..15]); cov_eop [ncam][6S], cov_xyz [ncam][3P],
+ * cov_cam [ncam][ncam], each may be NULL; *n_rows = ncam (at most 19 per camera).  Dense: small networks only. */
+int bao_covariance_rows(const ba_dims *d, const ba_inputs *in, const double *eop, const double *xyz,
+                        const double *iop, const double *ap, int32_t *n_rows, int32_t *cam_param, double *cov_eop,
+                        double *cov_xyz, double *cov_cam);
+
 const char *bao_last_error(void);
 
 #ifdef __cplusplus

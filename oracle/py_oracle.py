@@ -170,6 +170,23 @@ def covariance(net, eop=None, xyz=None, iop=None, ap=None):
     return ve, vx, vi, va
 
 
+def covariance_rows(net, eop=None, xyz=None, iop=None, ap=None):
+    """Covariances of the free camera parameters with all parameters: (cam_param [n], cov_eop [n,S,6], cov_xyz [n,P,3],
+    cov_cam [n,n]); cam_param = 19 * camera + parameter (0..2 xp yp c, 3..18 AP)."""
+    eop = net.eop if eop is None else eop
+    xyz = net.xyz if xyz is None else xyz
+    iop = net.iop if iop is None else iop
+    ap = net.ap if ap is None else ap
+    d, inp = net.dims(), net.inputs()
+    cap = 19 * net.n_cam
+    par, n = np.zeros(cap, dtype=np.int32), C.c_int32(0)
+    ce, cx, cc = np.zeros((cap, net.n_sta, 6)), np.zeros((cap, net.n_pts, 3)), np.zeros(cap * cap)
+    _check(lib().bao_covariance_rows(C.byref(d), C.byref(inp), _dp(eop), _dp(xyz), _dp(iop), _dp(ap), C.byref(n),
+                                     par.ctypes.data_as(C.POINTER(C.c_int32)), _dp(ce), _dp(cx), _dp(cc)))
+    n = n.value
+    return par[:n].copy(), ce[:n].copy(), cx[:n].copy(), cc[:n * n].reshape(n, n).copy()
+
+
 def linearize_once(net, omp=False):
     d, inp = net.dims(), net.inputs()
     return (lib_omp() if omp else lib()).bao_linearize_once(C.byref(d), C.byref(inp), _dp(net.eop), _dp(net.xyz), _dp(net.iop), _dp(net.ap))

@@ -33,7 +33,7 @@ def test_cli_matches_the_bindings(files):
     tmp, paths = files
     out = tmp / "cli"
     out.mkdir()
-    r = run_cli(paths + ["--free-ap", hex(host.AP_K1K2P1P2), "--covariance", "--out", str(out)], str(tmp))
+    r = run_cli(paths + ["--free-ap", hex(host.AP_K1K2P1P2), "--correlations", "--out", str(out)], str(tmp))
     assert r.returncode == 0, r.stderr
     assert "Termination CONVERGENCE" in r.stdout
 
@@ -45,7 +45,12 @@ def test_cli_matches_the_bindings(files):
     with solver.Problem(hn.net) as P:
         eop, xyz, iop, ap, sm, rows = P.solve(solver.default_options())
         var = P.covariance()
+        cam_rows = P.covariance_camera_rows()
         _, res = P.evaluate(eop, xyz, iop, ap)
+    # the correlation tables of the last camera (what the reference's matrices hold), as printed by the tool
+    host.correlations(var, cam_rows, camera=hn.net.n_cam - 1, path=str(tmp / "corr.txt"), text=True)
+    block = (tmp / "corr.txt").read_text()
+    assert block.startswith("Correlation Matrix AP-AP...") and block in r.stdout
     hn.set_parameters(eop, xyz, iop, ap)
     hn.set_variances(*var)
     hn.write_angles(str(ref))

@@ -7,8 +7,9 @@ from bundleadjustment_amd import host
 from oracle import py_oracle as po
 
 
-def numpy_variances(net):
-    """diag((J^T J)^-1) with J assembled densely: image rows (loss-corrected), XYZ priors, IOP priors."""
+def numpy_covariance(net):
+    """(J^T J)^-1 with J assembled densely: image rows (loss-corrected), XYZ priors, IOP priors; and the column of each
+    free camera parameter (camera, parameter)."""
     N, S, P, Cn = net.n_obs, net.n_sta, net.n_pts, net.n_cam
     r, J = po.residual_jacobian_all(net)
     cols = []  # ambient column -> (kind, index); only the free ones
@@ -44,6 +45,13 @@ def numpy_variances(net):
             A[2 * N + 3 * P + 3 * c + k, cam_col[(c, k)]] = 1.0 / net.iop_sigma[c, k]
     d = np.sqrt((A * A).sum(axis=0))
     Cx = np.linalg.inv((A / d).T @ (A / d)) / np.outer(d, d)
+    return Cx, cam_col
+
+
+def numpy_variances(net):
+    """diag((J^T J)^-1), in the layout of the oracle."""
+    S, P, Cn = net.n_sta, net.n_pts, net.n_cam
+    Cx, cam_col = numpy_covariance(net)
     v = np.diag(Cx)
     ve, vx = v[:6 * S].reshape(S, 6), v[6 * S:6 * S + 3 * P].reshape(P, 3)
     vi, va = np.zeros((Cn, 3)), np.zeros((Cn, 16))
@@ -64,3 +72,27 @@ def test_oracle_covariance_matches_numpy():
         assert np.allclose(g, w, rtol=1e-7, atol=0.0)
     # fixed AP coordinates have zero variance, free ones do not
     assert np.all(got[3][:, [0, 1, 4]] == 0.0) and np.all(got[3][:, [2, 3, 5, 6]] > 0.0)
+
+
+def test_oracle_covariance_rows_match_numpy():
+    # the rows of Cx that the reference's correlation analysis reads (src/main.cpp:5720-5778, 6154-6189, 6423-6436)
+    net = host.synth(n_cam=2, n_sta=8, n_pts=60, rays_per_point=5, ap_free_mask=host.AP_K1K2P1P2, control_every=4,
+                     outlier_fraction=0.1, seed=3).net
+    S, P = net.n_sta, net.n_pts
+    par, ce, cx, cc = po.covariance_rows(net)
+    Cx, cam_col = numpy_covariance(net)
+    assert len(par) == len(cam_col) == 14
+    cols = [cam_col[(int(q) // 19, int(q) % 19)] for q in par]
+    assert cols == sorted(cols)  # rows follow the camera columns of the program
+    sd = np.sqrt(np.diag(Cx))
+    for k, col in enumerate(cols):
+        # compared as correlations: entries of one row span many orders of magnitude
+        assert np.allclose(ce[k].reshape(-1) / (sd[:6 * S] * sd[col]), Cx[col, :6 * S] / (sd[:6 * S] * sd[col]), rtol=0, atol=1e-8)
+        assert np.allclose(cx[k].reshape(-1) / (sd[6 * S:6 * S + 3 * P] * sd[col]),
+                           Cx[col, 6 * S:6 * S + 3 * P] / (sd[6 * S:6 * S + 3 * P] * sd[col]), rtol=0, atol=1e-8)
+        assert np.allclose(cc[k] / (sd[cols] * sd[col]), Cx[col, cols] / (sd[cols] * sd[col]), rtol=0, atol=1e-8)
+    # the diagonal of the camera corner is what covariance() reports
+    _, _, vi, va = po.covariance(net)
+    for k, q in enumerate(par):
+        c, q = int(q) // 19, int(q) % 19
+        assert np.isclose(cc[k, k], vi[c, q] if q < 3 else va[c, q - 3], rtol=1e-10)
