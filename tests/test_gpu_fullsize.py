@@ -215,6 +215,10 @@ def test_cfg4_full_size_variances(big):
         P.solve_resident(opt)
         ve, vx, vi, va = P.covariance()
         wi, wa = P.covariance_cameras()
+        import time
+        t0 = time.time()
+        par, ce, cx, cc = P.covariance_camera_rows()
+        print(f"camera rows of the 10M network: {time.time() - t0:.2f} s")
     assert ve.shape == (net.n_sta, 6) and vx.shape == (net.n_pts, 3)
     assert np.all(np.isfinite(ve)) and np.all(ve > 0.0)
     assert np.all(np.isfinite(vx)) and np.all(vx > 0.0)
@@ -223,6 +227,17 @@ def test_cfg4_full_size_variances(big):
     assert np.all(vi > 0.0) and np.all(va[0, free] > 0.0) and np.all(np.delete(va[0], free) == 0.0)
     np.testing.assert_allclose(wi, vi, rtol=1e-6)
     np.testing.assert_allclose(wa, va, rtol=1e-6)
+    # The camera rows of Cx (one sparse direct factorisation, a pair of tree solves and one back substitution per row):
+    # their corner carries the same variances, and every entry is a covariance -- |correlation| <= 1 against the
+    # variances of the other route, for all 60 000 station parameters and 6 million point coordinates.
+    assert list(par) == [0, 1, 2] + [3 + k for k in free]
+    v_cam = np.concatenate([vi[0], va[0, free]])
+    np.testing.assert_allclose(np.diag(cc), v_cam, rtol=1e-8)
+    for k in range(len(par)):
+        assert np.max(np.abs(ce[k]) / np.sqrt(ve * v_cam[k])) <= 1.0 + 1e-9
+        assert np.max(np.abs(cx[k]) / np.sqrt(vx * v_cam[k])) <= 1.0 + 1e-9
+    tab = host.correlations((ve, vx, vi, va), (par, ce, cx, cc))
+    assert np.all(np.isfinite(tab["eop_iop"])) and np.all(tab["eop_iop"][0] >= tab["eop_iop"][1]) and np.all(tab["xyz_iop"][0] <= 1.0)
 
 
 @pytest.mark.timeout(900)
