@@ -203,44 +203,18 @@ k_gemm_nt(GemmArgs g) {
 // diagonal block: Cholesky and inverse in LDS
 // ------------------------------------------------------------------------------------------------------------------
 // One workgroup of four waves, the 128 x 128 block row-major in LDS (rows beyond the matrix are identity rows).
-//   Factorisation, left-looking over block columns of 16: the tiles of a block column take the sum over the finished
-//   columns on the matrix cores (operands straight from the row-major block: with a row stride of 130 doubles the 32
-//   lanes of a half wave hit 32 different banks); its 16 x 16 diagonal tile is factored by one wave, a lane per row,
-//   pivots and column entries handed round by DPP row broadcasts (no LDS round trip inside the chain of 16 pivots),
-//   while the other three waves already sum for the next block column; the rows below are solved against the tile by
-//   substitution, a lane per row.
-//   Inverse: the eight tiles are inverted side by side (a row of 16 lanes each), then merged pairwise, 16 -> 32 -> 64 -> 128,
+//   Factorisation over block columns of 16 with one wave on the critical path.  Wave 0 holds the 16 x 16 diagonal tile
+//   in the accumulator layout of the matrix instruction (four entries per lane) and eliminates its 16 pivots by rank-one
+//   products on the matrix cores: per pivot one lane read (the pivot), the reciprocal square root, and two products --
+//   one takes the column out of the tile, the other applies the same elimination to a unit matrix, which leaves the
+//   inverse W_JJ of the tile's factor when the last pivot is done.  With W_JJ the rows below need no substitution:
+//   X = P W_JJ^T is four matrix instructions per tile.  Wave 0 does that for the next block row only, subtracts X X^T
+//   from the next diagonal tile and goes on with its pivots; waves 1..3 own the block rows (row I in wave 1 + I % 3),
+//   multiply their tiles of the finished block column by W and bring their tiles of the next block column up to date
+//   (the sums over all finished columns, on the matrix cores) while wave 0 eliminates.  Two barriers per block column.
+//   Inverse: the tile inverses are there already; merged pairwise, 16 -> 32 -> 64 -> 128,
 //   [L11 0; L21 L22]^-1 = [W11 0; -W22 (L21 W11), W22], two products per level over 16 x 16 tiles, in place.
 #define TS (CB + 2)  // even (16-byte aligned rows) and = 2 mod 32 (conflict-free operand reads)
-
-// lane J of every row of 16 lanes, in all lanes of that row (DPP row_newbcast: one VALU move per 32 bits, the result
-// stays in vector registers)
-template <int J>
-__device__ __forceinline__ double bcast16(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + J, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + J, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double bcast16(double v, int j) {  // j is a constant after unrolling: the switch folds away
-  switch (j) {
-    case 0: return bcast16<0>(v);
-    case 1: return bcast16<1>(v);
-    case 2: return bcast16<2>(v);
-    case 3: return bcast16<3>(v);
-    case 4: return bcast16<4>(v);
-    case 5: return bcast16<5>(v);
-    case 6: return bcast16<6>(v);
-    case 7: return bcast16<7>(v);
-    case 8: return bcast16<8>(v);
-    case 9: return bcast16<9>(v);
-    case 10: return bcast16<10>(v);
-    case 11: return bcast16<11>(v);
-    case 12: return bcast16<12>(v);
-    case 13: return bcast16<13>(v);
-    case 14: return bcast16<14>(v);
-    default: return bcast16<15>(v);
-  }
-}
 
 // acc += X[rows of xa][k] Y[rows of xb][k] over k in [kb, ke), both operands row-major in LDS (pointers at row lr, column
 // lk); ke - kb is a multiple of 16: the twelve operand reads of sixteen columns are issued before their products
@@ -270,177 +244,186 @@ __device__ __forceinline__ void mfma_nn16(const double *xa, const double *pb, in
   }
 }
 
+// the value lane `src` holds, in every lane (src is a constant: two lane reads into scalar registers)
+__device__ __forceinline__ double lane_value(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// workgroup barrier for data that lives in LDS: stores to memory that are still on their way do not hold it up
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// what one wave writes to LDS, other lanes of the same wave read next
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ void chol_diag_block(double *__restrict__ A, int n, int ld, int k0, double *__restrict__ Wk, int *__restrict__ info,
-                                                double *Tm) {  // Tm: CB x TS + CB doubles of LDS
-  double *Il = Tm + CB * TS;      // CB: reciprocals of the diagonal of the factor
+                                                double *Tm) {  // Tm: CB x TS doubles of LDS
   const int kw = min(CB, n - k0);
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, lr = lane & 15, lk = lane >> 4;
   const int NT = CB / 16;
   {
-    // half a row per thread, eight 16-byte loads in flight at a time
+    // half a row per thread; the loads of the lower triangle all in flight before the first goes to LDS
     const int r = t >> 1, cb = 64 * (t & 1);
     const double *src = A + (int64_t)(k0 + r) * ld + k0 + cb;
+    double2 v[32];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      double2 v[8];
+    for (int i = 0; i < 32; ++i) {
+      const int c = cb + 2 * i;
+      v[i] = (r < kw && c <= r) ? *reinterpret_cast<const double2 *>(src + 2 * i) : make_double2(0.0, 0.0);
+    }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = cb + 16 * b + 2 * i;
-        v[i] = (r < kw && c <= r) ? *reinterpret_cast<const double2 *>(src + 16 * b + 2 * i) : make_double2(0.0, 0.0);
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = cb + 16 * b + 2 * i;
-        Tm[r * TS + c] = (r < kw && c <= r) ? v[i].x : (r == c ? 1.0 : 0.0);
-        Tm[r * TS + c + 1] = (r < kw && c + 1 <= r) ? v[i].y : (r == c + 1 ? 1.0 : 0.0);
-      }
+    for (int i = 0; i < 32; ++i) {
+      const int c = cb + 2 * i;
+      *reinterpret_cast<double2 *>(Tm + r * TS + c) = make_double2((r < kw && c <= r) ? v[i].x : (r == c ? 1.0 : 0.0),
+                                                                   (r < kw && c + 1 <= r) ? v[i].y : (r == c + 1 ? 1.0 : 0.0));
     }
   }
   __syncthreads();
-  // Sums of the NEXT block column over all finished columns but the last sixteen, held by waves 1..3 (tile m of the
-  // block column in wave 1 + m % 3, slot m / 3): they are formed while wave 0 factors the current diagonal tile.
-  d4 ahead[3];
+  d4 D = (d4){0.0, 0.0, 0.0, 0.0};  // wave 0: the diagonal tile, D[reg] = tile[lk + 4 reg][lr] (both triangles)
+  if (w == 0) {
 #pragma unroll
-  for (int sl = 0; sl < 3; ++sl) ahead[sl] = (d4){0.0, 0.0, 0.0, 0.0};
-  for (int J = 0; J < NT; ++J) {
-    const int c0 = 16 * J;
-    // ---- 1. tiles (I, J), I >= J: minus the sum over the finished columns
-    if (J > 0) {
-      if (w > 0) {
-#pragma unroll
-        for (int sl = 0; sl < 3; ++sl) {
-          const int I = J + (w - 1) + 3 * sl;
-          if (I < NT) {
-            d4 acc = ahead[sl];
-            mfma_nt16(Tm + (16 * I + lr) * TS + lk, Tm + (c0 + lr) * TS + lk, c0 - 16, c0, acc);
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) Tm[(16 * I + lk + 4 * reg) * TS + c0 + lr] -= acc[reg];
-          }
-        }
-      }
-      __syncthreads();
+    for (int reg = 0; reg < 4; ++reg) {
+      const int i = lk + 4 * reg;
+      D[reg] = Tm[max(i, lr) * TS + min(i, lr)];
     }
-    // ---- 2. the diagonal tile: factored by wave 0, lane lr = row lr (the four rows of 16 lanes do the same); the others
-    //         sum ahead for block column J + 1
+  }
+  int bad = -1;
+  for (int J = 0; J < NT; ++J) {
+    const int c0 = 16 * J, c1 = c0 + 16;
     if (w == 0) {
-      double r[16];
-      {
-        const double2 *row = reinterpret_cast<const double2 *>(Tm + (c0 + lr) * TS + c0);
+      // ---- the 16 pivots of tile (J, J); Wt becomes the inverse of its factor
+      d4 Wt;  // rows i > j of the running inverse; a row is final when its pivot is done and is kept in wrow_done
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const double2 v = row[c];
-          r[2 * c] = v.x;
-          r[2 * c + 1] = v.y;
-        }
-      }
-      int bad = -1;
-      double ili = 1.0;  // 1 / L[lr][lr]
+      for (int reg = 0; reg < 4; ++reg) Wt[reg] = (lk + 4 * reg == lr) ? 1.0 : 0.0;
+      double lcol[4] = {0.0, 0.0, 0.0, 0.0};       // lcol[q] = L[lr][lk + 4 q]
+      double wrow_done[4] = {0.0, 0.0, 0.0, 0.0};  // wrow_done[q] = W[lk + 4 q][lr]
+      // The pivot of column j + 1 is taken from the tile as it was before column j left it, minus the square of that
+      // column's entry -- on the vector unit, so that the chain from pivot to pivot does not wait for the product.  The
+      // matrix unit takes one product at a time: the one for the inverse is issued in the middle of the next pivot's
+      // Newton steps, when the one for the tile has left the unit, so that the wave never waits to issue.
+      double d = lane_value(D[0], 0);
+      double below = 0.0, wrow = 0.0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const double d = bcast16(r[j], j);
-        if (!(d > 0.0) && bad < 0) bad = j;
+        const int jq = j >> 2, jk = j & 3;
+        if (!(d > 0.0) && bad < 0) bad = c0 + j;
         // 1 / sqrt(d): hardware estimate and two Newton steps (the IEEE square root and division are five times as
         // long, and the chain of pivots is the critical path of the whole factorisation)
         double y = __builtin_amdgcn_rsq(d);
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
+        {
           const double e = fma(-(d * y), y, 1.0);
           y = fma(0.5 * y, e, y);
         }
-        if (lr == j) ili = y;
-        const double lij = (lr > j) ? r[j] * y : (lr == j ? d * y : 0.0);
-        r[j] = lij;
-#pragma unroll
-        for (int c = j + 1; c < 16; ++c) r[c] = fma(-lij, bcast16(lij, c), r[c]);
-      }
-      if (lane == 0 && bad >= 0 && c0 + bad < kw) atomicMax(info, k0 + c0 + bad + 1);
-      if (lk == 0) {
-        double2 *lrow = reinterpret_cast<double2 *>(Tm + (c0 + lr) * TS + c0);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const int ca = 2 * c, cb = 2 * c + 1;
-          lrow[c] = make_double2(ca <= lr ? r[ca] : 0.0, cb <= lr ? r[cb] : 0.0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j > 0) Wt = __builtin_amdgcn_mfma_f64_16x16x4f64(-below, wrow, Wt, 0, 0, 0);  // rows i > j - 1 of W -= l_i (row j - 1 of W)
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          const double e = fma(-(d * y), y, 1.0);
+          y = fma(0.5 * y, e, y);
         }
-        Il[c0 + lr] = ili;
+        const double dj = D[jq];
+        // lanes 16 jk + j .. 16 jk + 15 hold entries j .. 15 of row j of the tile (= column j: it is symmetric) in register jq
+        const bool col = (unsigned)(lane - (16 * jk + j)) < (unsigned)(16 - j);
+        const bool row = (lane >> 4) == jk;
+        const double lrow = col ? dj * y : 0.0;  // column j of the factor (entry j: d y = sqrt(d))
+        if (j < 15) {
+          const int jn = j + 1;
+          const double ln = lane_value(dj, 16 * jk + jn) * y;  // entry j + 1 of the column: the lane read does not wait for y
+          d = fma(-ln, ln, lane_value(D[jn >> 2], 16 * (jn & 3) + jn));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (j < 15) D = __builtin_amdgcn_mfma_f64_16x16x4f64(-lrow, lrow, D, 0, 0, 0);  // tile -= l l^T
+        __builtin_amdgcn_sched_barrier(0);
+        wrow = row ? Wt[jq] * y : 0.0;  // row j of the inverse: final
+        below = (lr > j) ? lrow : 0.0;
+        lcol[jq] = row ? lrow : lcol[jq];
+        wrow_done[jq] = row ? wrow : wrow_done[jq];
       }
-    } else if (J + 1 < NT) {
+      // the inverse takes the tile's place in LDS; the factor's tile waits in a tile above the diagonal, which nothing reads
+      {
+        double *slot = Tm + (J < NT - 1 ? 0 : 16) * TS + (J < NT - 1 ? c1 : CB - 16);
 #pragma unroll
-      for (int sl = 0; sl < 3; ++sl) {
-        const int I = J + 1 + (w - 1) + 3 * sl;
-        ahead[sl] = (d4){0.0, 0.0, 0.0, 0.0};
-        if (I < NT) mfma_nt16(Tm + (16 * I + lr) * TS + lk, Tm + (c0 + 16 + lr) * TS + lk, 0, c0, ahead[sl]);
+        for (int q = 0; q < 4; ++q) slot[lr * TS + lk + 4 * q] = lcol[q];
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) Tm[(c0 + lk + 4 * reg) * TS + c0 + lr] = wrow_done[reg];
+    } else if (J > 0) {
+      const int first = J + 1 + ((w - 1) - (J + 1) % 3 + 3) % 3;  // this wave's first block row below J
+      // ---- block column J - 1 of the rows this wave owns: X = P W^T in place
+      const int cp = c0 - 16;
+      for (int I = first; I < NT; I += 3) {
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+        mfma_nt16(Tm + (16 * I + lr) * TS + cp + lk, Tm + (cp + lr) * TS + cp + lk, 0, 16, acc);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) Tm[(16 * I + lk + 4 * reg) * TS + cp + lr] = acc[reg];
+      }
+      wave_lds_sync();
+      // ---- their tiles of block column J, and the diagonal tile of row J + 1: minus the sums over the finished columns
+      for (int I = first; I < NT; I += 3) {
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+        mfma_nt16(Tm + (16 * I + lr) * TS + lk, Tm + (c0 + lr) * TS + lk, 0, c0, acc);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) Tm[(16 * I + lk + 4 * reg) * TS + c0 + lr] -= acc[reg];
+      }
+      if (first == J + 1 && first < NT) {
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+        mfma_nt16(Tm + (c1 + lr) * TS + lk, Tm + (c1 + lr) * TS + lk, 0, c0, acc);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) Tm[(c1 + lk + 4 * reg) * TS + c1 + lr] -= acc[reg];
       }
     }
-    __syncthreads();
-    // ---- 3. the rows below: x L^T = p by substitution, a lane per row (the tile of L comes as broadcast reads)
-    if (J + 1 < NT) {
-      const int row = c0 + 16 + t;
-      if (row < CB) {
-        double x[16];
-        double2 *prow = reinterpret_cast<double2 *>(Tm + row * TS + c0);
+    lds_barrier();
+    if (w == 0 && J + 1 < NT) {
+      // ---- block row J + 1 against the new tile, then its diagonal tile for the next round of pivots
+      d4 X = (d4){0.0, 0.0, 0.0, 0.0};
+      mfma_nt16(Tm + (c1 + lr) * TS + c0 + lk, Tm + (c0 + lr) * TS + c0 + lk, 0, 16, X);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const double2 v = prow[c];
-          x[2 * c] = v.x;
-          x[2 * c + 1] = v.y;
-        }
+      for (int reg = 0; reg < 4; ++reg) Tm[(c1 + lk + 4 * reg) * TS + c0 + lr] = X[reg];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const double *lrow = Tm + (c0 + c) * TS + c0;
-          double sdot = x[c];
-#pragma unroll
-          for (int k = 0; k < 16; ++k)
-            if (k < c) sdot = fma(-x[k], lrow[k], sdot);
-          x[c] = sdot * Il[c0 + c];
-        }
-#pragma unroll
-        for (int c = 0; c < 8; ++c) prow[c] = make_double2(x[2 * c], x[2 * c + 1]);
+      for (int reg = 0; reg < 4; ++reg) {
+        const int i = lk + 4 * reg;
+        D[reg] = Tm[(c1 + max(i, lr)) * TS + c1 + min(i, lr)];
       }
-      __syncthreads();
+      wave_lds_sync();
+      {
+        const double *xr = Tm + (c1 + lr) * TS + c0 + lk;
+        double xa[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xa[u] = xr[4 * u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) D = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[u], xa[u], D, 0, 0, 0);
+      }
     }
+    lds_barrier();
   }
+  if (t == 0 && bad >= 0 && bad < kw) atomicMax(info, k0 + bad + 1);
+  // the factor: below the diagonal tiles from where it stands, the diagonal tiles from where wave 0 left them
 #pragma unroll 8
   for (int e = t; e < CB * CB / 2; e += 256) {
     const int rr = e / (CB / 2), c = 2 * (e - rr * (CB / 2));
-    if (rr < kw && c <= rr) {
-      const double2 v = *reinterpret_cast<const double2 *>(Tm + rr * TS + c);
-      double *dst = A + (int64_t)(k0 + rr) * ld + k0 + c;
-      if (c + 1 <= rr) *reinterpret_cast<double2 *>(dst) = v;
+    if (rr < kw && c < (rr & ~15))
+      *reinterpret_cast<double2 *>(A + (int64_t)(k0 + rr) * ld + k0 + c) = *reinterpret_cast<const double2 *>(Tm + rr * TS + c);
+  }
+#pragma unroll
+  for (int e = t; e < CB * 8; e += 256) {
+    const int rr = e >> 3, c = 2 * (e & 7), tile = rr >> 4;  // row of the block, column inside its diagonal tile
+    if (rr < kw && c <= (rr & 15)) {
+      const double2 v = *reinterpret_cast<const double2 *>(Tm + ((tile < NT - 1 ? 0 : 16) + (rr & 15)) * TS + (tile < NT - 1 ? 16 * tile + 16 : CB - 16) + c);
+      double *dst = A + (int64_t)(k0 + rr) * ld + k0 + 16 * tile + c;
+      if (c + 1 <= (rr & 15)) *reinterpret_cast<double2 *>(dst) = v;
       else *dst = v.x;
     }
   }
-  __syncthreads();
-  // ---- inverse in place: the eight diagonal tiles first, one per row of 16 lanes of waves 0 and 1 (lane lr = row lr:
-  //      W[i][c] = (delta_ic - sum_{k = c}^{i-1} L[i][k] W[k][c]) / L[i][i], the finished rows handed down by row broadcasts)
-  if (w < 2) {
-    const int J = 4 * w + lk;
-    double2 *row = reinterpret_cast<double2 *>(Tm + (16 * J + lr) * TS + 16 * J);
-    double r[16], sacc[16];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const double2 v = row[c];
-      r[2 * c] = v.x;
-      r[2 * c + 1] = v.y;
-      sacc[2 * c] = sacc[2 * c + 1] = 0.0;
-    }
-    const double ili = Il[16 * J + lr];
-#pragma unroll
-    for (int k = 0; k < 15; ++k) {
-      const double lik = (lr > k) ? r[k] : 0.0;
-#pragma unroll
-      for (int c = 0; c <= k; ++c) {
-        const double mine = ili * ((lr == c ? 1.0 : 0.0) - sacc[c]);  // final in lane k: all its terms are in
-        sacc[c] = fma(lik, bcast16(mine, k), sacc[c]);
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int ca = 2 * c, cb = 2 * c + 1;
-      row[c] = make_double2(ca <= lr ? ili * ((lr == ca ? 1.0 : 0.0) - sacc[ca]) : 0.0,
-                            cb <= lr ? ili * ((lr == cb ? 1.0 : 0.0) - sacc[cb]) : 0.0);
-    }
-  }
-  __syncthreads();
+  // ---- inverse in place: the diagonal tiles hold their inverses already
   for (int s = 16; s < CB; s *= 2) {
     const int ts = s / 16, per = ts * ts, ntile = (CB / (2 * s)) * per;
     d4 acc[4];
