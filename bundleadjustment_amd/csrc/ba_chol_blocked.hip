@@ -423,53 +423,70 @@ __device__ __forceinline__ void chol_diag_block(double *__restrict__ A, int n, i
       else *dst = v.x;
     }
   }
-  // ---- inverse in place: the diagonal tiles hold their inverses already
+  // ---- inverse in place: the diagonal tiles hold their inverses already.  A level has 2 s x 2 s blocks of ts x ts tiles
+  //      each (ts = s / 16); a wave takes ts tiles of one block: for M = L21 W11 a tile row of L21 against all tile columns
+  //      of W11, for W21 = -W22 M all tile rows of W22 against a tile column of M -- so both products overwrite their own
+  //      operand only, and the tiles of a wave run as independent chains on the matrix unit.
   for (int s = 16; s < CB; s *= 2) {
-    const int ts = s / 16, per = ts * ts, ntile = (CB / (2 * s)) * per;
+    const int ts = s / 16, o = 2 * s * (w / ts), r = w % ts;
     d4 acc[4];
-    // M = L21 W11 (W11 lower triangular: k from the first row of the tile column on)
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      acc[m] = (d4){0.0, 0.0, 0.0, 0.0};
-      const int q = w + 4 * m;
-      if (q < ntile) {
-        const int o = 2 * s * (q / per), ti = (q % per) / ts, tj = q % ts;
-        mfma_nn16(Tm + (o + s + 16 * ti + lr) * TS + o + lk, Tm + (o + lk) * TS + o + 16 * tj + lr, 16 * tj, s, acc[m]);
-      }
+    for (int m = 0; m < 4; ++m) acc[m] = (d4){0.0, 0.0, 0.0, 0.0};
+    lds_barrier();
+    // M = L21 W11 (W11 lower triangular: tile column m from row 16 m on)
+    for (int k = 0; k < s; k += 16) {
+      double xa[4], xb[4][4];
+      const double *pa = Tm + (o + s + 16 * r + lr) * TS + o + k + lk;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xa[u] = pa[4 * u];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        if (m < ts && 16 * m <= k) {
+          const double *pb = Tm + (o + k + lk) * TS + o + 16 * m + lr;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) xb[m][u] = pb[4 * u * TS];
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (m < ts && 16 * m <= k) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u], xb[m][u], acc[m], 0, 0, 0);
     }
-    __syncthreads();
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int q = w + 4 * m;
-      if (q < ntile) {
-        const int o = 2 * s * (q / per), ti = (q % per) / ts, tj = q % ts;
+    for (int m = 0; m < 4; ++m)
+      if (m < ts) {
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) Tm[(o + s + 16 * ti + lk + 4 * reg) * TS + o + 16 * tj + lr] = acc[m][reg];
+        for (int reg = 0; reg < 4; ++reg) Tm[(o + s + 16 * r + lk + 4 * reg) * TS + o + 16 * m + lr] = acc[m][reg];
+        acc[m] = (d4){0.0, 0.0, 0.0, 0.0};
       }
-    }
-    __syncthreads();
-    // W21 = -W22 M (W22 lower triangular: k up to the last row of the tile row)
+    lds_barrier();
+    // W21 = -W22 M (W22 lower triangular: tile row m up to column 16 (m + 1))
+    for (int k = 0; k < s; k += 16) {
+      double xa[4][4], xb[4];
+      const double *pb = Tm + (o + s + k + lk) * TS + o + 16 * r + lr;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      acc[m] = (d4){0.0, 0.0, 0.0, 0.0};
-      const int q = w + 4 * m;
-      if (q < ntile) {
-        const int o = 2 * s * (q / per), ti = (q % per) / ts, tj = q % ts;
-        mfma_nn16(Tm + (o + s + 16 * ti + lr) * TS + o + s + lk, Tm + (o + s + lk) * TS + o + 16 * tj + lr, 0, 16 * (ti + 1), acc[m]);
+      for (int u = 0; u < 4; ++u) xb[u] = pb[4 * u * TS];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        if (m < ts && k < 16 * (m + 1)) {
+          const double *pa = Tm + (o + s + 16 * m + lr) * TS + o + s + k + lk;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) xa[m][u] = pa[4 * u];
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (m < ts && k < 16 * (m + 1)) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[m][u], xb[u], acc[m], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      if (m < ts) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) Tm[(o + s + 16 * m + lk + 4 * reg) * TS + o + 16 * r + lr] = -acc[m][reg];
       }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int q = w + 4 * m;
-      if (q < ntile) {
-        const int o = 2 * s * (q / per), ti = (q % per) / ts, tj = q % ts;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) Tm[(o + s + 16 * ti + lk + 4 * reg) * TS + o + 16 * tj + lr] = -acc[m][reg];
-      }
-    }
-    __syncthreads();
   }
+  lds_barrier();
 #pragma unroll 8
   for (int e = t; e < CB * CB / 2; e += 256) {
     const int rr = e / (CB / 2), c = 2 * (e - rr * (CB / 2));
