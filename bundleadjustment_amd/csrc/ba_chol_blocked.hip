@@ -581,28 +581,31 @@ __device__ __forceinline__ void front_tile_nt(const double *__restrict__ A, int 
   }
 }
 
-// rows below panel kp: X = A[rows, panel] W^T in place, 64 rows (all 128 columns: a workgroup owns its rows) per workgroup
+// rows below panel kp: X = A[rows, panel] W^T in place, RB rows (all 128 columns: a workgroup owns its rows) per workgroup.
+// RB = 32 where a level has so few rows that tiles of 64 leave most of the device idle: a tile then takes half as long.
+// (The same for the trailing update, tiles of 32 x 32, gains nothing: its tiles are bound by their loads and stores.)
+template <int RB>
 __global__ void __launch_bounds__(256, 2)
 k_front_trsm(const FrontDesc *__restrict__ fd, int kp) {
-  __shared__ double sA[KC * (64 + 16)], sB[KC * (CB + 16)];
+  __shared__ double sA[KC * (RB + 16)], sB[KC * (CB + 16)];
   const FrontDesc f = fd[blockIdx.y];
   const int k0 = CB * kp;
   if (k0 >= f.nvp) return;
-  const int r0 = k0 + CB + 64 * blockIdx.x;
+  const int r0 = k0 + CB + RB * blockIdx.x;
   if (r0 >= f.m) return;
-  d4 acc[2][4];
+  d4 acc[RB / 32][4];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < RB / 32; ++a)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
-  front_tile_nt<64, CB>(f.A + k0, f.ld, r0, f.m, f.W + (int64_t)kp * CB * CB, CB, 0, CB, sA, sB, acc);
+  front_tile_nt<RB, CB>(f.A + k0, f.ld, r0, f.m, f.W + (int64_t)kp * CB * CB, CB, 0, CB, sA, sB, acc);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 1, wc = w & 1, lr = lane & 15, lk = lane >> 4;
   double *C = f.A + k0;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < RB / 32; ++a)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const int r = r0 + 32 * wr + 16 * a + lk + 4 * reg;
+      const int r = r0 + (RB / 2) * wr + 16 * a + lk + 4 * reg;
       if (r >= f.m) continue;
 #pragma unroll
       for (int c = 0; c < 4; ++c) C[(int64_t)r * f.ld + 64 * wc + 16 * c + lr] = acc[a][c][reg];
@@ -876,7 +879,8 @@ void launch_front_panels(hipStream_t s, const FrontDesc *fd, int n_fronts, int n
     hipLaunchKernelGGL(k_front_diag, dim3(n_fronts), dim3(256), lds, s, fd, kp, info);
     const int T = (max_m - CB * kp - CB + 63) / 64;  // tiles of 64 rows below the panel, of the largest front
     if (T <= 0) continue;
-    hipLaunchKernelGGL(k_front_trsm, dim3(T, n_fronts), dim3(256), 0, s, fd, kp);
+    if (T * n_fronts <= 128) hipLaunchKernelGGL(k_front_trsm<32>, dim3(2 * T, n_fronts), dim3(256), 0, s, fd, kp);
+    else hipLaunchKernelGGL(k_front_trsm<64>, dim3(T, n_fronts), dim3(256), 0, s, fd, kp);
     hipLaunchKernelGGL(k_front_syrk, dim3(T * (T + 1) / 2, n_fronts), dim3(256), 0, s, fd, kp);
   }
 }
