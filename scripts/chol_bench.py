@@ -5,8 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bundleadjustment_amd import capi, host, solver
 
 PEAK = 78.6e12  # fp64 matrix peak of MI355X, flop/s
-cases = [("cfg1", dict()), ("cfg2", dict()),
-         ("8190", dict(n_cam=1, n_sta=1365, n_pts=40000, rays_per_point=6, ap_free_mask=0, iop_free_mask=0))]
+cases = [("cfg1", dict()), ("cfg2", dict()), ("4000", dict(n_cam=1, n_sta=666, n_pts=20000, rays_per_point=6, ap_free_mask=0, iop_free_mask=0)),
+         ("8190", dict(n_cam=1, n_sta=1365, n_pts=40000, rays_per_point=6, ap_free_mask=0, iop_free_mask=0)),
+         ("30000", dict(n_cam=1, n_sta=5000, n_pts=100000, rays_per_point=6, ap_free_mask=0, iop_free_mask=0))]
 if len(sys.argv) > 1:
     cases = [c for c in cases if c[0] in sys.argv[1:]]
 for name, kw in cases:
