@@ -63,6 +63,7 @@ enum Scal {
   SC_COST = 0, SC_FIXED, SC_GMAX, SC_STEP2_SC, SC_CNORM2_SC, SC_MCC, SC_STEP2_P, SC_CNORM2_P, SC_CCOST, SC_XNORM2_SC,
   SC_XNORM2_P, SC_GMAX_P, SC_NOTPD_P, SC_GMAX_SC, SC_LS_DOT_P, SC_LS_DOT_SC, SC_LS_MAX_P, SC_LS_MAX_SC, SC_FLAGS,
   SC_CAMINFO,  // what the Cholesky of the camera block of the reduced system reports (0, or 1 + the failing column)
+  SC_SPINFO,   // what the sparse Cholesky of the reduced system reports, when its caller reads it with the step's scalars
   SC_COUNT = 32
 };
 
@@ -163,6 +164,7 @@ struct ba_problem {
   double *d_defl_b = nullptr, *d_r2 = nullptr;
   bool have_G = false;
   bool cam_info_pending = false;  // build_reduced has left the camera block's factorisation report in SC_CAMINFO
+  int cam_block_failed = 0;       // 1 + the column at which that factorisation broke down (the PCG cannot run then)
   bool defl_failed = false;       // the coarse-space matrix was not positive definite once: solves go without it
   // general explicit border (several cameras or many free camera parameters); null -> one probe per camera column
   double *d_Zc = nullptr, *d_part_cc = nullptr, *d_corner_gen = nullptr;
@@ -970,8 +972,10 @@ int linearize(ba_problem *p, const LmState &st) {
   BA_TRY(p->check_kernels());
   BA_TRY(p->read_scal());
   p->h_scal[SC_GMAX] = std::max(p->h_scal[SC_GMAX], std::max(p->h_scal[SC_GMAX_P], p->h_scal[SC_GMAX_SC]));
-  if (p->cam_info_pending && p->h_scal[SC_CAMINFO] != 0.0)
-    return fail(BA_ERR_NUMERIC, "camera block of the reduced system is not positive definite (column %d)", (int)p->h_scal[SC_CAMINFO] - 1);
+  // The factor of the camera block serves the PCG only (its preconditioner and coarse space): a break-down there is that
+  // solver's failure -- an invalid step, as a linear solver that fails is to the trust-region loop -- and nothing to the
+  // direct solvers, whose own factorisation of the whole reduced system finds the same columns.
+  p->cam_block_failed = (p->cam_info_pending && p->h_scal[SC_CAMINFO] != 0.0) ? (int)p->h_scal[SC_CAMINFO] : 0;
   unsigned flag = (unsigned)p->h_scal[SC_FLAGS];
   if (p->ar && p->h_scal[SC_NOTPD_P] != 0.0 && !flag) flag = 1u;  // another rank's point block
   if (flag) {
@@ -1122,6 +1126,8 @@ bool row_sharding_pays(const ba_problem *p, int nbs) {
 // only looks at the stopping flag once per batch.
 int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
   hipStream_t s = p->stream;
+  if (p->cam_block_failed)
+    return fail(BA_ERR_NUMERIC, "camera block of the reduced system is not positive definite (column %d)", p->cam_block_failed - 1);
   BsrCgArgs a{};
   a.S = p->S; a.ncam = p->ncam; a.rowptr = p->d_bsr_rowptr; a.col = p->d_bsr_col; a.val = p->d_bsr_val; a.Ssc = p->d_Ssc;
   a.Scc = p->d_Scc; a.Lcc = p->d_Sccinv; a.Minv = p->d_Minv; a.b = p->d_b; a.x = p->d_x; a.r = p->d_r; a.z = p->d_z; a.p = p->d_p;
@@ -1331,6 +1337,8 @@ int solve_pcg_explicit(ba_problem *p, const ba_options *opt, int *iters) {
 // block-Jacobi preconditioned conjugate gradients on the reduced system; solution in d_x
 int solve_pcg(ba_problem *p, const ba_options *opt, int *iters) {
   hipStream_t s = p->stream;
+  if (p->cam_block_failed)
+    return fail(BA_ERR_NUMERIC, "camera block of the reduced system is not positive definite (column %d)", p->cam_block_failed - 1);
   CgArgs ca{};
   ca.n = p->nr; ca.S = p->S; ca.ncam = p->ncam; ca.b = p->d_b; ca.Minv = p->d_Minv; ca.Lcc = p->d_Lcc; ca.Ssc = p->d_Ssc;
   ca.Scc = p->d_Scc; ca.d2_sta = p->d_d2_sta; ca.x = p->d_x; ca.r = p->d_r; ca.z = p->d_z; ca.p = p->d_p; ca.q = p->d_q;
@@ -1417,8 +1425,10 @@ int solve_dense(ba_problem *p, bool explicit_blocks) {
   return 0;
 }
 
-// Sparse direct solve of the block-sparse reduced system (its blocks carry the LM diagonal already)
-int solve_sparse(ba_problem *p) {
+// Sparse direct solve of the block-sparse reduced system (its blocks carry the LM diagonal already).  defer_report: the
+// factorisation's report is left in the scalar SC_SPINFO for the caller's next read-back instead of being waited for
+// here (a failed factorisation leaves a step that is not finite, which the caller tests anyway).
+int solve_sparse(ba_problem *p, bool defer_report = false) {
   hipStream_t s = p->stream;
   if (!p->sparse) {
     p->sparse = sparse_chol_create();
@@ -1438,6 +1448,10 @@ int solve_sparse(ba_problem *p) {
   sparse_chol_factor(p->sparse, s, p->d_bsr_val, p->d_Ssc, p->d_Scc, p->d_info);
   HIP_OK(hipMemsetAsync(p->d_x, 0, (size_t)p->nr * sizeof(double), s));  // stations outside the program keep a zero step
   sparse_chol_solve(p->sparse, s, p->d_b, p->d_x);
+  if (defer_report) {
+    launch_flag_to_scal(s, reinterpret_cast<const unsigned *>(p->d_info), p->d_scal, SC_SPINFO);
+    return p->check_kernels();
+  }
   int info = 0;
   HIP_OK(hipMemcpyAsync(&info, p->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
@@ -1942,7 +1956,7 @@ int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary,
     int lrc;
     if (linear_solver == BA_SOLVER_DENSE_SCHUR) lrc = solve_dense(p, use_explicit);
     else if (linear_solver == BA_SOLVER_SPARSE_SCHUR) {
-      lrc = solve_sparse(p);
+      lrc = solve_sparse(p, true);
       if (lrc == BA_ERR_UNSUPPORTED && auto_sparse) {  // no tree for this network (or no room for its fronts): the PCG after all
         p->sparse_failed = true;
         linear_solver = BA_SOLVER_PCG_SCHUR;
@@ -1966,6 +1980,7 @@ int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary,
       mcc = -p->h_scal[SC_MCC];
       it.step_norm = std::sqrt(p->h_scal[SC_STEP2_SC] + p->h_scal[SC_STEP2_P]);
       step_ok = std::isfinite(mcc) && std::isfinite(it.step_norm);
+      if (linear_solver == BA_SOLVER_SPARSE_SCHUR && p->h_scal[SC_SPINFO] != 0.0) step_ok = false;  // a pivot was not positive
     }
     it.t_solve_s = now_s() - t0;
     // ---- ComputeTrustRegionStep: the step is valid when the model predicts a decrease ----

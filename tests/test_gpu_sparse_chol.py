@@ -78,3 +78,30 @@ def test_a_network_without_block_form_is_refused():
             P.solve(_opt(capi.SOLVER_SPARSE_SCHUR, 2))
         except solver.BaError as e:
             assert e.code == capi.ERR_UNSUPPORTED
+
+
+def test_a_factorisation_that_breaks_down_is_an_invalid_step():
+    # All 16 additional parameters free with the reference's Gauss-Newton options: the radial monomials are numerically
+    # collinear, a pivot of the camera block is not positive (tests/test_oracle_solver.py).  The sparse solver's report comes
+    # back with the scalars of the step, not through a wait of its own: the step must still count as invalid, the radius
+    # shrink, and the solve end as the dense solver's and the oracle's do.
+    net = host.synth_config("cfg2", scale=0.025, ap_free_mask=host.AP_ALL16).net
+    res = {}
+    for ls in (capi.SOLVER_SPARSE_SCHUR, capi.SOLVER_DENSE_SCHUR, capi.SOLVER_PCG_SCHUR):
+        opt = solver.default_options()
+        opt.linear_solver = ls
+        with solver.Problem(net) as P:
+            res[ls] = P.solve(opt)
+    s, d = res[capi.SOLVER_SPARSE_SCHUR][4], res[capi.SOLVER_DENSE_SCHUR][4]
+    assert s["termination"] == capi.FAILURE and d["termination"] == capi.FAILURE
+    assert s["num_unsuccessful_steps"] == d["num_unsuccessful_steps"] == solver.default_options().max_num_consecutive_invalid_steps - 1
+    # (at which iteration a pivot first falls below zero is a matter of rounding: the factorisations eliminate in different orders)
+    assert all(r["step_is_valid"] == 0 for r in res[capi.SOLVER_SPARSE_SCHUR][5][-s["num_unsuccessful_steps"]:])
+    assert all(r["step_is_valid"] == 0 for r in res[capi.SOLVER_DENSE_SCHUR][5][-d["num_unsuccessful_steps"]:])
+    # the PCG cannot start without the factor of the camera block: the same end, by the same rule
+    g = res[capi.SOLVER_PCG_SCHUR][4]
+    assert g["termination"] == capi.FAILURE and g["num_unsuccessful_steps"] == s["num_unsuccessful_steps"]
+    # and the oracle (Ceres' loop restated) ends the same way
+    from oracle import py_oracle as po
+    o = po.solve(net, capi.default_options(capi.SOLVER_DENSE_SCHUR), po.SCHUR_DENSE)
+    assert o[4]["termination"] == capi.FAILURE and o[4]["num_unsuccessful_steps"] == s["num_unsuccessful_steps"]
