@@ -63,7 +63,7 @@ enum Scal {
   SC_COST = 0, SC_FIXED, SC_GMAX, SC_STEP2_SC, SC_CNORM2_SC, SC_MCC, SC_STEP2_P, SC_CNORM2_P, SC_CCOST, SC_XNORM2_SC,
   SC_XNORM2_P, SC_GMAX_P, SC_NOTPD_P, SC_GMAX_SC, SC_LS_DOT_P, SC_LS_DOT_SC, SC_LS_MAX_P, SC_LS_MAX_SC, SC_FLAGS,
   SC_CAMINFO,  // what the Cholesky of the camera block of the reduced system reports (0, or 1 + the failing column)
-  SC_SPINFO,   // what the sparse Cholesky of the reduced system reports, when its caller reads it with the step's scalars
+  SC_SPINFO,   // what the dense or sparse Cholesky of the reduced system reports, when its caller reads it with the step's scalars
   SC_COUNT = 32
 };
 
@@ -1410,13 +1410,17 @@ int factor_dense(ba_problem *p) {
   return 0;
 }
 
-int solve_dense(ba_problem *p, bool explicit_blocks) {
+int solve_dense(ba_problem *p, bool explicit_blocks, bool defer_report = false) {  // defer_report: as solve_sparse
   hipStream_t s = p->stream;
   BA_TRY(build_dense(p, explicit_blocks));
   BA_TRY(factor_dense(p));
   launch_copy(s, p->nr, p->d_b, p->d_x);
   if (p->dense_blocked) launch_chol_solve_blocked(s, p->d_Sdense, p->nr, p->dense_ld, p->d_cholW, p->d_x);
   else launch_chol_solve(s, p->d_Sdense, p->nr, p->d_x);
+  if (defer_report) {
+    launch_flag_to_scal(s, reinterpret_cast<const unsigned *>(p->d_info), p->d_scal, SC_SPINFO);
+    return p->check_kernels();
+  }
   int info = 0;
   HIP_OK(hipMemcpyAsync(&info, p->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
@@ -1427,7 +1431,8 @@ int solve_dense(ba_problem *p, bool explicit_blocks) {
 
 // Sparse direct solve of the block-sparse reduced system (its blocks carry the LM diagonal already).  defer_report: the
 // factorisation's report is left in the scalar SC_SPINFO for the caller's next read-back instead of being waited for
-// here (a failed factorisation leaves a step that is not finite, which the caller tests anyway).
+// here (a failed factorisation leaves a step that is not finite, which the caller tests anyway).  What the wait cost was
+// the copy of one int into pageable host memory: ~0.1 ms per LM iteration.
 int solve_sparse(ba_problem *p, bool defer_report = false) {
   hipStream_t s = p->stream;
   if (!p->sparse) {
@@ -1954,7 +1959,7 @@ int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary,
     }
     int lin_iters = 0;
     int lrc;
-    if (linear_solver == BA_SOLVER_DENSE_SCHUR) lrc = solve_dense(p, use_explicit);
+    if (linear_solver == BA_SOLVER_DENSE_SCHUR) lrc = solve_dense(p, use_explicit, true);
     else if (linear_solver == BA_SOLVER_SPARSE_SCHUR) {
       lrc = solve_sparse(p, true);
       if (lrc == BA_ERR_UNSUPPORTED && auto_sparse) {  // no tree for this network (or no room for its fronts): the PCG after all
@@ -1980,7 +1985,8 @@ int ba_solve_resident(ba_problem *p, const ba_options *opt, ba_summary *summary,
       mcc = -p->h_scal[SC_MCC];
       it.step_norm = std::sqrt(p->h_scal[SC_STEP2_SC] + p->h_scal[SC_STEP2_P]);
       step_ok = std::isfinite(mcc) && std::isfinite(it.step_norm);
-      if (linear_solver == BA_SOLVER_SPARSE_SCHUR && p->h_scal[SC_SPINFO] != 0.0) step_ok = false;  // a pivot was not positive
+      if ((linear_solver == BA_SOLVER_SPARSE_SCHUR || linear_solver == BA_SOLVER_DENSE_SCHUR) && p->h_scal[SC_SPINFO] != 0.0)
+        step_ok = false;  // a pivot was not positive
     }
     it.t_solve_s = now_s() - t0;
     // ---- ComputeTrustRegionStep: the step is valid when the model predicts a decrease ----
