@@ -310,42 +310,40 @@ __device__ __forceinline__ void chol_diag_block(double *__restrict__ A, int n, i
       // column's entry -- on the vector unit, so that the chain from pivot to pivot does not wait for the product.  The
       // matrix unit takes one product at a time: the one for the inverse is issued in the middle of the next pivot's
       // Newton steps, when the one for the tile has left the unit, so that the wave never waits to issue.
+      // Only the first operand of a product is masked (lanes 16 jk + j .. 16 jk + 15: entries j .. 15 of column j): where it
+      // is zero the second operand does not matter, and what the products then do to columns < j of the tile and to row j
+      // of the running inverse is never read again.
       double d = lane_value(D[0], 0);
-      double below = 0.0, wrow = 0.0;
+      double nl = 0.0, wrow = 0.0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int jq = j >> 2, jk = j & 3;
         if (!(d > 0.0) && bad < 0) bad = c0 + j;
-        // 1 / sqrt(d): hardware estimate and two Newton steps (the IEEE square root and division are five times as
-        // long, and the chain of pivots is the critical path of the whole factorisation)
+        // 1 / sqrt(d): hardware estimate and two Newton steps y <- y + y (1/2 - (d/2) y^2) (the IEEE square root and
+        // division are five times as long, and the chain of pivots is the critical path of the whole factorisation)
+        const double hd = 0.5 * d;
         double y = __builtin_amdgcn_rsq(d);
-        {
-          const double e = fma(-(d * y), y, 1.0);
-          y = fma(0.5 * y, e, y);
-        }
+        y = fma(y, fma(-(hd * y), y, 0.5), y);
         __builtin_amdgcn_sched_barrier(0);
-        if (j > 0) Wt = __builtin_amdgcn_mfma_f64_16x16x4f64(-below, wrow, Wt, 0, 0, 0);  // rows i > j - 1 of W -= l_i (row j - 1 of W)
+        if (j > 0) Wt = __builtin_amdgcn_mfma_f64_16x16x4f64(nl, wrow, Wt, 0, 0, 0);  // rows i >= j - 1 of W -= l_i (row j - 1 of W)
         __builtin_amdgcn_sched_barrier(0);
-        {
-          const double e = fma(-(d * y), y, 1.0);
-          y = fma(0.5 * y, e, y);
-        }
+        y = fma(y, fma(-(hd * y), y, 0.5), y);
         const double dj = D[jq];
-        // lanes 16 jk + j .. 16 jk + 15 hold entries j .. 15 of row j of the tile (= column j: it is symmetric) in register jq
+        // these 16 lanes hold row j of the tile (= column j: it is symmetric) in register jq
         const bool col = (unsigned)(lane - (16 * jk + j)) < (unsigned)(16 - j);
         const bool row = (lane >> 4) == jk;
-        const double lrow = col ? dj * y : 0.0;  // column j of the factor (entry j: d y = sqrt(d))
+        const double t = dj * y;  // in those lanes: column j of the factor (entry j: d y = sqrt(d)), rubbish above the diagonal
+        nl = col ? -t : 0.0;
         if (j < 15) {
           const int jn = j + 1;
           const double ln = lane_value(dj, 16 * jk + jn) * y;  // entry j + 1 of the column: the lane read does not wait for y
           d = fma(-ln, ln, lane_value(D[jn >> 2], 16 * (jn & 3) + jn));
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (j < 15) D = __builtin_amdgcn_mfma_f64_16x16x4f64(-lrow, lrow, D, 0, 0, 0);  // tile -= l l^T
+        if (j < 15) D = __builtin_amdgcn_mfma_f64_16x16x4f64(nl, t, D, 0, 0, 0);  // tile -= l l^T
         __builtin_amdgcn_sched_barrier(0);
-        wrow = row ? Wt[jq] * y : 0.0;  // row j of the inverse: final
-        below = (lr > j) ? lrow : 0.0;
-        lcol[jq] = row ? lrow : lcol[jq];
+        wrow = Wt[jq] * y;  // in those lanes: row j of the inverse, final
+        lcol[jq] = row ? t : lcol[jq];
         wrow_done[jq] = row ? wrow : wrow_done[jq];
       }
       // the inverse takes the tile's place in LDS; the factor's tile waits in a tile above the diagonal, which nothing reads
