@@ -175,7 +175,7 @@ def main():
     ap.add_argument("--pcg-rtol", type=float, default=1e-12, help="PCG stopping tolerance; 1e-12 is what the parity tests use")
     ap.add_argument("--solver", choices=("auto", "pcg", "sparse"), default="auto",
                     help="reduced solve of the networks beyond the dense limit: what BA_SOLVER_AUTO picks (the sparse direct "
-                         "Cholesky up to order 100 000, the PCG beyond), or one of the two by name")
+                         "Cholesky up to order 250 000, the PCG beyond), or one of the two by name")
     ap.add_argument("--cpu-scale", type=float, default=0.02, help="size of the CPU-baseline sample relative to the config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full-budget", type=float, default=90.0,

@@ -77,7 +77,7 @@ SOLVER_PCG_IMPLICIT = 2
 SOLVER_AUTO = 3
 SOLVER_SPARSE_SCHUR = 4
 AUTO_DENSE_ORDER = 4096
-AUTO_SPARSE_ORDER = 100000
+AUTO_SPARSE_ORDER = 250000
 CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
 ERR_INVALID, ERR_DEVICE, ERR_NUMERIC, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -4, -5
 STOP_REASONS = {0: "none", 1: "max_iterations", 2: "gradient_tol", 3: "parameter_tol",

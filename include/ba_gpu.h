@@ -74,7 +74,7 @@ enum ba_linear_solver {
                                  block-sparse form (BA_ERR_UNSUPPORTED otherwise). */
 };
 #define BA_AUTO_DENSE_ORDER 4096
-#define BA_AUTO_SPARSE_ORDER 100000
+#define BA_AUTO_SPARSE_ORDER 250000
 
 typedef struct {
   int32_t n_obs; /* rows of the .pho file  */

@@ -152,7 +152,7 @@ def test_default_options_pick_the_solver_by_size():
     assert g[4]["final_cost"] == explicit[4]["final_cost"]
     pcg = gpu_solve(large, options(capi.SOLVER_PCG_SCHUR))
     assert pcg[4]["total_linear_iterations"] > 0 and abs(pcg[4]["final_cost"] - g[4]["final_cost"]) <= 1e-9 * g[4]["final_cost"]
-    huge = host.synth(n_cam=1, n_sta=17000, n_pts=90000, rays_per_point=4, seed=3).net
+    huge = host.synth(n_cam=1, n_sta=42000, n_pts=200000, rays_per_point=4, seed=3).net
     assert 6 * huge.n_sta > capi.AUTO_SPARSE_ORDER
     opt2 = solver.default_options()
     opt2.max_num_iterations = 2
