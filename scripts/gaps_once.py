@@ -1,4 +1,5 @@
-"""Idle time of the device inside one LM iteration: gaps between consecutive kernels (any queue) from a kernel trace."""
+"""Idle time of the device over a stretch of a kernel trace (between two launches of k_point_elim near the end of the run):
+gaps between consecutive kernels on any queue.  10M network under bench.py: 0.6 ms idle in 61 ms, the largest gap 63 us."""
 import csv, glob, sys
 d = sys.argv[1]
 f = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[-1]
@@ -14,6 +15,6 @@ for r in rows[i0:i1]:
         gaps.append(((s - busy_end) / 1e3, (busy_end - t0) / 1e3, r["Kernel_Name"][:50]))
     busy_end = max(busy_end, e)
 total = (int(rows[i1]["Start_Timestamp"]) - t0) / 1e3
-print("iteration %.1f us, idle %.1f us in %d gaps" % (total, sum(g[0] for g in gaps), len(gaps)))
+print("stretch %.1f us, idle %.1f us in %d gaps" % (total, sum(g[0] for g in gaps), len(gaps)))
 for g in sorted(gaps, reverse=True)[:15]:
     print("  gap %7.1f us at %8.1f before %s" % g)
