@@ -1,7 +1,7 @@
 """Cost of the first solve of a problem (the sparse solver's tree or the PCG hierarchy is built then) against later ones:
     python scripts/first_solve.py cfg4   ->  10M network: first one-iteration solve 0.030 s, later ones 0.016 s; 50M network (PCG): 0.205 / 0.069 s."""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bundleadjustment_amd import capi, host, solver
 net = host.synth_config(sys.argv[1] if len(sys.argv) > 1 else "cfg4").net
 t0 = time.perf_counter()
