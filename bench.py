@@ -385,7 +385,7 @@ def main():
 
     # What N GPUs can do with this network, from this run's own measurements (N = 1: measured; N > 1: the work that
     # divides is this rank's share times N).  Points and their observations are divided; the reduced solve runs on
-    # every rank (multi-GPU); four sums over the ranks per LM iteration, of which one is large.
+    # every rank on the summed system; four sums over the ranks per LM iteration, of which one is large.
     lin_ms = 1e3 * sum(r["t_linearize_s"] for r in rows[1:]) / max(len(rows) - 1, 1)
     solve_ms = 1e3 * sum(r["t_solve_s"] + r["t_eval_s"] for r in rows[1:]) / max(len(rows) - 1, 1)
     pcg_ms = 1e3 * ktime[14] if sparse else 1e3 * ktime[5] * lin_iters / args.steps
